@@ -1,0 +1,212 @@
+/*
+ * lgd_hip.h — C ABI of liblgd_hip.so: the hand-written gfx950 (MI355X) kernels of the
+ * LMD / LMD+ stage-2 denoising hot path.
+ *
+ * The reference (TonyLianLong/LLM-groundedDiffusion) is pure Python on PyTorch; it has no FFI of
+ * its own.  Each entry point below therefore replaces a *PyTorch op sequence* of the reference and
+ * cites it (file:line under the reference root).  The ctypes binding a maintainer would add is
+ * llm-groundeddiffusion_amd/_lib.py.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the parameter is documented "host";
+ *  - activations / weights are IEEE fp16 (`_Float16`), statistics / biases / losses fp32;
+ *  - feature maps are channels-last: [B][H*W][C] row-major ("NHWC"); the UNet boundary tensors
+ *    (latents in, noise prediction out) are NCHW fp32 exactly as the reference passes them;
+ *  - no allocation, no synchronisation, no host<->device copy inside any call: every output and
+ *    workspace is caller-allocated; kernels are enqueued on `stream` (a hipStream_t passed as
+ *    void*) and the call returns immediately — all calls are hipGraph-capturable;
+ *  - return value: 0 on success, negative LGD_ERR_* otherwise (the Python side raises RuntimeError,
+ *    the error convention of the reference's plugin boundary: generate.py:391-396).
+ */
+#ifndef LGD_HIP_H
+#define LGD_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGD_ABI_VERSION 1
+int lgd_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM / implicit-GEMM convolution on MFMA (v_mfma_f32_16x16x32_f16).
+ *   C[m][n] = epilogue( sum_k A(m,k) * W[n][k] )
+ * Replaces: nn.Linear / nn.Conv2d calls of the UNet — attention_processor.py:338-363,426-453
+ * (to_q/to_k/to_v/to_out), attention.py:286-289,333-335 (FeedForward/GEGLU), transformer_2d.py:
+ * 283-291,319-325 (proj_in/proj_out), [ext diffusers 0.18.0] ResnetBlock2D conv1/conv2/
+ * conv_shortcut, Downsample2D, Upsample2D (call sites unet_2d_blocks.py:186-197,315-326,360-362,
+ * 577-588,621), and their input-gradient (dgrad) forms used by pipelines.py:56.
+ *
+ * A operand ("taps" = 1: plain rows; "taps" = 9: 3x3 gather, zero padding 1):
+ *   A(m,k): k -> (tap, c) with c in [0, c0+c1); c < c0 reads source a0 else a1 (channel concat of
+ *   two feature maps without materialising torch.cat, unet_2d_blocks.py:646-649);
+ *   taps=9: m -> (b, oy, ox) over hout*wout; input pixel (oy*stride+ky-1, ox*stride+kx-1); with
+ *   ups=1 the logical input is the nearest-2x upsampling of the stored hin*win map; with ups=2
+ *   it is the zero-inserted map (data at even coordinates only: dgrad of a stride-2 conv).
+ * Epilogue (in this order): +bias[n] +bias2[n]; GEGLU pairs (value, gate) column blocks of 16 and
+ * emits value*gelu(gate) (N/2 output columns); *alpha; +res[m][n]; store fp16 (or fp32).
+ * ------------------------------------------------------------------------------------------- */
+#define LGD_EPI_GEGLU 1   /* weights/bias rows packed [16 value | 16 gate] blocks               */
+#define LGD_EPI_OUT_F32 2 /* C is fp32                                                           */
+#define LGD_EPI_RES_F32 4 /* res is fp32                                                         */
+
+typedef struct LgdGemmDesc {
+  const void* a0;
+  const void* a1;
+  int64_t lda0, lda1; /* row (pixel) stride of each source, elements                       */
+  int32_t c0, c1;     /* channels taken from a0 / a1; K = taps*(c0+c1)                      */
+  int32_t taps;       /* 1 or 9                                                             */
+  int32_t hin, win, hout, wout, stride, ups;
+  const void* w;      /* [N][K] fp16                                                        */
+  int64_t ldw;
+  int32_t M, N, K;
+  int32_t nb_o, nb_i; /* batch = nb_o*nb_i problems (e.g. image x head)                     */
+  int64_t a_bs_o, a_bs_i, w_bs_o, w_bs_i, c_bs_o, c_bs_i, r_bs_o, r_bs_i;
+  const float* bias;  /* [N] or NULL                                                        */
+  const float* bias2; /* [N] or NULL (time-embedding projection of the current step)        */
+  const void* res;    /* [M][ldr] or NULL                                                   */
+  int64_t ldr;
+  float alpha;
+  int32_t epi;
+  void* c;
+  int64_t ldc;
+  int32_t splits;     /* split-K factor (>=1); >1 needs ws                                  */
+  float* ws;          /* fp32 [batch][splits][M][N]                                         */
+  int32_t tile;       /* 0 auto; else 1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64, 5: 32x128 */
+} LgdGemmDesc;
+
+int lgd_gemm_f16(const LgdGemmDesc* desc /* host */, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * conv_in: latents NCHW fp32 (B,4,L,L) -> [B][L*L][Cout] fp16, 3x3 pad 1 (unet_2d_condition.py:860)
+ * w: [Cout][3][3][Cin] fp16, bias fp32.
+ * ------------------------------------------------------------------------------------------- */
+int lgd_conv_in_f16(const float* x_nchw, const void* w, const float* bias, void* y, int B, int Cin,
+                    int L, int Cout, void* stream);
+/* conv_out: [B][L*L][Cin] fp16 (already GroupNorm+SiLU'd) -> NCHW fp32 (B,Cout,L,L), times
+ * out_scale (unet_2d_condition.py:972-975).  w: [Cout][3][3][Cin] fp16.  Called with the
+ * flipped/transposed conv_in weights it is also conv_in's input gradient (the latent gradient of
+ * pipelines.py:56; out_scale then undoes the fp16 gradient scaling). */
+int lgd_conv_out_f16(const void* x, const void* w, const float* bias, float* y_nchw, int B, int Cin,
+                     int L, int Cout, float out_scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GroupNorm (+SiLU) over channels-last maps, two launches: statistics then apply.
+ * Replaces [ext] ResnetBlock2D norm1/norm2 + nonlinearity, transformer_2d.py:283 (eps 1e-6, no
+ * SiLU) and unet_2d_condition.py:972-974.  x may be the channel concat of two maps (x0: c0
+ * channels, x1: c1 channels).  part: fp32 workspace [B][nchunk][G][2]; stats: fp32 [B][G][2]
+ * (mean, rstd) written by apply for the backward pass.
+ * ------------------------------------------------------------------------------------------- */
+int lgd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, int B, int HW, int G,
+                      float eps, const float* gamma, const float* beta, int silu, void* y,
+                      float* part, int nchunk, float* stats, void* stream);
+/* backward of the above w.r.t. x: gy [B][HW][C] -> gx0 (c0 channels, row stride c0) and gx1.
+ * accumulate!=0 adds into gx (gradient fan-in). */
+int lgd_groupnorm_bwd_f16(const void* gy, const void* x0, const void* x1, int c0, int c1, int B,
+                          int HW, int G, const float* gamma, const float* beta, int silu,
+                          const float* stats, void* gx0, void* gx1, float* part, int nchunk,
+                          int accumulate, void* stream);
+
+/* LayerNorm over the last dim (attention.py:185,206,223; GatedSelfAttentionDense norm1/norm2
+ * attention.py:35-36,50-51). rows x C, C % 8 == 0. y row stride ldy (lets the fuser write visual
+ * tokens into the [S+30] concat buffer). stats [rows][2] (mean, rstd) optional. */
+int lgd_layernorm_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int rows, int C, float eps,
+                      const float* gamma, const float* beta, float* stats, int rows_per_batch,
+                      int64_t x_bs, int64_t y_bs, void* stream);
+int lgd_layernorm_bwd_f16(const void* gy, int64_t ldgy, const void* x, int64_t ldx, void* gx,
+                          int64_t ldgx, int rows, int C, const float* gamma, const float* stats,
+                          int rows_per_batch, int64_t gy_bs, int64_t x_bs, int64_t gx_bs,
+                          int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Scaled-dot-product attention, flash style (online softmax, K/V tiles staged in LDS, MFMA for
+ * QK^T and PV).  Replaces F.scaled_dot_product_attention at attention_processor.py:355-357 and
+ * the baddbmm/softmax/bmm path at :201-233,447 when no map is requested.
+ *   q: [B][Sq][H*d] view with row stride ldq (so a fused QKV buffer can be passed), k/v likewise.
+ *   o: [B][Sq][H*d] fp16.  lse (optional): fp32 [B][H][Sq] = log2-domain log-sum-exp, for backward.
+ * ------------------------------------------------------------------------------------------- */
+int lgd_attn_fwd_f16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk,
+                     int64_t k_bs, const void* v, int64_t ldv, int64_t v_bs, void* o, int64_t ldo,
+                     int64_t o_bs, float* lse, int B, int H, int Sq, int Sk, int d, float scale,
+                     void* stream);
+/* backward: given q,k,v,o,do,lse -> dq,dk,dv (fp16, same views). delta: fp32 ws [B][H][Sq]. */
+int lgd_attn_bwd_f16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk,
+                     int64_t k_bs, const void* v, int64_t ldv, int64_t v_bs, const void* o,
+                     int64_t ldo, int64_t o_bs, const void* go, int64_t ldgo, int64_t go_bs,
+                     const float* lse, float* delta, void* gq, int64_t ldgq, int64_t gq_bs, void* gk,
+                     int64_t ldgk, int64_t gk_bs, void* gv, int64_t ldgv, int64_t gv_bs, int B, int H,
+                     int Sq, int Sk, int d, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Cross-attention over the 77 text tokens with probability-map capture — the hook of
+ * attention_processor.py:426-480 (slow path).  Whole K/V of a head lives in LDS.
+ *   probs (optional): fp32 [Bp][H][Sq][Tp] where, following :466-476,
+ *     tok < 0  : all Sk columns are stored (Tp = Sk)
+ *     tok >= 0 : only column `tok` (Tp = 1)                      (return_token_ca_only=int)
+ *     cond_only: only batch items b >= B/2 are stored (Bp = B/2) (return_cond_ca_only)
+ * ------------------------------------------------------------------------------------------- */
+int lgd_cross_attn_fwd_f16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk,
+                           int64_t k_bs, const void* v, int64_t ldv, int64_t v_bs, void* o,
+                           int64_t ldo, int64_t o_bs, float* probs, int tok, int cond_only, int B,
+                           int H, int Sq, int Sk, int d, float scale, void* stream);
+/* backward w.r.t. q only (text K/V are constants of the run): recomputes P; takes the upstream
+ * gradient on the output (go, may be NULL) and on the probability map (gp fp32 [B][H][Sq][Sk], may
+ * be NULL) — the map is an output with its own gradient (guidance.py:244-286 via pipelines.py:56). */
+int lgd_cross_attn_bwd_f16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk,
+                           int64_t k_bs, const void* v, int64_t ldv, int64_t v_bs, const void* go,
+                           int64_t ldgo, int64_t go_bs, const float* gp, void* gq, int64_t ldgq,
+                           int64_t gq_bs, int B, int H, int Sq, int Sk, int d, float scale,
+                           void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Elementwise pieces.
+ * ------------------------------------------------------------------------------------------- */
+/* GEGLU backward (attention.py:333-335): h = proj(x) packed [16 value|16 gate] blocks, width 2*n;
+ * gy [rows][n] -> gh [rows][2n] in the same packed layout. */
+int lgd_geglu_bwd_f16(const void* h, const void* gy, void* gh, int64_t rows, int n, void* stream);
+/* y = a + b (fp16), n elements (gradient fan-in / residual). */
+int lgd_add_f16(const void* a, const void* b, void* y, int64_t n, void* stream);
+/* y = alpha * x (fp16) */
+int lgd_scale_f16(const void* x, void* y, float alpha, int64_t n, void* stream);
+/* sum over the 2x2 children of a nearest-2x upsampling: gy [B][2H*2W][C] -> gx [B][H*W][C] */
+int lgd_upsample2x_bwd_f16(const void* gy, void* gx, int B, int H, int W, int C, void* stream);
+
+/* Classifier-free guidance + DDIM (eta=0) step + frozen-mask blend + latent history in one pass
+ * (pipelines.py:436-453; [ext] DDIMScheduler.step).  eps: NCHW fp32 (2B,C,L,L) = [uncond; cond].
+ *   e = eu + gs*(ec-eu); epsilon or v prediction; x0 = (x - sqrt(1-a_t) e)/sqrt(a_t);
+ *   x' = sqrt(a_p) x0 + sqrt(1-a_p) e;
+ *   if step < frozen_steps: x' = frozen_ref[step+1]*mask + x'*(1-mask)   (mask [B][HW] fp32)
+ *   hist[step+1] = x'  (save_all_latents) when hist != NULL
+ * coef_table: device fp32 [T][4] = {a_t, a_prev, guidance_scale, v_prediction flag}; the step is
+ * read from the device int32 *step_idx so that a captured hipGraph can be replayed for every step. */
+int lgd_cfg_ddim_step_f32(const float* eps, const float* x, float* x_out, const float* coef_table,
+                          const int32_t* step_idx, const float* frozen_ref, const float* mask,
+                          int frozen_steps, float* hist, int B, int C, int HW, void* stream);
+/* guidance latent update (pipelines.py:60-69): x -= coef_table[*step_idx][col] * g */
+int lgd_axpy_f32(const float* g, float* x, const float* coef_table, const int32_t* step_idx, int col,
+                 int64_t n, void* stream);
+/* copy row `*idx` (device int32) of a [T][n] fp32 table into out[n] — per-step time-embedding
+ * bias of every resnet without changing any kernel argument (graph-replay friendly). */
+int lgd_select_row_f32(const float* table, const int32_t* idx, float* out, int n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Cross-attention energy of LMD / LMD+ and its gradient on the probability maps, one launch for
+ * all (key, object, token, head) items: utils/guidance.py:91-148 (max-based fg/bg top-k box loss),
+ * :150-242 (reference-attention L1 transfer), :244-286 (compute_ca_lossv3), times loss_scale
+ * (pipelines.py:48).
+ *   items: int32 [n_items][8] = {map_id, kind(0 topk, 1 ref), token, mask_id, k_fg, k_bg, ref_id, 0}
+ *   coefs: fp32  [n_items][4] = {fg_coef, bg_coef, ref_coef, 0} (all normalisations folded in)
+ *   maps:  device array of n_maps pointers to fp32 [H][HW][T]; gmaps likewise (pre-zeroed) or NULL
+ *   map_hw: int32[n_maps]; masks: fp32 [n_masks][max_hw] (1 inside the box); refs: fp32
+ *   [n_refs][H][max_hw] reference maps R_b (guidance.py:201)
+ *   partial: fp32 [n_items*H] workspace; loss: fp32[1] = sum of all terms.
+ * ------------------------------------------------------------------------------------------- */
+int lgd_ca_energy_f32(const float* const* maps, float* const* gmaps, const int32_t* map_hw,
+                      const int32_t* items, const float* coefs, const float* masks, const float* refs,
+                      int n_items, int H, int T, int max_hw, float* partial, float* loss,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LGD_HIP_H */

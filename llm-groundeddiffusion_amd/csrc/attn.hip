@@ -1,0 +1,352 @@
+// Flash-style scaled-dot-product attention for gfx950 — forward.
+//
+// Work decomposition: grid = (ceil(Sq/64), H, B); 4 waves per workgroup, each wave owns 16 query
+// rows; K/V are consumed in tiles of 64 keys staged in LDS (register-prefetched one tile ahead).
+//
+// MFMA layout trick (no LDS round trip for P): both products are issued transposed,
+//     S^T = K Q^T   (A := K rows,  B := Q rows)   -> lane holds query (lane&15), 4 keys per tile
+//     O^T = V^T P^T (A := V^T rows, B := P^T)      -> lane holds query (lane&15), 4 dv per tile
+// so the softmax statistics of a query live in the lanes {q, q+16, q+32, q+48} (two xor-shuffles
+// for the row max), the rescale factor is a per-lane scalar, and the S^T accumulators convert to
+// the P^T operand in registers.  The contraction index of the second MFMA is permuted the same way
+// on both operands: element j of lane group g is key 32c + (j<4 ? g*4+j : 16+g*4+j-4), which is
+// why V is staged transposed ([dv][key]) and read as two 8-byte pieces.
+//
+// SAVE_P variant (cross-attention map capture, attention_processor.py:440-480): two passes over
+// the keys — pass 1 row max / row sum, pass 2 normalised probabilities, which are written to the
+// fp32 map and fed to the PV product.
+#include "common.h"
+#include "../../include/lgd_hip.h"
+
+namespace {
+
+constexpr int KV_T = 64;         // keys per tile
+constexpr int VT_LD = KV_T + 8;  // halfs per row of the transposed V tile
+constexpr float NEG_BIG = -1.0e30f;
+
+struct AttnArgs {
+  const half_t* q; long ldq, q_bs;
+  const half_t* k; long ldk, k_bs;
+  const half_t* v; long ldv, v_bs;
+  half_t* o; long ldo, o_bs;
+  float* lse;
+  float* probs; int tok; int cond_only;
+  int B, H, Sq, Sk, d;
+  float scale_log2;  // scale * log2(e)
+};
+
+template <int DP, bool SAVE_P>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+  constexpr int K_LD = DP + 8;
+  constexpr int NDC = DP / 32;  // 32-wide chunks of the head dim (QK^T contraction)
+  constexpr int NDT = DP / 16;  // 16-row tiles of dv (O^T rows)
+  constexpr int KSEG = DP / 8;  // 16-byte segments per K row
+  constexpr int K_IT = (KV_T * KSEG + 255) / 256;
+  constexpr int V_ITEMS = (KV_T / 2) * KSEG;  // (key pair, segment)
+  constexpr int V_IT = (V_ITEMS + 255) / 256;
+
+  __shared__ __attribute__((aligned(16))) half_t smem[KV_T * K_LD + DP * VT_LD];
+  half_t* Ks = smem;
+  half_t* Vt = smem + KV_T * K_LD;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 64 + wid * 16;
+  const int d = a.d;
+  const half_t* Qb = a.q + (long)b * a.q_bs + (long)h * d;
+  const half_t* Kb = a.k + (long)b * a.k_bs + (long)h * d;
+  const half_t* Vb = a.v + (long)b * a.v_bs + (long)h * d;
+
+  // ---- Q fragments (B operand of S^T): lane -> query c16, head-dim elements dc*32 + g*8..+8
+  half8_t qf[NDC];
+  {
+    const int qrow = q0 + c16;
+#pragma unroll
+    for (int dc = 0; dc < NDC; ++dc) {
+      const int dd = dc * 32 + g * 8;
+      if (qrow < a.Sq && dd < d)
+        qf[dc] = *reinterpret_cast<const half8_t*>(Qb + (long)qrow * a.ldq + dd);
+      else
+        qf[dc] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+
+  uint4 k_reg[K_IT], v_reg[V_IT][2];
+  auto load_tile = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < K_IT; ++i) {
+      int idx = tid + i * 256;
+      int row = idx / KSEG, seg = idx - row * KSEG;
+      bool ok = (idx < KV_T * KSEG) && (kv0 + row < a.Sk) && (seg * 8 < d);
+      k_reg[i] = ok ? *reinterpret_cast<const uint4*>(Kb + (long)(kv0 + row) * a.ldk + seg * 8)
+                    : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < V_IT; ++i) {
+      int idx = tid + i * 256;
+      int pair = idx & 31, seg = idx >> 5;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        int row = pair * 2 + r;
+        bool ok = (idx < V_ITEMS) && (kv0 + row < a.Sk) && (seg * 8 < d);
+        v_reg[i][r] = ok ? *reinterpret_cast<const uint4*>(Vb + (long)(kv0 + row) * a.ldv + seg * 8)
+                         : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < K_IT; ++i) {
+      int idx = tid + i * 256;
+      if (idx < KV_T * KSEG) {
+        int row = idx / KSEG, seg = idx - row * KSEG;
+        *reinterpret_cast<uint4*>(Ks + row * K_LD + seg * 8) = k_reg[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < V_IT; ++i) {
+      int idx = tid + i * 256;
+      if (idx < V_ITEMS) {
+        int pair = idx & 31, seg = idx >> 5;
+        const half_t* e0 = reinterpret_cast<const half_t*>(&v_reg[i][0]);
+        const half_t* e1 = reinterpret_cast<const half_t*>(&v_reg[i][1]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          half2_t pr = {e0[e], e1[e]};
+          *reinterpret_cast<half2_t*>(Vt + (seg * 8 + e) * VT_LD + pair * 2) = pr;
+        }
+      }
+    }
+  };
+
+  // S^T for the current LDS tile, scaled to the log2 domain and masked.
+  auto compute_s = [&](int kv0, f32x4 (&s)[4]) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dc = 0; dc < NDC; ++dc) {
+        half8_t kf =
+            *reinterpret_cast<const half8_t*>(Ks + (kt * 16 + c16) * K_LD + dc * 32 + g * 8);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[dc], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = kv0 + kt * 16 + g * 4 + r;
+        s[kt][r] = key < a.Sk ? acc[r] * a.scale_log2 : NEG_BIG;
+      }
+    }
+  };
+
+  f32x4 oacc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_BIG, l_run = 0.f;
+
+  auto pv = [&](const f32x4 (&p)[4]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      half8_t pf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pf[r] = (half_t)p[2 * c][r];
+        pf[4 + r] = (half_t)p[2 * c + 1][r];
+      }
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const half_t* vrow = Vt + (dt * 16 + c16) * VT_LD + c * 32 + g * 4;
+        half4_t lo = *reinterpret_cast<const half4_t*>(vrow);
+        half4_t hi = *reinterpret_cast<const half4_t*>(vrow + 16);
+        half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
+      }
+    }
+  };
+
+  const int n_tiles = (a.Sk + KV_T - 1) / KV_T;
+
+  if (SAVE_P) {
+    // ---- pass 1: exact row max and row sum
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int t = 0; t < n_tiles; ++t) {
+      if (t + 1 < n_tiles) load_tile((t + 1) * KV_T);
+      f32x4 s[4];
+      compute_s(t * KV_T, s);
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float m_new = fmaxf(m_run, mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum += exp2f(s[kt][r] - m_new);
+      l_run = l_run * exp2f(m_run - m_new) + sum;
+      m_run = m_new;
+      __syncthreads();
+      if (t + 1 < n_tiles) {
+        store_tile();
+        __syncthreads();
+      }
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv_l = 1.f / l_run;
+    // ---- pass 2: normalised probabilities -> map + PV
+    const int qrow = q0 + c16;
+    const bool store_b = !a.cond_only || b >= a.B / 2;
+    const int bp = a.cond_only ? b - a.B / 2 : b;
+    const int Tp = a.tok >= 0 ? 1 : a.Sk;
+    float* prow = a.probs ? a.probs + (((long)bp * a.H + h) * a.Sq + qrow) * Tp : nullptr;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int t = 0; t < n_tiles; ++t) {
+      if (t + 1 < n_tiles) load_tile((t + 1) * KV_T);
+      f32x4 s[4];
+      compute_s(t * KV_T, s);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = exp2f(s[kt][r] - m_run) * inv_l;
+          s[kt][r] = p;
+          int key = t * KV_T + kt * 16 + g * 4 + r;
+          if (prow && store_b && qrow < a.Sq && key < a.Sk) {
+            if (a.tok < 0) prow[key] = p;
+            else if (key == a.tok) prow[0] = p;
+          }
+        }
+      pv(s);
+      __syncthreads();
+      if (t + 1 < n_tiles) {
+        store_tile();
+        __syncthreads();
+      }
+    }
+    l_run = 1.f;  // already normalised
+  } else {
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int t = 0; t < n_tiles; ++t) {
+      if (t + 1 < n_tiles) load_tile((t + 1) * KV_T);
+      f32x4 s[4];
+      compute_s(t * KV_T, s);
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f(m_run - m_new);
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = exp2f(s[kt][r] - m_new);
+          s[kt][r] = p;
+          sum += p;
+        }
+      l_run = l_run * alpha + sum;
+      m_run = m_new;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+      pv(s);
+      __syncthreads();
+      if (t + 1 < n_tiles) {
+        store_tile();
+        __syncthreads();
+      }
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+  }
+
+  // ---- epilogue: lane owns query q0+c16, dv = dt*16 + g*4 + r
+  const int qrow = q0 + c16;
+  if (qrow < a.Sq) {
+    const float inv = 1.f / l_run;
+    half_t* orow = a.o + (long)b * a.o_bs + (long)qrow * a.ldo + (long)h * d;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const int dv = dt * 16 + g * 4;
+      if (dv < d) {
+        half4_t o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)(oacc[dt][r] * inv);
+        *reinterpret_cast<half4_t*>(orow + dv) = o;
+      }
+    }
+    if (a.lse && g == 0 && !SAVE_P)
+      a.lse[((long)b * a.H + h) * a.Sq + qrow] = m_run + log2f(l_run);
+  }
+}
+
+template <bool SAVE_P>
+int launch_attn(const AttnArgs& a, hipStream_t st) {
+  dim3 grid((a.Sq + 63) / 64, a.H, a.B);
+  const int d = a.d;
+  if (d <= 32) hipLaunchKernelGGL((attn_fwd_kernel<32, SAVE_P>), grid, dim3(256), 0, st, a);
+  else if (d <= 64) hipLaunchKernelGGL((attn_fwd_kernel<64, SAVE_P>), grid, dim3(256), 0, st, a);
+  else if (d <= 96) hipLaunchKernelGGL((attn_fwd_kernel<96, SAVE_P>), grid, dim3(256), 0, st, a);
+  else if (d <= 128) hipLaunchKernelGGL((attn_fwd_kernel<128, SAVE_P>), grid, dim3(256), 0, st, a);
+  else if (d <= 160) hipLaunchKernelGGL((attn_fwd_kernel<160, SAVE_P>), grid, dim3(256), 0, st, a);
+  else return LGD_ERR_UNSUPPORTED;
+  return lgd_check_launch();
+}
+
+bool bad_view(int64_t ld, int d) { return (ld % 8) != 0 || (d % 8) != 0; }
+
+}  // namespace
+
+extern "C" int lgd_attn_fwd_f16(const void* q, int64_t ldq, int64_t q_bs, const void* k,
+                                int64_t ldk, int64_t k_bs, const void* v, int64_t ldv, int64_t v_bs,
+                                void* o, int64_t ldo, int64_t o_bs, float* lse, int B, int H, int Sq,
+                                int Sk, int d, float scale, void* stream) {
+  if (B < 1 || H < 1 || Sq < 1 || Sk < 1 || d < 8) return LGD_ERR_ARG;
+  if (bad_view(ldq, d) || bad_view(ldk, d) || bad_view(ldv, d) || (ldo % 4)) return LGD_ERR_ARG;
+  AttnArgs a;
+  a.q = (const half_t*)q; a.ldq = ldq; a.q_bs = q_bs;
+  a.k = (const half_t*)k; a.ldk = ldk; a.k_bs = k_bs;
+  a.v = (const half_t*)v; a.ldv = ldv; a.v_bs = v_bs;
+  a.o = (half_t*)o; a.ldo = ldo; a.o_bs = o_bs;
+  a.lse = lse; a.probs = nullptr; a.tok = -1; a.cond_only = 0;
+  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.d = d;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  return launch_attn<false>(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int lgd_cross_attn_fwd_f16(const void* q, int64_t ldq, int64_t q_bs, const void* k,
+                                      int64_t ldk, int64_t k_bs, const void* v, int64_t ldv,
+                                      int64_t v_bs, void* o, int64_t ldo, int64_t o_bs, float* probs,
+                                      int tok, int cond_only, int B, int H, int Sq, int Sk, int d,
+                                      float scale, void* stream) {
+  if (B < 1 || H < 1 || Sq < 1 || Sk < 1 || d < 8) return LGD_ERR_ARG;
+  if (bad_view(ldq, d) || bad_view(ldk, d) || bad_view(ldv, d) || (ldo % 4)) return LGD_ERR_ARG;
+  if (cond_only && (B % 2)) return LGD_ERR_ARG;  // attention_processor.py:475
+  if (tok >= Sk) return LGD_ERR_ARG;
+  AttnArgs a;
+  a.q = (const half_t*)q; a.ldq = ldq; a.q_bs = q_bs;
+  a.k = (const half_t*)k; a.ldk = ldk; a.k_bs = k_bs;
+  a.v = (const half_t*)v; a.ldv = ldv; a.v_bs = v_bs;
+  a.o = (half_t*)o; a.ldo = ldo; a.o_bs = o_bs;
+  a.lse = nullptr; a.probs = probs; a.tok = tok; a.cond_only = cond_only;
+  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.d = d;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (probs) return launch_attn<true>(a, st);
+  return launch_attn<false>(a, st);
+}

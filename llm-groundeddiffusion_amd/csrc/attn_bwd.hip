@@ -1,0 +1,491 @@
+// Attention input-gradients for the backward-guidance pass (torch.autograd.grad at
+// models/pipelines.py:56 through attention_processor.py:201-233,447 / :355-357).
+//
+// Self-attention: flash-style recompute in two kernels, both reusing the transposed-MFMA layout of
+// attn.hip (lane&15 = query or key, 4 consecutive contraction rows per lane):
+//   dq kernel : workgroup = 64 queries, loops over key tiles.  Also produces
+//               delta[q] = sum_d dO[q,d] O[q,d] for the second kernel.
+//   dkv kernel: workgroup = 64 keys, loops over query tiles.
+// With P = softmax(S), S = scale Q K^T:  dV = P^T dO;  dP = dO V^T;  dS = P o (dP - delta);
+// dQ = scale dS K;  dK = scale dS^T Q.
+//
+// Cross-attention (77 text tokens): only dQ is needed (text K/V are constants), but the
+// probability map is itself an output that receives a gradient from the energy, so the kernel
+// takes gP in addition to gO:  dP_total = gP + gO V^T.  One wave per query row, VALU only — the
+// contraction sizes (77 x d) are tiny and the pass is latency-bound.
+#include "common.h"
+#include "../../include/lgd_hip.h"
+
+namespace {
+
+constexpr int T64 = 64;
+constexpr int TR_LD = T64 + 8;  // halfs per row of a transposed tile
+
+// Stage a tile of 64 rows x DP (zero padded beyond `nrows`/`d`) from global into LDS, row-major
+// (`rm`, leading dim DP+8) and/or transposed (`tr`, [DP][72]).  All 256 threads participate.
+template <int DP, bool RM, bool TR>
+__device__ __forceinline__ void stage_tile(const half_t* __restrict__ src, long ld, int row0,
+                                           int nrows, int d, half_t* rm, half_t* tr) {
+  constexpr int KSEG = DP / 8;
+  constexpr int ITEMS = (T64 / 2) * KSEG;
+  for (int idx = threadIdx.x; idx < ITEMS; idx += 256) {
+    const int pair = idx & 31, seg = idx >> 5;
+    uint4 v[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      int row = pair * 2 + r;
+      bool ok = (row0 + row < nrows) && (seg * 8 < d);
+      v[r] = ok ? *reinterpret_cast<const uint4*>(src + (long)(row0 + row) * ld + seg * 8)
+                : make_uint4(0, 0, 0, 0);
+      if (RM) *reinterpret_cast<uint4*>(rm + row * (DP + 8) + seg * 8) = v[r];
+    }
+    if (TR) {
+      const half_t* e0 = reinterpret_cast<const half_t*>(&v[0]);
+      const half_t* e1 = reinterpret_cast<const half_t*>(&v[1]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        half2_t pr = {e0[e], e1[e]};
+        *reinterpret_cast<half2_t*>(tr + (seg * 8 + e) * TR_LD + pair * 2) = pr;
+      }
+    }
+  }
+}
+
+struct AttnBwdArgs {
+  const half_t* q; long ldq, q_bs;
+  const half_t* k; long ldk, k_bs;
+  const half_t* v; long ldv, v_bs;
+  const half_t* o; long ldo, o_bs;
+  const half_t* go; long ldgo, go_bs;
+  const float* lse;
+  float* delta;
+  half_t* gq; long ldgq, gq_bs;
+  half_t* gk; long ldgk, gk_bs;
+  half_t* gv; long ldgv, gv_bs;
+  int B, H, Sq, Sk, d;
+  float scale, scale_log2;
+};
+
+// A operand from a transposed LDS tile with the permuted contraction order used throughout:
+// element j of lane group g <-> contraction index 32c + (j<4 ? g*4+j : 16+g*4+j-4).
+__device__ __forceinline__ half8_t tr_frag(const half_t* tr, int row, int c, int g) {
+  const half_t* p = tr + row * TR_LD + c * 32 + g * 4;
+  half4_t lo = *reinterpret_cast<const half4_t*>(p);
+  half4_t hi = *reinterpret_cast<const half4_t*>(p + 16);
+  return (half8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int DP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
+  constexpr int K_LD = DP + 8;
+  constexpr int NDC = DP / 32, NDT = DP / 16;
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  half_t* Ks = reinterpret_cast<half_t*>(dyn_smem);
+  half_t* Vs = Ks + T64 * K_LD;
+  half_t* Kt = Vs + T64 * K_LD;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int d = a.d;
+  const int qrow = blockIdx.x * 64 + wid * 16 + c16;
+  const bool q_ok = qrow < a.Sq;
+  const half_t* Qb = a.q + (long)b * a.q_bs + (long)h * d;
+  const half_t* Kb = a.k + (long)b * a.k_bs + (long)h * d;
+  const half_t* Vb = a.v + (long)b * a.v_bs + (long)h * d;
+  const half_t* Ob = a.o + (long)b * a.o_bs + (long)h * d;
+  const half_t* GOb = a.go + (long)b * a.go_bs + (long)h * d;
+
+  half8_t qf[NDC], dof[NDC];
+  float delta = 0.f;
+#pragma unroll
+  for (int dc = 0; dc < NDC; ++dc) {
+    const int dd = dc * 32 + g * 8;
+    if (q_ok && dd < d) {
+      qf[dc] = *reinterpret_cast<const half8_t*>(Qb + (long)qrow * a.ldq + dd);
+      dof[dc] = *reinterpret_cast<const half8_t*>(GOb + (long)qrow * a.ldgo + dd);
+      half8_t of = *reinterpret_cast<const half8_t*>(Ob + (long)qrow * a.ldo + dd);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) delta += (float)dof[dc][e] * (float)of[e];
+    } else {
+      qf[dc] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+      dof[dc] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  delta += __shfl_xor(delta, 16, 64);
+  delta += __shfl_xor(delta, 32, 64);
+  const long stat_idx = ((long)b * a.H + h) * a.Sq + qrow;
+  if (q_ok && g == 0) a.delta[stat_idx] = delta;
+  const float lse = q_ok ? a.lse[stat_idx] : 0.f;
+
+  f32x4 dq[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int n_tiles = (a.Sk + T64 - 1) / T64;
+  for (int t = 0; t < n_tiles; ++t) {
+    const int kv0 = t * T64;
+    __syncthreads();
+    stage_tile<DP, true, true>(Kb, a.ldk, kv0, a.Sk, d, Ks, Kt);
+    stage_tile<DP, true, false>(Vb, a.ldv, kv0, a.Sk, d, Vs, nullptr);
+    __syncthreads();
+    f32x4 ds[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dc = 0; dc < NDC; ++dc) {
+        half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kt * 16 + c16) * K_LD + dc * 32 + g * 8);
+        half8_t vf = *reinterpret_cast<const half8_t*>(Vs + (kt * 16 + c16) * K_LD + dc * 32 + g * 8);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[dc], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, dof[dc], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = kv0 + kt * 16 + g * 4 + r;
+        float p = (key < a.Sk && q_ok) ? exp2f(s[r] * a.scale_log2 - lse) : 0.f;
+        ds[kt][r] = p * (dp[r] - delta);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      half8_t dsf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dsf[r] = (half_t)ds[2 * c][r];
+        dsf[4 + r] = (half_t)ds[2 * c + 1][r];
+      }
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        half8_t ktf = tr_frag(Kt, dt * 16 + c16, c, g);
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ktf, dsf, dq[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (q_ok) {
+    half_t* out = a.gq + (long)b * a.gq_bs + (long)qrow * a.ldgq + (long)h * d;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const int dv = dt * 16 + g * 4;
+      if (dv < d) {
+        half4_t o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)(dq[dt][r] * a.scale);
+        *reinterpret_cast<half4_t*>(out + dv) = o;
+      }
+    }
+  }
+}
+
+template <int DP>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
+  constexpr int K_LD = DP + 8;
+  constexpr int NDC = DP / 32, NDT = DP / 16;
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  half_t* Qs = reinterpret_cast<half_t*>(dyn_smem);
+  half_t* Gs = Qs + T64 * K_LD;          // dO row-major
+  half_t* Qt = Gs + T64 * K_LD;          // Q transposed [d][q]
+  half_t* Gt = Qt + DP * TR_LD;          // dO transposed [dv][q]
+  float* s_lse = reinterpret_cast<float*>(Gt + DP * TR_LD);
+  float* s_delta = s_lse + T64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int d = a.d;
+  const int krow = blockIdx.x * 64 + wid * 16 + c16;
+  const bool k_ok = krow < a.Sk;
+  const half_t* Qb = a.q + (long)b * a.q_bs + (long)h * d;
+  const half_t* Kb = a.k + (long)b * a.k_bs + (long)h * d;
+  const half_t* Vb = a.v + (long)b * a.v_bs + (long)h * d;
+  const half_t* GOb = a.go + (long)b * a.go_bs + (long)h * d;
+  const float* lse_b = a.lse + ((long)b * a.H + h) * a.Sq;
+  const float* delta_b = a.delta + ((long)b * a.H + h) * a.Sq;
+
+  // B operands: lane -> key c16, head-dim elements dc*32 + g*8..+8
+  half8_t kf[NDC], vf[NDC];
+#pragma unroll
+  for (int dc = 0; dc < NDC; ++dc) {
+    const int dd = dc * 32 + g * 8;
+    if (k_ok && dd < d) {
+      kf[dc] = *reinterpret_cast<const half8_t*>(Kb + (long)krow * a.ldk + dd);
+      vf[dc] = *reinterpret_cast<const half8_t*>(Vb + (long)krow * a.ldv + dd);
+    } else {
+      kf[dc] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+      vf[dc] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  f32x4 dk[NDT], dv[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) {
+    dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int n_tiles = (a.Sq + T64 - 1) / T64;
+  for (int t = 0; t < n_tiles; ++t) {
+    const int q0 = t * T64;
+    __syncthreads();
+    stage_tile<DP, true, true>(Qb, a.ldq, q0, a.Sq, d, Qs, Qt);
+    stage_tile<DP, true, true>(GOb, a.ldgo, q0, a.Sq, d, Gs, Gt);
+    if (tid < T64) {
+      int qq = q0 + tid;
+      s_lse[tid] = qq < a.Sq ? lse_b[qq] : 0.f;
+      s_delta[tid] = qq < a.Sq ? delta_b[qq] : 0.f;
+    }
+    __syncthreads();
+    f32x4 p[4], ds[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dc = 0; dc < NDC; ++dc) {
+        half8_t qa = *reinterpret_cast<const half8_t*>(Qs + (qt * 16 + c16) * K_LD + dc * 32 + g * 8);
+        half8_t ga = *reinterpret_cast<const half8_t*>(Gs + (qt * 16 + c16) * K_LD + dc * 32 + g * 8);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, kf[dc], s, 0, 0, 0);    // D[q][key]
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga, vf[dc], dp, 0, 0, 0);  // D[q][key]
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = qt * 16 + g * 4 + r;
+        const bool ok = k_ok && (q0 + ql < a.Sq);
+        float pv = ok ? exp2f(s[r] * a.scale_log2 - s_lse[ql]) : 0.f;
+        p[qt][r] = pv;
+        ds[qt][r] = pv * (dp[r] - s_delta[ql]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      half8_t pf, dsf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pf[r] = (half_t)p[2 * c][r];
+        pf[4 + r] = (half_t)p[2 * c + 1][r];
+        dsf[r] = (half_t)ds[2 * c][r];
+        dsf[4 + r] = (half_t)ds[2 * c + 1][r];
+      }
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        half8_t gtf = tr_frag(Gt, dt * 16 + c16, c, g);
+        half8_t qtf = tr_frag(Qt, dt * 16 + c16, c, g);
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gtf, pf, dv[dt], 0, 0, 0);   // dV^T[dv][key]
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qtf, dsf, dk[dt], 0, 0, 0);  // dK^T[j][key]
+      }
+    }
+  }
+  if (k_ok) {
+    half_t* outk = a.gk + (long)b * a.gk_bs + (long)krow * a.ldgk + (long)h * d;
+    half_t* outv = a.gv + (long)b * a.gv_bs + (long)krow * a.ldgv + (long)h * d;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const int j = dt * 16 + g * 4;
+      if (j < d) {
+        half4_t ok_, ov_;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ok_[r] = (half_t)(dk[dt][r] * a.scale);
+          ov_[r] = (half_t)dv[dt][r];
+        }
+        *reinterpret_cast<half4_t*>(outk + j) = ok_;
+        *reinterpret_cast<half4_t*>(outv + j) = ov_;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cross-attention dQ.  grid = (ceil(Sq/4), H, B): one wave per query row; K and V of the head
+// (Sk <= 128 rows) are staged in LDS as fp32? no — fp16 [Sk][d+2] (odd dword stride: lanes walk
+// rows conflict-free).
+// ---------------------------------------------------------------------------------------------
+struct CrossBwdArgs {
+  const half_t* q; long ldq, q_bs;
+  const half_t* k; long ldk, k_bs;
+  const half_t* v; long ldv, v_bs;
+  const half_t* go; long ldgo, go_bs;
+  const float* gp;
+  half_t* gq; long ldgq, gq_bs;
+  int B, H, Sq, Sk, d;
+  float scale;
+};
+
+constexpr int XB_MAXSK = 128;
+constexpr int XB_MAXD = 192;
+constexpr int XB_ROWS = 16;  // query rows per wave
+
+__global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const CrossBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  const int d = a.d, Sk = a.Sk;
+  const int ld = d + 2;  // halfs; (d+2)/2 dwords is odd for every d % 8 == 0 -> conflict-free rows
+  half_t* Ks = reinterpret_cast<half_t*>(dyn_smem);
+  half_t* Vs = Ks + Sk * ld;
+  float* s_q = reinterpret_cast<float*>(Vs + Sk * ld);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const half_t* Kb = a.k + (long)b * a.k_bs + (long)h * d;
+  const half_t* Vb = a.v + (long)b * a.v_bs + (long)h * d;
+  const int nseg = d / 8;
+  for (int i = tid; i < Sk * nseg; i += 256) {
+    int r = i / nseg, sg = i - r * nseg;
+    uint4 kk = *reinterpret_cast<const uint4*>(Kb + (long)r * a.ldk + sg * 8);
+    uint4 vv = *reinterpret_cast<const uint4*>(Vb + (long)r * a.ldv + sg * 8);
+    uint32_t* kd = reinterpret_cast<uint32_t*>(Ks + r * ld + sg * 8);
+    uint32_t* vd = reinterpret_cast<uint32_t*>(Vs + r * ld + sg * 8);
+    kd[0] = kk.x; kd[1] = kk.y; kd[2] = kk.z; kd[3] = kk.w;
+    vd[0] = vv.x; vd[1] = vv.y; vd[2] = vv.z; vd[3] = vv.w;
+  }
+  float* qv = s_q + wid * 2 * XB_MAXD;  // q row (fp32)
+  float* gov = qv + XB_MAXD;            // dO row
+  float* s_ds = s_q + 4 * 2 * XB_MAXD + wid * XB_MAXSK;
+  for (int qi = 0; qi < XB_ROWS; ++qi) {
+    const int qrow = (blockIdx.x * 4 + wid) * XB_ROWS + qi;
+    const bool ok = qrow < a.Sq;
+    if (ok) {
+      const half_t* qp = a.q + (long)b * a.q_bs + (long)qrow * a.ldq + (long)h * d;
+      const half_t* gp_ = a.go ? a.go + (long)b * a.go_bs + (long)qrow * a.ldgo + (long)h * d : nullptr;
+      for (int c = lane; c < d; c += 64) {
+        qv[c] = (float)qp[c];
+        gov[c] = gp_ ? (float)gp_[c] : 0.f;
+      }
+    }
+    __syncthreads();
+    // each lane owns keys lane and lane+64
+    float s[2], dp[2], p[2];
+    float mx = -1.0e30f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int key = lane + r * 64;
+      s[r] = -1.0e30f;
+      dp[r] = 0.f;
+      if (ok && key < Sk) {
+        float acc = 0.f, accv = 0.f;
+        const half2_t* kr = reinterpret_cast<const half2_t*>(Ks + key * ld);
+        const half2_t* vr = reinterpret_cast<const half2_t*>(Vs + key * ld);
+        for (int c2 = 0; c2 < d / 2; ++c2) {
+          half2_t kk = kr[c2], vv = vr[c2];
+          acc += qv[2 * c2] * (float)kk[0] + qv[2 * c2 + 1] * (float)kk[1];
+          accv += gov[2 * c2] * (float)vv[0] + gov[2 * c2 + 1] * (float)vv[1];
+        }
+        s[r] = acc * a.scale;
+        dp[r] = accv;
+        if (a.gp) dp[r] += a.gp[(((long)b * a.H + h) * a.Sq + qrow) * Sk + key];
+        mx = fmaxf(mx, s[r]);
+      }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      p[r] = (ok && lane + r * 64 < Sk) ? __expf(s[r] - mx) : 0.f;
+      sum += p[r];
+    }
+    sum = wave_sum(sum);
+    const float inv = ok ? 1.f / sum : 0.f;
+    float dot = 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      p[r] *= inv;
+      dot += p[r] * dp[r];
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int key = lane + r * 64;
+      if (key < Sk) s_ds[key] = p[r] * (dp[r] - dot) * a.scale;
+    }
+    __syncthreads();
+    if (ok) {
+      half_t* out = a.gq + (long)b * a.gq_bs + (long)qrow * a.ldgq + (long)h * d;
+      for (int c = lane; c < d; c += 64) {
+        float acc = 0.f;
+        for (int key = 0; key < Sk; ++key) acc += s_ds[key] * (float)Ks[key * ld + c];
+        out[c] = (half_t)acc;
+      }
+    }
+  }
+}
+
+template <int DP>
+int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
+  constexpr int K_LD = DP + 8;
+  const size_t smem_dq = (size_t)(2 * T64 * K_LD + DP * TR_LD) * 2;
+  const size_t smem_dkv = (size_t)(2 * T64 * K_LD + 2 * DP * TR_LD) * 2 + 2 * T64 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DP>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dkv);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DP>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dq);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DP>), dim3((a.Sq + 63) / 64, a.H, a.B), dim3(256), smem_dq,
+                     st, a);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP>), dim3((a.Sk + 63) / 64, a.H, a.B), dim3(256),
+                     smem_dkv, st, a);
+  return lgd_check_launch();
+}
+
+}  // namespace
+
+extern "C" int lgd_attn_bwd_f16(const void* q, int64_t ldq, int64_t q_bs, const void* k,
+                                int64_t ldk, int64_t k_bs, const void* v, int64_t ldv, int64_t v_bs,
+                                const void* o, int64_t ldo, int64_t o_bs, const void* go,
+                                int64_t ldgo, int64_t go_bs, const float* lse, float* delta, void* gq,
+                                int64_t ldgq, int64_t gq_bs, void* gk, int64_t ldgk, int64_t gk_bs,
+                                void* gv, int64_t ldgv, int64_t gv_bs, int B, int H, int Sq, int Sk,
+                                int d, float scale, void* stream) {
+  if (B < 1 || H < 1 || Sq < 1 || Sk < 1 || d < 8 || (d % 8)) return LGD_ERR_ARG;
+  if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 8) || (ldgo % 8) || (ldgq % 4) || (ldgk % 4) ||
+      (ldgv % 4) || !lse || !delta)
+    return LGD_ERR_ARG;
+  AttnBwdArgs a;
+  a.q = (const half_t*)q; a.ldq = ldq; a.q_bs = q_bs;
+  a.k = (const half_t*)k; a.ldk = ldk; a.k_bs = k_bs;
+  a.v = (const half_t*)v; a.ldv = ldv; a.v_bs = v_bs;
+  a.o = (const half_t*)o; a.ldo = ldo; a.o_bs = o_bs;
+  a.go = (const half_t*)go; a.ldgo = ldgo; a.go_bs = go_bs;
+  a.lse = lse; a.delta = delta;
+  a.gq = (half_t*)gq; a.ldgq = ldgq; a.gq_bs = gq_bs;
+  a.gk = (half_t*)gk; a.ldgk = ldgk; a.gk_bs = gk_bs;
+  a.gv = (half_t*)gv; a.ldgv = ldgv; a.gv_bs = gv_bs;
+  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.d = d;
+  a.scale = scale;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d <= 32) return launch_bwd<32>(a, st);
+  if (d <= 64) return launch_bwd<64>(a, st);
+  if (d <= 96) return launch_bwd<96>(a, st);
+  if (d <= 128) return launch_bwd<128>(a, st);
+  if (d <= 160) return launch_bwd<160>(a, st);
+  return LGD_ERR_UNSUPPORTED;
+}
+
+extern "C" int lgd_cross_attn_bwd_f16(const void* q, int64_t ldq, int64_t q_bs, const void* k,
+                                      int64_t ldk, int64_t k_bs, const void* v, int64_t ldv,
+                                      int64_t v_bs, const void* go, int64_t ldgo, int64_t go_bs,
+                                      const float* gp, void* gq, int64_t ldgq, int64_t gq_bs, int B,
+                                      int H, int Sq, int Sk, int d, float scale, void* stream) {
+  if (B < 1 || H < 1 || Sq < 1 || Sk < 1 || Sk > XB_MAXSK || d < 8 || (d % 8) || d > XB_MAXD ||
+      (ldq % 1) || (ldk % 8) || (ldv % 8))
+    return LGD_ERR_ARG;
+  CrossBwdArgs a;
+  a.q = (const half_t*)q; a.ldq = ldq; a.q_bs = q_bs;
+  a.k = (const half_t*)k; a.ldk = ldk; a.k_bs = k_bs;
+  a.v = (const half_t*)v; a.ldv = ldv; a.v_bs = v_bs;
+  a.go = (const half_t*)go; a.ldgo = ldgo; a.go_bs = go_bs;
+  a.gp = gp;
+  a.gq = (half_t*)gq; a.ldgq = ldgq; a.gq_bs = gq_bs;
+  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.d = d; a.scale = scale;
+  const int ld = d + 2;
+  size_t smem = (size_t)(2 * Sk * ld + 2) * 2 + (size_t)4 * 2 * XB_MAXD * 4 + (size_t)4 * XB_MAXSK * 4;
+  smem = (smem + 15) & ~(size_t)15;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn_bwd_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3((Sq + 4 * XB_ROWS - 1) / (4 * XB_ROWS), H, B), dim3(256), smem,
+                     reinterpret_cast<hipStream_t>(stream), a);
+  return lgd_check_launch();
+}

@@ -1,0 +1,63 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the LMD/LMD+
+// stage-2 denoising path.  No CUDA compatibility layer: this code only targets
+// MI355X.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LGD_WAVE 64
+
+// Error codes returned through the C ABI (0 = ok).
+#define LGD_OK 0
+#define LGD_ERR_ARG (-1)
+#define LGD_ERR_LAUNCH (-2)
+#define LGD_ERR_UNSUPPORTED (-3)
+
+static inline int lgd_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? LGD_OK : LGD_ERR_LAUNCH;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); `red` is >= 4 floats of LDS.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = red[0] + red[1] + red[2] + red[3];
+  return r;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+// d/dx silu(x) = s + x*s*(1-s), s = sigmoid(x)
+__device__ __forceinline__ float silu_grad_f(float x) {
+  float s = 1.f / (1.f + __expf(-x));
+  return s * (1.f + x * (1.f - s));
+}
+// exact (erf) GELU, as torch.nn.functional.gelu default
+__device__ __forceinline__ float gelu_f(float x) {
+  return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}

@@ -1,0 +1,409 @@
+// MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950.
+//
+//   C[m][n] = epilogue( sum_k A(m,k) * W[n][k] ),  fp16 operands, fp32 accumulate.
+//
+// One kernel covers every dense contraction of the SD UNet (see include/lgd_hip.h for the
+// reference call sites): nn.Linear, 1x1 conv, 3x3 conv (stride 1/2, nearest-2x upsample folded into
+// the gather, channel-concat of two sources folded into the K loop) and their dgrad forms.
+//
+// Structure (per workgroup, 256 threads = 4 waves in a 2x2 grid):
+//   * tile BM x BN x 64; each wave owns (BM/2)x(BN/2) as MI x NI MFMA 16x16x32 tiles;
+//   * operands are register-staged: global -> VGPR (issued before the MFMAs of the current
+//     K-tile) -> LDS after the barrier, so the HBM/L2 latency hides under the MFMA phase;
+//   * LDS rows are padded to 72 halfs (144 B) so the 16-lane ds_read_b128 groups spread
+//     over the banks;
+//   * the MFMA is issued "swapped" (A := weight rows, B := activation rows), which makes each lane
+//     own 4 consecutive output channels of one pixel -> one 8-byte store, and 4-wide bias /
+//     residual loads in the epilogue;
+//   * split-K (grid.z) writes fp32 partials to a workspace, a second launch reduces and applies
+//     the same epilogue (deterministic, no atomics) — needed for the 8x8 / 16x16 levels where
+//     M = B*HW is 128..512 and the weight stream must be spread over all 256 CUs.
+#include "common.h"
+#include "../../include/lgd_hip.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int LDS_LD = BK + 8;  // halfs per LDS row
+
+struct GemmArgs {
+  LgdGemmDesc d;
+  int cin;       // c0 + c1
+  int k_per_split;  // multiple of BK
+};
+
+__device__ __forceinline__ float4 ld_bias4(const float* p, int n) {
+  return *reinterpret_cast<const float4*>(p + n);
+}
+
+// Applies the epilogue to 4 consecutive output channels (n..n+3) of row m and stores them.
+// For GEGLU `v` holds the value accumulators and `g` the gate accumulators of the same columns.
+template <bool GEGLU>
+__device__ __forceinline__ void epilogue_store4(const LgdGemmDesc& d, long c_off, long r_off, int m,
+                                                int n_in, int n_out, f32x4 v, f32x4 g) {
+  // n_in: column index in the (packed) weight/bias space for the value block;
+  // n_out: output column.
+  if (d.bias) {
+    float4 b = ld_bias4(d.bias, n_in);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    if (GEGLU) {
+      float4 bg = ld_bias4(d.bias, n_in + 16);
+      g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
+    }
+  }
+  if (d.bias2) {
+    float4 b = ld_bias4(d.bias2, n_in);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (GEGLU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] * gelu_f(g[r]);
+  }
+  const float alpha = d.alpha;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] *= alpha;
+  if (d.res) {
+    if (d.epi & LGD_EPI_RES_F32) {
+      const float* rp = reinterpret_cast<const float*>(d.res) + r_off + (long)m * d.ldr + n_out;
+      float4 rv = *reinterpret_cast<const float4*>(rp);
+      v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+    } else {
+      const half_t* rp = reinterpret_cast<const half_t*>(d.res) + r_off + (long)m * d.ldr + n_out;
+      half4_t rv = *reinterpret_cast<const half4_t*>(rp);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+    }
+  }
+  if (d.epi & LGD_EPI_OUT_F32) {
+    float* cp = reinterpret_cast<float*>(d.c) + c_off + (long)m * d.ldc + n_out;
+    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    half_t* cp = reinterpret_cast<half_t*>(d.c) + c_off + (long)m * d.ldc + n_out;
+    half4_t o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+    *reinterpret_cast<half4_t*>(cp) = o;
+  }
+}
+
+template <int MI, int NI>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs ga) {
+  constexpr int BM = 32 * MI;
+  constexpr int BN = 32 * NI;
+  constexpr int A_IT = BM * 8 / 256;  // 16-byte segments per thread for the A tile
+  constexpr int B_IT = BN * 8 / 256;
+  static_assert(A_IT >= 1 && B_IT >= 1, "tile too small");
+
+  __shared__ __attribute__((aligned(16))) half_t smem[(BM + BN) * LDS_LD];
+  half_t* As = smem;
+  half_t* Bs = smem + BM * LDS_LD;
+
+  const LgdGemmDesc& d = ga.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  // ---- block coordinates: x -> (m tile, n tile), z -> (batch, split)
+  const int n_tiles_n = (d.N + BN - 1) / BN;
+  const int tile_m = blockIdx.x / n_tiles_n;
+  const int tile_n = blockIdx.x - tile_m * n_tiles_n;
+  const int zz = blockIdx.z;
+  const int batch = zz / d.splits;
+  const int split = zz - batch * d.splits;
+  const int b_o = batch / d.nb_i, b_i = batch - b_o * d.nb_i;
+  const long a_off = b_o * d.a_bs_o + b_i * d.a_bs_i;
+  const long w_off = b_o * d.w_bs_o + b_i * d.w_bs_i;
+  const long c_off = b_o * d.c_bs_o + b_i * d.c_bs_i;
+  const long r_off = b_o * d.r_bs_o + b_i * d.r_bs_i;
+
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int k_beg = split * ga.k_per_split;
+  int k_end = k_beg + ga.k_per_split;
+  if (k_end > d.K) k_end = d.K;
+  const int nk = (k_end - k_beg + BK - 1) / BK;
+
+  const half_t* A0 = reinterpret_cast<const half_t*>(d.a0) + a_off;
+  const half_t* A1 = d.a1 ? reinterpret_cast<const half_t*>(d.a1) + a_off : nullptr;
+  const half_t* W = reinterpret_cast<const half_t*>(d.w) + w_off;
+
+  // ---- per-thread staging coordinates
+  const int kseg = tid & 7;       // which 8-half segment of the 64-wide K tile
+  const int rbase = tid >> 3;     // row within a 32-row pass
+  const int cin = ga.cin;
+  const bool conv = d.taps == 9;
+
+  // A rows of this thread: pixel decomposition (conv) or plain row
+  int a_iy0[A_IT], a_ix0[A_IT];
+  long a_row[A_IT];  // plain: row index; conv: b*hin*win
+  bool a_ok[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    int m = m0 + rbase + 32 * i;
+    a_ok[i] = m < d.M;
+    if (conv) {
+      int hw = d.hout * d.wout;
+      int b = m / hw;
+      int rem = m - b * hw;
+      int oy = rem / d.wout;
+      int ox = rem - oy * d.wout;
+      a_iy0[i] = oy * d.stride - 1;
+      a_ix0[i] = ox * d.stride - 1;
+      a_row[i] = (long)b * d.hin * d.win;
+    } else {
+      a_iy0[i] = 0; a_ix0[i] = 0;
+      a_row[i] = m;
+    }
+  }
+  // running (tap, channel) of this thread's K segment
+  int k_cur = k_beg + kseg * 8;
+  int tap = conv ? k_cur / cin : 0;
+  int ch = k_cur - tap * cin;
+
+  uint4 a_reg[A_IT], b_reg[B_IT];
+
+  auto load_tile = [&]() {
+    // A
+    const bool k_ok = k_cur < k_end;
+    int ky = 0, kx = 0;
+    if (conv) { ky = tap / 3; kx = tap - ky * 3; }
+    const bool src1 = ch >= d.c0;
+    const half_t* src = src1 ? A1 : A0;
+    const long ld = src1 ? d.lda1 : d.lda0;
+    const int cc = src1 ? ch - d.c0 : ch;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      bool ok = a_ok[i] && k_ok;
+      long row = a_row[i];
+      if (conv) {
+        int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+        if (d.ups) {
+          // ups=1: nearest-2x upsampled input; ups=2: zero-inserted input (only even coordinates
+          // carry data) — the input-gradient of a stride-2 convolution.
+          ok = ok && iy >= 0 && ix >= 0 && iy < 2 * d.hin && ix < 2 * d.win;
+          if (d.ups == 2) ok = ok && !((iy | ix) & 1);
+          iy >>= 1; ix >>= 1;
+        } else {
+          ok = ok && iy >= 0 && ix >= 0 && iy < d.hin && ix < d.win;
+        }
+        row += (long)iy * d.win + ix;
+      }
+      if (ok) a_reg[i] = *reinterpret_cast<const uint4*>(src + row * ld + cc);
+      else a_reg[i] = make_uint4(0, 0, 0, 0);
+    }
+    // B (weights)
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      int n = n0 + rbase + 32 * i;
+      bool ok = (n < d.N) && k_ok;
+      if (ok) b_reg[i] = *reinterpret_cast<const uint4*>(W + (long)n * d.ldw + k_cur);
+      else b_reg[i] = make_uint4(0, 0, 0, 0);
+    }
+    // advance to the next K tile
+    k_cur += BK;
+    ch += BK;
+    if (conv) {
+      while (ch >= cin) { ch -= cin; ++tap; }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+      *reinterpret_cast<uint4*>(As + (rbase + 32 * i) * LDS_LD + kseg * 8) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i)
+      *reinterpret_cast<uint4*>(Bs + (rbase + 32 * i) * LDS_LD + kseg * 8) = b_reg[i];
+  };
+
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fk = (lane >> 4) * 8;
+
+  if (nk > 0) {
+    load_tile();
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) load_tile();
+#pragma unroll
+      for (int kk = 0; kk < BK / 32; ++kk) {
+        half8_t af[MI], bf[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          af[mi] = *reinterpret_cast<const half8_t*>(
+              As + (wm * 16 * MI + mi * 16 + frow) * LDS_LD + kk * 32 + fk);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          bf[ni] = *reinterpret_cast<const half8_t*>(
+              Bs + (wn * 16 * NI + ni * 16 + frow) * LDS_LD + kk * 32 + fk);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[ni][mi] =
+                __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+      }
+      __syncthreads();
+      if (kt + 1 < nk) {
+        store_tile();
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- epilogue: lane owns pixel m = .. + (lane&15), channels n = .. + (lane>>4)*4 + r
+  const int m_l = lane & 15;
+  const int n_l = (lane >> 4) * 4;
+  if (d.splits > 1) {
+    float* ws = ga.d.ws + ((long)batch * d.splits + split) * (long)d.M * d.N;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      int m = m0 + wm * 16 * MI + mi * 16 + m_l;
+      if (m >= d.M) continue;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        int n = n0 + wn * 16 * NI + ni * 16 + n_l;
+        if (n >= d.N) continue;
+        f32x4 v = acc[ni][mi];
+        *reinterpret_cast<float4*>(ws + (long)m * d.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    return;
+  }
+  const bool geglu = d.epi & LGD_EPI_GEGLU;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    int m = m0 + wm * 16 * MI + mi * 16 + m_l;
+    if (m >= d.M) continue;
+    if (geglu) {
+      if constexpr (NI % 2 == 0) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ni += 2) {
+          int n_in = n0 + wn * 16 * NI + ni * 16 + n_l;
+          if (n_in >= d.N) continue;
+          int n_out = (n0 + wn * 16 * NI + ni * 16) / 2 + n_l;
+          epilogue_store4<true>(d, c_off, r_off, m, n_in, n_out, acc[ni][mi], acc[ni + 1][mi]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        int n = n0 + wn * 16 * NI + ni * 16 + n_l;
+        if (n >= d.N) continue;
+        epilogue_store4<false>(d, c_off, r_off, m, n, n, acc[ni][mi], acc[ni][mi]);
+      }
+    }
+  }
+}
+
+// Sums the split-K partials and applies the epilogue. One thread per 4 output channels.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs ga) {
+  const LgdGemmDesc& d = ga.d;
+  const bool geglu = d.epi & LGD_EPI_GEGLU;
+  const int n_out_cols = geglu ? d.N / 2 : d.N;
+  const long groups_per_row = n_out_cols / 4;
+  const long total = (long)d.M * groups_per_row;
+  const int batch = blockIdx.z;
+  const int b_o = batch / d.nb_i, b_i = batch - b_o * d.nb_i;
+  const long c_off = b_o * d.c_bs_o + b_i * d.c_bs_i;
+  const long r_off = b_o * d.r_bs_o + b_i * d.r_bs_i;
+  const float* ws = d.ws + (long)batch * d.splits * (long)d.M * d.N;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+    int m = (int)(idx / groups_per_row);
+    int gcol = (int)(idx - (long)m * groups_per_row) * 4;  // output column
+    int n_in = geglu ? (gcol / 16) * 32 + (gcol % 16) : gcol;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < d.splits; ++s) {
+      const float* p = ws + (long)s * d.M * d.N + (long)m * d.N + n_in;
+      float4 t = *reinterpret_cast<const float4*>(p);
+      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+      if (geglu) {
+        float4 u = *reinterpret_cast<const float4*>(p + 16);
+        g[0] += u.x; g[1] += u.y; g[2] += u.z; g[3] += u.w;
+      }
+    }
+    if (geglu) epilogue_store4<true>(d, c_off, r_off, m, n_in, gcol, v, g);
+    else epilogue_store4<false>(d, c_off, r_off, m, n_in, gcol, v, g);
+  }
+}
+
+template <int MI, int NI>
+int launch_gemm(const GemmArgs& ga, hipStream_t st) {
+  constexpr int BM = 32 * MI, BN = 32 * NI;
+  const LgdGemmDesc& d = ga.d;
+  long tiles = (long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+  dim3 grid((unsigned)tiles, 1, (unsigned)(d.nb_o * d.nb_i * d.splits));
+  hipLaunchKernelGGL((gemm_kernel<MI, NI>), grid, dim3(256), 0, st, ga);
+  return lgd_check_launch();
+}
+
+}  // namespace
+
+extern "C" int lgd_abi_version(void) { return LGD_ABI_VERSION; }
+
+extern "C" int lgd_gemm_f16(const LgdGemmDesc* desc, void* stream) {
+  if (!desc) return LGD_ERR_ARG;
+  GemmArgs ga;
+  ga.d = *desc;
+  LgdGemmDesc& d = ga.d;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0) return LGD_ERR_ARG;
+  if (d.taps != 1 && d.taps != 9) return LGD_ERR_ARG;
+  ga.cin = d.c0 + d.c1;
+  if (d.K != d.taps * ga.cin) return LGD_ERR_ARG;
+  if ((d.c0 % 8) || (d.c1 % 8) || (d.N % 4) || (d.ldw % 8) || (d.lda0 % 8) || (d.lda1 % 8) ||
+      (d.ldc % 4))
+    return LGD_ERR_ARG;
+  if (d.c1 > 0 && !d.a1) return LGD_ERR_ARG;
+  if (d.res && (d.ldr % 4)) return LGD_ERR_ARG;
+  if (d.nb_o < 1) d.nb_o = 1;
+  if (d.nb_i < 1) d.nb_i = 1;
+  if (d.splits < 1) d.splits = 1;
+  const bool geglu = d.epi & LGD_EPI_GEGLU;
+  if (geglu && (d.N % 32)) return LGD_ERR_ARG;
+  if (d.splits > 1 && !d.ws) return LGD_ERR_ARG;
+  // K range of each split, multiple of BK
+  int ktiles = (d.K + BK - 1) / BK;
+  int tps = (ktiles + d.splits - 1) / d.splits;
+  ga.k_per_split = tps * BK;
+  // drop empty trailing splits
+  d.splits = (ktiles + tps - 1) / tps;
+
+  int tile = d.tile;
+  if (tile == 0) {
+    // heuristic: the largest tile that still yields >= ~2 workgroups per CU-pair
+    long batches = (long)d.nb_o * d.nb_i * d.splits;
+    auto wgs = [&](int bm, int bn) {
+      return batches * ((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn);
+    };
+    if (d.M <= 32) tile = 5;
+    else if (wgs(128, 128) >= 384 && d.N % 128 == 0) tile = 1;
+    else if (wgs(128, 64) >= 256) tile = 2;
+    else tile = 4;
+  }
+  int rc;
+  switch (tile) {
+    case 1: rc = launch_gemm<4, 4>(ga, st); break;
+    case 2: rc = launch_gemm<4, 2>(ga, st); break;
+    case 3: rc = launch_gemm<2, 4>(ga, st); break;
+    case 4: rc = launch_gemm<2, 2>(ga, st); break;
+    case 5: rc = launch_gemm<1, 4>(ga, st); break;
+    default: return LGD_ERR_ARG;
+  }
+  if (rc) return rc;
+  if (d.splits > 1) {
+    int n_out = geglu ? d.N / 2 : d.N;
+    long total = (long)d.M * (n_out / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    dim3 grid(blocks, 1, d.nb_o * d.nb_i);
+    hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, st, ga);
+    rc = lgd_check_launch();
+  }
+  return rc;
+}

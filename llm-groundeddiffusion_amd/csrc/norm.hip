@@ -1,0 +1,456 @@
+// GroupNorm(+SiLU) and LayerNorm, forward and input-gradient, for channels-last fp16 maps.
+// All HBM-bound: 16-byte vector loads, fp32 statistics, wavefront-shuffle reductions.
+#include "common.h"
+#include "../../include/lgd_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm statistics, pass 1: each workgroup reduces a chunk of pixels of one image for all
+// groups.  grid = (nchunk, B).  part[b][chunk][g] = {sum, sumsq}.
+// A thread owns a fixed 8-channel vector column (tid + j*256 < C/8) and walks pixels, so loads of
+// a wave are contiguous within a pixel row.
+// ------------------------------------------------------------------------------------------
+constexpr int GN_MAXC = 2560;
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x0,
+                                                        const half_t* __restrict__ x1, int c0,
+                                                        int c1, int HW, int G, float* part,
+                                                        int nchunk) {
+  __shared__ float s_sum[64], s_sq[64];  // G <= 64
+  const int C = c0 + c1;
+  const int cpg = C / G;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int p_per = (HW + nchunk - 1) / nchunk;
+  const int p_beg = chunk * p_per;
+  int p_end = p_beg + p_per;
+  if (p_end > HW) p_end = HW;
+  for (int i = threadIdx.x; i < G; i += 256) { s_sum[i] = 0.f; s_sq[i] = 0.f; }
+  __syncthreads();
+  const int nvec = C / 8;
+  // thread -> (vector column, pixel lane): consecutive threads read consecutive channels of one
+  // pixel; when C/8 < 256 the spare threads take further pixels of the chunk.
+  const int vs = nvec < 256 ? nvec : 256;
+  const int pl = 256 / vs;
+  const int plane = threadIdx.x / vs;
+  for (int v = threadIdx.x % vs; v < nvec && plane < pl; v += vs) {
+    const int c = v * 8;
+    const bool second = c >= c0;
+    const half_t* src = second ? x1 : x0;
+    const int cc = second ? c - c0 : c;
+    const int ld = second ? c1 : c0;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    for (int p = p_beg + plane; p < p_end; p += pl) {
+      half8_t h = *reinterpret_cast<const half8_t*>(src + ((long)b * HW + p) * ld + cc);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)h[e];
+        s[e] += f;
+        q[e] += f * f;
+      }
+    }
+    // channels c..c+7 may straddle a group boundary when cpg % 8 != 0
+    int g_prev = c / cpg;
+    float as = 0.f, aq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int g = (c + e) / cpg;
+      if (g != g_prev) {
+        atomicAdd(&s_sum[g_prev], as);
+        atomicAdd(&s_sq[g_prev], aq);
+        as = 0.f; aq = 0.f; g_prev = g;
+      }
+      as += s[e];
+      aq += q[e];
+    }
+    atomicAdd(&s_sum[g_prev], as);
+    atomicAdd(&s_sq[g_prev], aq);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < G; i += 256) {
+    float* o = part + (((long)b * nchunk + chunk) * G + i) * 2;
+    o[0] = s_sum[i];
+    o[1] = s_sq[i];
+  }
+}
+
+// pass 2: finalise statistics (every workgroup re-reduces the tiny partial table of its image),
+// build per-channel scale/shift in LDS, normalise (+SiLU) a chunk of pixels.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x0,
+                                                        const half_t* __restrict__ x1, int c0,
+                                                        int c1, int HW, int G, float eps,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int silu,
+                                                        half_t* __restrict__ y,
+                                                        const float* __restrict__ part, int nchunk,
+                                                        float* stats, int napply) {
+  __shared__ float s_mean[64], s_rstd[64];
+  __shared__ float s_a[GN_MAXC], s_b[GN_MAXC];
+  const int C = c0 + c1;
+  const int cpg = C / G;
+  const int b = blockIdx.y;
+  if (threadIdx.x < G) {
+    float s = 0.f, q = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const float* p = part + (((long)b * nchunk + ch) * G + threadIdx.x) * 2;
+      s += p[0];
+      q += p[1];
+    }
+    float n = (float)HW * cpg;
+    float mean = s / n;
+    float var = q / n - mean * mean;
+    if (var < 0.f) var = 0.f;
+    float rstd = rsqrtf(var + eps);
+    s_mean[threadIdx.x] = mean;
+    s_rstd[threadIdx.x] = rstd;
+    if (stats && blockIdx.x == 0) {
+      stats[((long)b * G + threadIdx.x) * 2 + 0] = mean;
+      stats[((long)b * G + threadIdx.x) * 2 + 1] = rstd;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    int g = c / cpg;
+    float a = s_rstd[g] * gamma[c];
+    s_a[c] = a;
+    s_b[c] = beta[c] - s_mean[g] * a;
+  }
+  __syncthreads();
+  const int p_per = (HW + napply - 1) / napply;
+  const int p_beg = blockIdx.x * p_per;
+  int p_end = p_beg + p_per;
+  if (p_end > HW) p_end = HW;
+  const int nvec = C / 8;
+  const long total = (long)(p_end - p_beg) * nvec;
+  for (long idx = threadIdx.x; idx < total; idx += 256) {
+    int p = p_beg + (int)(idx / nvec);
+    int c = (int)(idx % nvec) * 8;
+    const bool second = c >= c0;
+    const half_t* src = second ? x1 : x0;
+    const int cc = second ? c - c0 : c;
+    const int ld = second ? c1 : c0;
+    half8_t h = *reinterpret_cast<const half8_t*>(src + ((long)b * HW + p) * ld + cc);
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = (float)h[e] * s_a[c + e] + s_b[c + e];
+      if (silu) f = silu_f(f);
+      o[e] = (half_t)f;
+    }
+    *reinterpret_cast<half8_t*>(y + ((long)b * HW + p) * C + c) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm backward (w.r.t. x).  With xhat = (x-mean)*rstd, z = gamma*xhat+beta, y = act(z):
+//   dz = gy * act'(z);  dxhat = dz*gamma
+//   dx = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat*xhat))
+// pass 1 accumulates per (b, g): S1 = sum dxhat, S2 = sum dxhat*xhat (same chunking as forward).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(
+    const half_t* __restrict__ gy, const half_t* __restrict__ x0, const half_t* __restrict__ x1,
+    int c0, int c1, int HW, int G, const float* __restrict__ gamma, const float* __restrict__ beta,
+    int silu, const float* __restrict__ stats, float* part, int nchunk) {
+  __shared__ float s_1[64], s_2[64];
+  const int C = c0 + c1;
+  const int cpg = C / G;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int p_per = (HW + nchunk - 1) / nchunk;
+  const int p_beg = chunk * p_per;
+  int p_end = p_beg + p_per;
+  if (p_end > HW) p_end = HW;
+  for (int i = threadIdx.x; i < G; i += 256) { s_1[i] = 0.f; s_2[i] = 0.f; }
+  __syncthreads();
+  const int nvec = C / 8;
+  const int vs = nvec < 256 ? nvec : 256;
+  const int pl = 256 / vs;
+  const int plane = threadIdx.x / vs;
+  for (int v = threadIdx.x % vs; v < nvec && plane < pl; v += vs) {
+    const int c = v * 8;
+    const bool second = c >= c0;
+    const half_t* src = second ? x1 : x0;
+    const int cc = second ? c - c0 : c;
+    const int ld = second ? c1 : c0;
+    float mean[8], rstd[8], gm[8], bt[8], a1[8], a2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int g = (c + e) / cpg;
+      mean[e] = stats[((long)b * G + g) * 2];
+      rstd[e] = stats[((long)b * G + g) * 2 + 1];
+      gm[e] = gamma[c + e];
+      bt[e] = beta[c + e];
+      a1[e] = 0.f; a2[e] = 0.f;
+    }
+    for (int p = p_beg + plane; p < p_end; p += pl) {
+      half8_t hx = *reinterpret_cast<const half8_t*>(src + ((long)b * HW + p) * ld + cc);
+      half8_t hg = *reinterpret_cast<const half8_t*>(gy + ((long)b * HW + p) * C + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float xh = ((float)hx[e] - mean[e]) * rstd[e];
+        float dz = (float)hg[e];
+        if (silu) dz *= silu_grad_f(gm[e] * xh + bt[e]);
+        float dxh = dz * gm[e];
+        a1[e] += dxh;
+        a2[e] += dxh * xh;
+      }
+    }
+    int g_prev = c / cpg;
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int g = (c + e) / cpg;
+      if (g != g_prev) {
+        atomicAdd(&s_1[g_prev], t1);
+        atomicAdd(&s_2[g_prev], t2);
+        t1 = 0.f; t2 = 0.f; g_prev = g;
+      }
+      t1 += a1[e];
+      t2 += a2[e];
+    }
+    atomicAdd(&s_1[g_prev], t1);
+    atomicAdd(&s_2[g_prev], t2);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < G; i += 256) {
+    float* o = part + (((long)b * nchunk + chunk) * G + i) * 2;
+    o[0] = s_1[i];
+    o[1] = s_2[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
+    const half_t* __restrict__ gy, const half_t* __restrict__ x0, const half_t* __restrict__ x1,
+    int c0, int c1, int HW, int G, const float* __restrict__ gamma, const float* __restrict__ beta,
+    int silu, const float* __restrict__ stats, half_t* gx0, half_t* gx1,
+    const float* __restrict__ part, int nchunk, int accumulate, int napply) {
+  __shared__ float s_m1[64], s_m2[64];
+  const int C = c0 + c1;
+  const int cpg = C / G;
+  const int b = blockIdx.y;
+  if (threadIdx.x < G) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const float* p = part + (((long)b * nchunk + ch) * G + threadIdx.x) * 2;
+      s1 += p[0];
+      s2 += p[1];
+    }
+    float n = (float)HW * cpg;
+    s_m1[threadIdx.x] = s1 / n;
+    s_m2[threadIdx.x] = s2 / n;
+  }
+  __syncthreads();
+  const int p_per = (HW + napply - 1) / napply;
+  const int p_beg = blockIdx.x * p_per;
+  int p_end = p_beg + p_per;
+  if (p_end > HW) p_end = HW;
+  const int nvec = C / 8;
+  const long total = (long)(p_end - p_beg) * nvec;
+  for (long idx = threadIdx.x; idx < total; idx += 256) {
+    int p = p_beg + (int)(idx / nvec);
+    int c = (int)(idx % nvec) * 8;
+    const bool second = c >= c0;
+    const half_t* src = second ? x1 : x0;
+    half_t* dst = second ? gx1 : gx0;
+    const int cc = second ? c - c0 : c;
+    const int ld = second ? c1 : c0;
+    const long off = ((long)b * HW + p) * ld + cc;
+    half8_t hx = *reinterpret_cast<const half8_t*>(src + off);
+    half8_t hg = *reinterpret_cast<const half8_t*>(gy + ((long)b * HW + p) * C + c);
+    half8_t o;
+    if (accumulate) o = *reinterpret_cast<const half8_t*>(dst + off);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int g = (c + e) / cpg;
+      float mean = stats[((long)b * G + g) * 2];
+      float rstd = stats[((long)b * G + g) * 2 + 1];
+      float gm = gamma[c + e];
+      float xh = ((float)hx[e] - mean) * rstd;
+      float dz = (float)hg[e];
+      if (silu) dz *= silu_grad_f(gm * xh + beta[c + e]);
+      float dxh = dz * gm;
+      float dx = rstd * (dxh - s_m1[g] - xh * s_m2[g]);
+      if (accumulate) dx += (float)o[e];
+      o[e] = (half_t)dx;
+    }
+    *reinterpret_cast<half8_t*>(dst + off) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row held in registers (C <= 64*8*MAXV halfs).
+// ------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 5;  // C up to 2560
+
+__global__ __launch_bounds__(256) void layernorm_kernel(
+    const half_t* __restrict__ x, long ldx, half_t* __restrict__ y, long ldy, int rows, int C,
+    float eps, const float* __restrict__ gamma, const float* __restrict__ beta, float* stats,
+    int rpb, long x_bs, long y_bs) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int bb = row / rpb, rr = row - bb * rpb;
+  const half_t* xr = x + bb * x_bs + (long)rr * ldx;
+  half_t* yr = y + bb * y_bs + (long)rr * ldy;
+  const int nvec = C / 8;
+  half8_t h[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int v = lane + j * 64;
+    if (v < nvec) {
+      h[j] = *reinterpret_cast<const half8_t*>(xr + v * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)h[j][e];
+    }
+  }
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int v = lane + j * 64;
+    if (v < nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float dlt = (float)h[j][e] - mean;
+        q += dlt * dlt;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+  if (stats && lane == 0) {
+    stats[(long)row * 2] = mean;
+    stats[(long)row * 2 + 1] = rstd;
+  }
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int v = lane + j * 64;
+    if (v < nvec) {
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int c = v * 8 + e;
+        o[e] = (half_t)(((float)h[j][e] - mean) * rstd * gamma[c] + beta[c]);
+      }
+      *reinterpret_cast<half8_t*>(yr + v * 8) = o;
+    }
+  }
+}
+
+// dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat))
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const half_t* __restrict__ gy, long ldgy, const half_t* __restrict__ x, long ldx, half_t* gx,
+    long ldgx, int rows, int C, const float* __restrict__ gamma, const float* __restrict__ stats,
+    int rpb, long gy_bs, long x_bs, long gx_bs, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int bb = row / rpb, rr = row - bb * rpb;
+  const half_t* gr = gy + bb * gy_bs + (long)rr * ldgy;
+  const half_t* xr = x + bb * x_bs + (long)rr * ldx;
+  half_t* dr = gx + bb * gx_bs + (long)rr * ldgx;
+  const float mean = stats[(long)row * 2], rstd = stats[(long)row * 2 + 1];
+  const int nvec = C / 8;
+  float dxh[LN_MAXV][8], xh[LN_MAXV][8];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int v = lane + j * 64;
+    if (v < nvec) {
+      half8_t hx = *reinterpret_cast<const half8_t*>(xr + v * 8);
+      half8_t hg = *reinterpret_cast<const half8_t*>(gr + v * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = ((float)hx[e] - mean) * rstd;
+        float d = (float)hg[e] * gamma[v * 8 + e];
+        xh[j][e] = a;
+        dxh[j][e] = d;
+        s1 += d;
+        s2 += d * a;
+      }
+    }
+  }
+  s1 = wave_sum(s1) / C;
+  s2 = wave_sum(s2) / C;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int v = lane + j * 64;
+    if (v < nvec) {
+      half8_t o;
+      if (accumulate) o = *reinterpret_cast<const half8_t*>(dr + v * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float dx = rstd * (dxh[j][e] - s1 - xh[j][e] * s2);
+        if (accumulate) dx += (float)o[e];
+        o[e] = (half_t)dx;
+      }
+      *reinterpret_cast<half8_t*>(dr + v * 8) = o;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int lgd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, int B, int HW,
+                                 int G, float eps, const float* gamma, const float* beta, int silu,
+                                 void* y, float* part, int nchunk, float* stats, void* stream) {
+  const int C = c0 + c1;
+  if (G > 64 || C > GN_MAXC || (C % G) || (c0 % 8) || (c1 % 8) || nchunk < 1) return LGD_ERR_ARG;
+  if (c1 > 0 && !x1) return LGD_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, st, (const half_t*)x0,
+                     (const half_t*)x1, c0, c1, HW, G, part, nchunk);
+  int napply = (int)(((long)HW * C / 8 + 2047) / 2048);  // ~8 vectors per thread
+  if (napply < 1) napply = 1;
+  if (napply > HW) napply = HW;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(napply, B), dim3(256), 0, st, (const half_t*)x0,
+                     (const half_t*)x1, c0, c1, HW, G, eps, gamma, beta, silu, (half_t*)y, part,
+                     nchunk, stats, napply);
+  return lgd_check_launch();
+}
+
+extern "C" int lgd_groupnorm_bwd_f16(const void* gy, const void* x0, const void* x1, int c0, int c1,
+                                     int B, int HW, int G, const float* gamma, const float* beta,
+                                     int silu, const float* stats, void* gx0, void* gx1, float* part,
+                                     int nchunk, int accumulate, void* stream) {
+  const int C = c0 + c1;
+  if (G > 64 || C > GN_MAXC || (C % G) || (c0 % 8) || (c1 % 8) || nchunk < 1) return LGD_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nchunk, B), dim3(256), 0, st, (const half_t*)gy,
+                     (const half_t*)x0, (const half_t*)x1, c0, c1, HW, G, gamma, beta, silu, stats,
+                     part, nchunk);
+  int napply = (int)(((long)HW * C / 8 + 2047) / 2048);
+  if (napply < 1) napply = 1;
+  if (napply > HW) napply = HW;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(napply, B), dim3(256), 0, st, (const half_t*)gy,
+                     (const half_t*)x0, (const half_t*)x1, c0, c1, HW, G, gamma, beta, silu, stats,
+                     (half_t*)gx0, (half_t*)gx1, part, nchunk, accumulate, napply);
+  return lgd_check_launch();
+}
+
+extern "C" int lgd_layernorm_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int rows, int C,
+                                 float eps, const float* gamma, const float* beta, float* stats,
+                                 int rows_per_batch, int64_t x_bs, int64_t y_bs, void* stream) {
+  if ((C % 8) || C > 64 * 8 * LN_MAXV || rows < 1) return LGD_ERR_ARG;
+  if (rows_per_batch < 1) rows_per_batch = rows;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, (const half_t*)x,
+                     (long)ldx, (half_t*)y, (long)ldy, rows, C, eps, gamma, beta, stats,
+                     rows_per_batch, (long)x_bs, (long)y_bs);
+  return lgd_check_launch();
+}
+
+extern "C" int lgd_layernorm_bwd_f16(const void* gy, int64_t ldgy, const void* x, int64_t ldx,
+                                     void* gx, int64_t ldgx, int rows, int C, const float* gamma,
+                                     const float* stats, int rows_per_batch, int64_t gy_bs,
+                                     int64_t x_bs, int64_t gx_bs, int accumulate, void* stream) {
+  if ((C % 8) || C > 64 * 8 * LN_MAXV || rows < 1 || !stats) return LGD_ERR_ARG;
+  if (rows_per_batch < 1) rows_per_batch = rows;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st,
+                     (const half_t*)gy, (long)ldgy, (const half_t*)x, (long)ldx, (half_t*)gx,
+                     (long)ldgx, rows, C, gamma, stats, rows_per_batch, (long)gy_bs, (long)x_bs,
+                     (long)gx_bs, accumulate);
+  return lgd_check_launch();
+}

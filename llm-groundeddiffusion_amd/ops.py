@@ -1,0 +1,304 @@
+"""Thin host wrappers over the C ABI: torch tensors in, raw device pointers across the boundary.
+
+torch is used for device memory and the current HIP stream only.  Every function enqueues kernels on
+`torch.cuda.current_stream()` and returns immediately (graph-capturable).  No fallbacks: a failing
+call raises RuntimeError (the error convention of the reference's plugin boundary,
+generate.py:391-396).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import EPI_GEGLU, EPI_OUT_F32, EPI_RES_F32, LgdGemmDesc
+
+F16, F32 = torch.float16, torch.float32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _call(name, *args):
+    lib = _lib.load()
+    rc = getattr(lib, name)(*args)
+    _lib.check(rc, name)
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM / conv
+# ---------------------------------------------------------------------------------------------
+def gemm_desc(a0, w, c, M, N, K, *, a1=None, lda0=None, lda1=0, c0=None, c1=0, taps=1,
+              hin=0, win=0, hout=0, wout=0, stride=1, ups=0, ldw=None, bias=None, bias2=None,
+              res=None, ldr=0, alpha=1.0, epi=0, ldc=None, splits=1, ws=None, tile=0,
+              nb_o=1, nb_i=1, a_bs=(0, 0), w_bs=(0, 0), c_bs=(0, 0), r_bs=(0, 0)):
+    """Builds an LgdGemmDesc from raw pointers (ints) or tensors."""
+    d = LgdGemmDesc()
+    ptr = lambda t: (t.data_ptr() if torch.is_tensor(t) else (t or 0))
+    d.a0, d.a1 = ptr(a0), ptr(a1)
+    cin = K // taps
+    d.c0 = cin - c1 if c0 is None else c0
+    d.c1 = c1
+    d.lda0 = d.c0 if lda0 is None else lda0
+    d.lda1 = lda1 if lda1 else max(c1, 0)
+    d.taps, d.hin, d.win, d.hout, d.wout, d.stride, d.ups = taps, hin, win, hout, wout, stride, ups
+    d.w = ptr(w)
+    d.ldw = K if ldw is None else ldw
+    d.M, d.N, d.K = M, N, K
+    d.nb_o, d.nb_i = nb_o, nb_i
+    d.a_bs_o, d.a_bs_i = a_bs
+    d.w_bs_o, d.w_bs_i = w_bs
+    d.c_bs_o, d.c_bs_i = c_bs
+    d.r_bs_o, d.r_bs_i = r_bs
+    d.bias, d.bias2 = ptr(bias), ptr(bias2)
+    d.res, d.ldr = ptr(res), ldr
+    d.alpha, d.epi = alpha, epi
+    d.c = ptr(c)
+    n_out = N // 2 if (epi & EPI_GEGLU) else N
+    d.ldc = n_out if ldc is None else ldc
+    d.splits, d.ws, d.tile = splits, ptr(ws), tile
+    return d
+
+
+def gemm_launch(desc):
+    _call("lgd_gemm_f16", C.byref(desc), _stream())
+
+
+def linear(x, w, bias=None, res=None, out=None, *, alpha=1.0, geglu=False, out_f32=False,
+           splits=1, ws=None, tile=0, bias2=None):
+    """y = x @ w.T (+bias) ... ; x [M,K] fp16 contiguous, w [N,K] fp16."""
+    M, K = x.shape
+    N = w.shape[0]
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty((M, n_out), device=x.device, dtype=F32 if out_f32 else F16)
+    epi = (EPI_GEGLU if geglu else 0) | (EPI_OUT_F32 if out_f32 else 0)
+    if res is not None and res.dtype == F32:
+        epi |= EPI_RES_F32
+    if splits > 1 and ws is None:
+        ws = torch.empty((splits, M, N), device=x.device, dtype=F32)
+    d = gemm_desc(x, w, out, M, N, K, bias=bias, bias2=bias2, res=res,
+                  ldr=(res.stride(0) if res is not None else 0), alpha=alpha, epi=epi,
+                  splits=splits, ws=ws, tile=tile, lda0=x.stride(0), ldw=w.stride(0),
+                  ldc=out.stride(0))
+    gemm_launch(d)
+    return out
+
+
+def conv3x3(x, w, B, H, W, *, x1=None, bias=None, bias2=None, res=None, stride=1, ups=False,
+            out=None, splits=1, ws=None, tile=0, alpha=1.0):
+    """3x3 conv, pad 1, channels-last.  x [B*H*W, C0] (stored map; with ups the logical input is
+    2H x 2W), optional x1 [B*H*W, C1] concatenated on channels; w [Cout, 9*(C0+C1)]."""
+    c0 = x.shape[1]
+    c1 = x1.shape[1] if x1 is not None else 0
+    Cout = w.shape[0]
+    K = 9 * (c0 + c1)
+    assert w.shape[1] == K
+    if ups:
+        Hl, Wl = 2 * H, 2 * W
+    else:
+        Hl, Wl = H, W
+    Ho, Wo = (Hl - 1) // stride + 1, (Wl - 1) // stride + 1
+    M = B * Ho * Wo
+    if out is None:
+        out = torch.empty((M, Cout), device=x.device, dtype=F16)
+    if splits > 1 and ws is None:
+        ws = torch.empty((splits, M, Cout), device=x.device, dtype=F32)
+    d = gemm_desc(x, w, out, M, Cout, K, a1=x1, c0=c0, c1=c1, lda0=x.stride(0),
+                  lda1=(x1.stride(0) if x1 is not None else 0), taps=9, hin=H, win=W, hout=Ho,
+                  wout=Wo, stride=stride, ups=1 if ups else 0, bias=bias, bias2=bias2, res=res,
+                  ldr=(res.stride(0) if res is not None else 0), splits=splits, ws=ws, tile=tile,
+                  alpha=alpha, ldc=out.stride(0))
+    gemm_launch(d)
+    return out
+
+
+def conv_in(x_nchw, w, bias, out=None):
+    B, Cin, L, _ = x_nchw.shape
+    Cout = w.shape[0]
+    if out is None:
+        out = torch.empty((B * L * L, Cout), device=x_nchw.device, dtype=F16)
+    _call("lgd_conv_in_f16", _p(x_nchw), _p(w), _p(bias), _p(out), B, Cin, L, Cout, _stream())
+    return out
+
+
+def conv_out(x, w, bias, B, L, out=None, out_scale=1.0):
+    Cin = x.shape[1]
+    Cout = w.shape[0]
+    if out is None:
+        out = torch.empty((B, Cout, L, L), device=x.device, dtype=F32)
+    _call("lgd_conv_out_f16", _p(x), _p(w), _p(bias), _p(out), B, Cin, L, Cout, float(out_scale),
+          _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# norms
+# ---------------------------------------------------------------------------------------------
+def gn_chunks(B, HW):
+    n = max(1, min(HW // 16, max(1, 512 // max(B, 1))))
+    return min(n, 256)
+
+
+def groupnorm(x, B, HW, G, eps, gamma, beta, silu, *, x1=None, out=None, part=None, stats=None):
+    c0 = x.shape[1]
+    c1 = x1.shape[1] if x1 is not None else 0
+    C_ = c0 + c1
+    nchunk = gn_chunks(B, HW)
+    if out is None:
+        out = torch.empty((B * HW, C_), device=x.device, dtype=F16)
+    if part is None:
+        part = torch.empty((B, nchunk, G, 2), device=x.device, dtype=F32)
+    _call("lgd_groupnorm_f16", _p(x), _p(x1), c0, c1, B, HW, G, float(eps), _p(gamma), _p(beta),
+          1 if silu else 0, _p(out), _p(part), nchunk, _p(stats), _stream())
+    return out
+
+
+def groupnorm_bwd(gy, x, B, HW, G, gamma, beta, silu, stats, *, x1=None, gx0=None, gx1=None,
+                  part=None, accumulate=False):
+    c0 = x.shape[1]
+    c1 = x1.shape[1] if x1 is not None else 0
+    nchunk = gn_chunks(B, HW)
+    if gx0 is None:
+        gx0 = torch.empty_like(x)
+    if x1 is not None and gx1 is None:
+        gx1 = torch.empty_like(x1)
+    if part is None:
+        part = torch.empty((B, nchunk, G, 2), device=x.device, dtype=F32)
+    _call("lgd_groupnorm_bwd_f16", _p(gy), _p(x), _p(x1), c0, c1, B, HW, G, _p(gamma), _p(beta),
+          1 if silu else 0, _p(stats), _p(gx0), _p(gx1), _p(part), nchunk, 1 if accumulate else 0,
+          _stream())
+    return gx0, gx1
+
+
+def layernorm(x, gamma, beta, eps=1e-5, *, out=None, ldy=None, stats=None, rows_per_batch=0,
+              x_bs=0, y_bs=0, rows=None, ldx=None):
+    C_ = gamma.shape[0]
+    if rows is None:
+        rows = x.numel() // C_
+    if out is None:
+        out = torch.empty((rows, C_), device=x.device, dtype=F16)
+    _call("lgd_layernorm_f16", _p(x), ldx or C_, _p(out), ldy or C_, rows, C_, float(eps), _p(gamma),
+          _p(beta), _p(stats), rows_per_batch, x_bs, y_bs, _stream())
+    return out
+
+
+def layernorm_bwd(gy, x, gamma, stats, *, gx=None, rows=None, ldgy=None, ldx=None, ldgx=None,
+                  rows_per_batch=0, gy_bs=0, x_bs=0, gx_bs=0, accumulate=False):
+    C_ = gamma.shape[0]
+    if rows is None:
+        rows = x.numel() // C_
+    if gx is None:
+        gx = torch.empty((rows, C_), device=x.device, dtype=F16)
+    _call("lgd_layernorm_bwd_f16", _p(gy), ldgy or C_, _p(x), ldx or C_, _p(gx), ldgx or C_, rows, C_,
+          _p(gamma), _p(stats), rows_per_batch, gy_bs, x_bs, gx_bs, 1 if accumulate else 0, _stream())
+    return gx
+
+
+# ---------------------------------------------------------------------------------------------
+# attention.  Views are (tensor, ld, batch_stride) with head h at column offset h*d.
+# ---------------------------------------------------------------------------------------------
+def attn_fwd(q, k, v, o, B, H, Sq, Sk, d, scale, *, lse=None, q_view=None, k_view=None,
+             v_view=None, o_view=None):
+    qv = q_view or (H * d, Sq * H * d)
+    kv = k_view or (H * d, Sk * H * d)
+    vv = v_view or (H * d, Sk * H * d)
+    ov = o_view or (H * d, Sq * H * d)
+    _call("lgd_attn_fwd_f16", _p(q), qv[0], qv[1], _p(k), kv[0], kv[1], _p(v), vv[0], vv[1], _p(o),
+          ov[0], ov[1], _p(lse), B, H, Sq, Sk, d, float(scale), _stream())
+    return o
+
+
+def attn_bwd(q, k, v, o, go, lse, delta, gq, gk, gv, B, H, Sq, Sk, d, scale, *, q_view=None,
+             k_view=None, v_view=None, o_view=None, go_view=None, gq_view=None, gk_view=None,
+             gv_view=None):
+    dq_ = (H * d, Sq * H * d)
+    dk_ = (H * d, Sk * H * d)
+    qv, kv, vv = q_view or dq_, k_view or dk_, v_view or dk_
+    ov, gov = o_view or dq_, go_view or dq_
+    gqv, gkv, gvv = gq_view or dq_, gk_view or dk_, gv_view or dk_
+    _call("lgd_attn_bwd_f16", _p(q), qv[0], qv[1], _p(k), kv[0], kv[1], _p(v), vv[0], vv[1], _p(o),
+          ov[0], ov[1], _p(go), gov[0], gov[1], _p(lse), _p(delta), _p(gq), gqv[0], gqv[1], _p(gk),
+          gkv[0], gkv[1], _p(gv), gvv[0], gvv[1], B, H, Sq, Sk, d, float(scale), _stream())
+
+
+def cross_attn_fwd(q, k, v, o, B, H, Sq, Sk, d, scale, *, probs=None, tok=-1, cond_only=False,
+                   q_view=None, k_view=None, v_view=None, o_view=None):
+    qv = q_view or (H * d, Sq * H * d)
+    kv = k_view or (H * d, Sk * H * d)
+    vv = v_view or (H * d, Sk * H * d)
+    ov = o_view or (H * d, Sq * H * d)
+    _call("lgd_cross_attn_fwd_f16", _p(q), qv[0], qv[1], _p(k), kv[0], kv[1], _p(v), vv[0], vv[1],
+          _p(o), ov[0], ov[1], _p(probs), int(tok), 1 if cond_only else 0, B, H, Sq, Sk, d,
+          float(scale), _stream())
+    return o
+
+
+def cross_attn_bwd(q, k, v, go, gp, gq, B, H, Sq, Sk, d, scale, *, q_view=None, k_view=None,
+                   v_view=None, go_view=None, gq_view=None):
+    dq_ = (H * d, Sq * H * d)
+    dk_ = (H * d, Sk * H * d)
+    qv, kv, vv = q_view or dq_, k_view or dk_, v_view or dk_
+    gov, gqv = go_view or dq_, gq_view or dq_
+    _call("lgd_cross_attn_bwd_f16", _p(q), qv[0], qv[1], _p(k), kv[0], kv[1], _p(v), vv[0], vv[1],
+          _p(go), gov[0], gov[1], _p(gp), _p(gq), gqv[0], gqv[1], B, H, Sq, Sk, d, float(scale),
+          _stream())
+    return gq
+
+
+# ---------------------------------------------------------------------------------------------
+# elementwise / step
+# ---------------------------------------------------------------------------------------------
+def geglu_bwd(h, gy, gh=None):
+    rows, n2 = h.shape
+    if gh is None:
+        gh = torch.empty_like(h)
+    _call("lgd_geglu_bwd_f16", _p(h), _p(gy), _p(gh), rows, n2 // 2, _stream())
+    return gh
+
+
+def add(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    _call("lgd_add_f16", _p(a), _p(b), _p(out), a.numel(), _stream())
+    return out
+
+
+def scale(x, alpha, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    _call("lgd_scale_f16", _p(x), _p(out), float(alpha), x.numel(), _stream())
+    return out
+
+
+def upsample2x_bwd(gy, B, H, W, C_, out=None):
+    if out is None:
+        out = torch.empty((B * H * W, C_), device=gy.device, dtype=F16)
+    _call("lgd_upsample2x_bwd_f16", _p(gy), _p(out), B, H, W, C_, _stream())
+    return out
+
+
+def cfg_ddim_step(eps, x, x_out, coef_table, step_idx, *, frozen_ref=None, mask=None,
+                  frozen_steps=0, hist=None):
+    B, C_, L, _ = x.shape
+    _call("lgd_cfg_ddim_step_f32", _p(eps), _p(x), _p(x_out), _p(coef_table), _p(step_idx),
+          _p(frozen_ref), _p(mask), int(frozen_steps), _p(hist), B, C_, L * L, _stream())
+    return x_out
+
+
+def axpy(g, x, coef_table, step_idx, col):
+    _call("lgd_axpy_f32", _p(g), _p(x), _p(coef_table), _p(step_idx), int(col), x.numel(), _stream())
+
+
+def select_row(table, idx, out):
+    _call("lgd_select_row_f32", _p(table), _p(idx), _p(out), out.numel(), _stream())
+
+
+def ca_energy(map_ptrs, gmap_ptrs, map_hw, items, coefs, masks, refs, n_items, H, T, max_hw,
+              partial, loss):
+    _call("lgd_ca_energy_f32", _p(map_ptrs), _p(gmap_ptrs), _p(map_hw), _p(items), _p(coefs),
+          _p(masks), _p(refs), n_items, H, T, max_hw, _p(partial), _p(loss), _stream())

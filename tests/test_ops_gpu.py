@@ -1,0 +1,345 @@
+"""Per-kernel parity: each C-ABI entry point vs the plain PyTorch fp32 op sequence it replaces
+(inputs rounded to fp16 first, reference computed in fp32).  Tolerances are stated per test."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import lgd_amd  # noqa: E402
+from lgd_amd import ops  # noqa: E402
+
+H16, F32 = torch.float16, torch.float32
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
+
+
+def rnd(*shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+def pack_conv_w(w):  # [Cout,Cin,3,3] -> [Cout, 9*Cin] (ky,kx,ci)
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+def pack_geglu(w, b):  # [2n,K] -> 16-row value/gate interleave
+    n = w.shape[0] // 2
+    idx = []
+    for j in range(n // 16):
+        idx += list(range(16 * j, 16 * j + 16)) + list(range(n + 16 * j, n + 16 * j + 16))
+    idx = torch.tensor(idx, device=w.device)
+    return w[idx].contiguous(), (b[idx].contiguous() if b is not None else None)
+
+
+@pytest.mark.parametrize("M,N,K,tile,splits", [
+    (8192, 320, 320, 0, 1), (4100, 640, 640, 1, 1), (512, 1280, 1280, 2, 1), (128, 1280, 5120, 4, 4),
+    (77, 320, 768, 5, 1), (154, 1280, 768, 0, 1), (30, 640, 768, 5, 3), (2048, 640, 2560, 3, 2),
+    (64, 64, 32, 4, 1), (100, 100, 72, 2, 1),
+])
+def test_gemm_plain(dev, M, N, K, tile, splits):
+    x = rnd(M, K, dev=dev, seed=1).half()
+    w = rnd(N, K, dev=dev, seed=2, scale=K ** -0.5).half()
+    b = rnd(N, dev=dev, seed=3)
+    r = rnd(M, N, dev=dev, seed=4).half()
+    y = ops.linear(x, w, b, res=r, tile=tile, splits=splits, alpha=0.5)
+    ref = (x.float() @ w.float().t() + b) * 0.5 + r.float()
+    assert relerr(y, ref) < 3e-3
+
+
+def test_gemm_out_f32_bias2(dev):
+    M, N, K = 300, 320, 640
+    x = rnd(M, K, dev=dev, seed=1).half()
+    w = rnd(N, K, dev=dev, seed=2, scale=K ** -0.5).half()
+    b, b2 = rnd(N, dev=dev, seed=3), rnd(N, dev=dev, seed=5)
+    y = ops.linear(x, w, b, bias2=b2, out_f32=True)
+    ref = x.float() @ w.float().t() + b + b2
+    assert y.dtype == F32 and relerr(y, ref) < 1e-3
+
+
+@pytest.mark.parametrize("M,dim,splits", [(4096, 320, 1), (300, 640, 1), (128, 1280, 2)])
+def test_gemm_geglu(dev, M, dim, splits):
+    inner = 4 * dim
+    x = rnd(M, dim, dev=dev, seed=1).half()
+    w = rnd(2 * inner, dim, dev=dev, seed=2, scale=dim ** -0.5).half()
+    b = rnd(2 * inner, dev=dev, seed=3)
+    wp, bp = pack_geglu(w, b)
+    y = ops.linear(x, wp, bp, geglu=True, splits=splits)
+    h = x.float() @ w.float().t() + b
+    v, g = h.chunk(2, dim=-1)
+    ref = v * F.gelu(g)
+    assert y.shape == (M, inner) and relerr(y, ref) < 3e-3
+
+
+@pytest.mark.parametrize("B,H,C0,C1,Cout,stride,ups,splits", [
+    (2, 16, 64, 0, 64, 1, False, 1), (2, 32, 320, 0, 320, 1, False, 1),
+    (1, 16, 128, 64, 128, 1, False, 1), (2, 8, 1280, 1280, 1280, 1, False, 8),
+    (2, 16, 320, 0, 320, 2, False, 1), (1, 8, 640, 0, 640, 1, True, 1),
+    (1, 10, 64, 0, 128, 1, False, 1), (1, 16, 64, 0, 64, 1, 2, 1),
+])
+def test_conv3x3(dev, B, H, C0, C1, Cout, stride, ups, splits):
+    C = C0 + C1
+    x = rnd(B, C, H, H, dev=dev, seed=1).half()
+    w = rnd(Cout, C, 3, 3, dev=dev, seed=2, scale=(9 * C) ** -0.5).half()
+    b = rnd(Cout, dev=dev, seed=3)
+    xl = x.permute(0, 2, 3, 1).reshape(B * H * H, C).contiguous()
+    x0 = xl[:, :C0].contiguous()
+    x1 = xl[:, C0:].contiguous() if C1 else None
+    xin = x.float()
+    if ups == 1 or ups is True:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    elif ups == 2:
+        z = torch.zeros(B, C, 2 * H, 2 * H, device=dev)
+        z[:, :, ::2, ::2] = xin
+        xin = z
+    ref = F.conv2d(xin, w.float(), b, stride=stride, padding=1)
+    Ho = ref.shape[-1]
+    res = rnd(B * Ho * Ho, Cout, dev=dev, seed=7).half()
+    y = ops.conv3x3(x0, pack_conv_w(w), B, H, H, x1=x1, bias=b, res=res, stride=stride,
+                    ups=int(ups), splits=splits)
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, Cout) + res.float()
+    assert relerr(y, ref) < 3e-3
+
+
+def test_conv_dgrad_identity(dev):
+    """dgrad of a stride-1 conv = conv with flipped, transposed weights (how the engine calls it)."""
+    B, H, Cin, Cout = 1, 16, 64, 128
+    x = rnd(B, Cin, H, H, dev=dev, seed=1).requires_grad_(True)
+    w = rnd(Cout, Cin, 3, 3, dev=dev, seed=2, scale=0.05).half()
+    gy = rnd(B, Cout, H, H, dev=dev, seed=3).half()
+    F.conv2d(x, w.float(), padding=1).backward(gy.float())
+    wd = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()  # [Cin, Cout, 3, 3]
+    gyl = gy.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous()
+    gx = ops.conv3x3(gyl, pack_conv_w(wd), B, H, H)
+    ref = x.grad.permute(0, 2, 3, 1).reshape(-1, Cin)
+    assert relerr(gx, ref) < 3e-3
+
+
+def test_conv_in_out(dev):
+    B, L, C = 2, 64, 320
+    x = rnd(B, 4, L, L, dev=dev, seed=1)
+    w = rnd(C, 4, 3, 3, dev=dev, seed=2, scale=0.15).half()
+    b = rnd(C, dev=dev, seed=3)
+    y = ops.conv_in(x, pack_conv_w(w), b)
+    ref = F.conv2d(x, w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, C)
+    assert relerr(y, ref) < 2e-3
+    h = rnd(B * L * L, C, dev=dev, seed=4).half()
+    w2 = rnd(4, C, 3, 3, dev=dev, seed=5, scale=0.02).half()
+    b2 = rnd(4, dev=dev, seed=6)
+    o = ops.conv_out(h, pack_conv_w(w2), b2, B, L, out_scale=0.5)
+    ref2 = F.conv2d(h.float().reshape(B, L, L, C).permute(0, 3, 1, 2), w2.float(), b2, padding=1) * 0.5
+    assert relerr(o, ref2) < 1e-3
+
+
+@pytest.mark.parametrize("B,HW,C0,C1,silu,eps", [
+    (2, 4096, 320, 0, True, 1e-5), (2, 1024, 640, 320, True, 1e-5), (1, 256, 1280, 1280, True, 1e-5),
+    (2, 64, 1280, 0, False, 1e-6), (1, 4096, 64, 0, True, 1e-5), (2, 256, 128, 64, False, 1e-6),
+])
+def test_groupnorm_fwd_bwd(dev, B, HW, C0, C1, silu, eps):
+    C, G = C0 + C1, 32
+    x = (rnd(B, HW, C, dev=dev, seed=1) * 2 + 0.5).half()
+    gamma, beta = 1 + 0.2 * rnd(C, dev=dev, seed=2), 0.2 * rnd(C, dev=dev, seed=3)
+    x0 = x[..., :C0].reshape(B * HW, C0).contiguous()
+    x1 = x[..., C0:].reshape(B * HW, C1).contiguous() if C1 else None
+    stats = torch.empty(B, G, 2, device=dev)
+    y = ops.groupnorm(x0, B, HW, G, eps, gamma, beta, silu, x1=x1, stats=stats)
+    xr = x.float().permute(0, 2, 1).clone().requires_grad_(True)  # (B, C, HW)
+    ref = F.group_norm(xr, G, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    refl = ref.permute(0, 2, 1).reshape(B * HW, C)
+    assert relerr(y, refl) < 3e-3
+    gy = rnd(B * HW, C, dev=dev, seed=4).half()
+    ref.backward(gy.float().reshape(B, HW, C).permute(0, 2, 1))
+    gx0, gx1 = ops.groupnorm_bwd(gy, x0, B, HW, G, gamma, beta, silu, stats, x1=x1)
+    gref = xr.grad.permute(0, 2, 1)
+    assert relerr(gx0, gref[..., :C0].reshape(B * HW, C0)) < 5e-3
+    if C1:
+        assert relerr(gx1, gref[..., C0:].reshape(B * HW, C1)) < 5e-3
+
+
+@pytest.mark.parametrize("rows,C", [(8192, 320), (2048, 640), (513, 1280), (30, 64)])
+def test_layernorm_fwd_bwd(dev, rows, C):
+    x = (rnd(rows, C, dev=dev, seed=1) * 1.5 + 0.3).half()
+    gamma, beta = 1 + 0.2 * rnd(C, dev=dev, seed=2), 0.2 * rnd(C, dev=dev, seed=3)
+    stats = torch.empty(rows, 2, device=dev)
+    y = ops.layernorm(x, gamma, beta, stats=stats)
+    xr = x.float().clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gamma, beta, 1e-5)
+    assert relerr(y, ref) < 2e-3
+    gy = rnd(rows, C, dev=dev, seed=4).half()
+    ref.backward(gy.float())
+    gx = ops.layernorm_bwd(gy, x, gamma, stats)
+    assert relerr(gx, xr.grad) < 5e-3
+
+
+def _attn_ref(q, k, v, scale):
+    s = torch.einsum("bhqd,bhkd->bhqk", q, k) * scale
+    p = s.softmax(-1)
+    return torch.einsum("bhqk,bhkd->bhqd", p, v), p
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk,d", [
+    (2, 8, 4096, 4096, 40), (2, 8, 1024, 1054, 80), (1, 8, 256, 286, 160), (2, 8, 64, 64, 160),
+    (1, 5, 576, 576, 64), (2, 8, 100, 77, 8), (1, 8, 256, 256, 16), (1, 8, 64, 94, 32),
+])
+def test_attn_fwd_bwd(dev, B, H, Sq, Sk, d):
+    C = H * d
+    scale = d ** -0.5
+    q = rnd(B, Sq, C, dev=dev, seed=1).half()
+    k = rnd(B, Sk, C, dev=dev, seed=2).half()
+    v = rnd(B, Sk, C, dev=dev, seed=3).half()
+    o = torch.empty(B, Sq, C, device=dev, dtype=H16)
+    lse = torch.empty(B, H, Sq, device=dev)
+    ops.attn_fwd(q, k, v, o, B, H, Sq, Sk, d, scale, lse=lse)
+    sp = lambda t, S: t.float().reshape(B, S, H, d).permute(0, 2, 1, 3).clone().requires_grad_(True)
+    qr, kr, vr = sp(q, Sq), sp(k, Sk), sp(v, Sk)
+    ref, _ = _attn_ref(qr, kr, vr, scale)
+    refl = ref.permute(0, 2, 1, 3).reshape(B, Sq, C)
+    assert relerr(o, refl) < 4e-3
+    # backward
+    go = rnd(B, Sq, C, dev=dev, seed=4).half()
+    ref.backward(go.float().reshape(B, Sq, H, d).permute(0, 2, 1, 3))
+    gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty(B, H, Sq, device=dev)
+    ops.attn_bwd(q, k, v, o, go, lse, delta, gq, gk, gv, B, H, Sq, Sk, d, scale)
+    un = lambda t, S: t.permute(0, 2, 1, 3).reshape(B, S, C)
+    assert relerr(gq, un(qr.grad, Sq)) < 1e-2
+    assert relerr(gk, un(kr.grad, Sk)) < 1e-2
+    assert relerr(gv, un(vr.grad, Sk)) < 1e-2
+
+
+def test_attn_qkv_fused_view(dev):
+    """q/k/v taken as column views of one fused [B,S,3C] projection output."""
+    B, H, S, d = 2, 8, 256, 40
+    C = H * d
+    qkv = rnd(B, S, 3 * C, dev=dev, seed=1).half()
+    o = torch.empty(B, S, C, device=dev, dtype=H16)
+    view = (3 * C, S * 3 * C)
+    ops.attn_fwd(qkv, qkv[:, :, C:], qkv[:, :, 2 * C:], o, B, H, S, S, d, d ** -0.5,
+                 q_view=view, k_view=view, v_view=view)
+    sp = lambda t: t.float().reshape(B, S, H, d).permute(0, 2, 1, 3)
+    ref, _ = _attn_ref(sp(qkv[..., :C]), sp(qkv[..., C:2 * C]), sp(qkv[..., 2 * C:]), d ** -0.5)
+    assert relerr(o, ref.permute(0, 2, 1, 3).reshape(B, S, C)) < 4e-3
+
+
+@pytest.mark.parametrize("B,H,Sq,d,tok,cond_only", [
+    (2, 8, 4096, 40, -1, False), (2, 8, 256, 160, 5, True), (1, 8, 64, 160, -1, False),
+    (2, 8, 1024, 80, -1, True), (1, 8, 256, 8, 3, False),
+])
+def test_cross_attn_maps(dev, B, H, Sq, d, tok, cond_only):
+    Sk, C = 77, H * d
+    scale = d ** -0.5
+    q = (rnd(B, Sq, C, dev=dev, seed=1) * 2).half()
+    k = rnd(B, Sk, C, dev=dev, seed=2).half()
+    v = rnd(B, Sk, C, dev=dev, seed=3).half()
+    o = torch.empty(B, Sq, C, device=dev, dtype=H16)
+    Bp = B // 2 if cond_only else B
+    Tp = 1 if tok >= 0 else Sk
+    probs = torch.zeros(Bp, H, Sq, Tp, device=dev)
+    ops.cross_attn_fwd(q, k, v, o, B, H, Sq, Sk, d, scale, probs=probs, tok=tok, cond_only=cond_only)
+    sp = lambda t, S: t.float().reshape(B, S, H, d).permute(0, 2, 1, 3)
+    ref, p = _attn_ref(sp(q, Sq), sp(k, Sk), sp(v, Sk), scale)
+    assert relerr(o, ref.permute(0, 2, 1, 3).reshape(B, Sq, C)) < 4e-3
+    if tok >= 0:
+        p = p[..., tok:tok + 1]
+    if cond_only:
+        p = p[B // 2:]
+    assert relerr(probs, p) < 2e-3
+    # no-map variant must agree with the map variant
+    o2 = torch.empty_like(o)
+    ops.cross_attn_fwd(q, k, v, o2, B, H, Sq, Sk, d, scale)
+    assert relerr(o2, o) < 2e-3
+
+
+@pytest.mark.parametrize("B,H,Sq,d,with_go,with_gp", [
+    (1, 8, 256, 160, True, True), (1, 8, 64, 160, False, True), (2, 8, 1024, 80, True, False),
+    (1, 8, 100, 8, True, True),
+])
+def test_cross_attn_bwd(dev, B, H, Sq, d, with_go, with_gp):
+    Sk, C = 77, H * d
+    scale = d ** -0.5
+    q = rnd(B, Sq, C, dev=dev, seed=1).half()
+    k = rnd(B, Sk, C, dev=dev, seed=2).half()
+    v = rnd(B, Sk, C, dev=dev, seed=3).half()
+    sp = lambda t, S: t.float().reshape(B, S, H, d).permute(0, 2, 1, 3)
+    qr = sp(q, Sq).clone().requires_grad_(True)
+    ref, p = _attn_ref(qr, sp(k, Sk), sp(v, Sk), scale)
+    go = rnd(B, Sq, C, dev=dev, seed=4).half() if with_go else None
+    gp = rnd(B, H, Sq, Sk, dev=dev, seed=5) if with_gp else None
+    loss = 0
+    if with_go:
+        loss = loss + (ref * sp(go, Sq)).sum()
+    if with_gp:
+        loss = loss + (p * gp).sum()
+    loss.backward()
+    gq = torch.empty_like(q)
+    ops.cross_attn_bwd(q, k, v, go, gp, gq, B, H, Sq, Sk, d, scale)
+    assert relerr(gq, qr.grad.permute(0, 2, 1, 3).reshape(B, Sq, C)) < 5e-3
+
+
+def test_geglu_bwd_and_elementwise(dev):
+    rows, n = 300, 1280
+    w = rnd(rows, 2 * n, dev=dev, seed=1).half()  # natural layout [v | g]
+    hp, _ = None, None
+    # pack natural -> 16-blocks along columns
+    idx = []
+    for j in range(n // 16):
+        idx += list(range(16 * j, 16 * j + 16)) + list(range(n + 16 * j, n + 16 * j + 16))
+    idx = torch.tensor(idx, device=dev)
+    hpk = w[:, idx].contiguous()
+    gy = rnd(rows, n, dev=dev, seed=2).half()
+    gh = ops.geglu_bwd(hpk, gy)
+    wr = w.float().clone().requires_grad_(True)
+    vv, gg = wr.chunk(2, dim=-1)
+    (vv * F.gelu(gg)).backward(gy.float())
+    assert relerr(gh, wr.grad[:, idx]) < 3e-3
+    a, b = rnd(1000, 64, dev=dev, seed=3).half(), rnd(1000, 64, dev=dev, seed=4).half()
+    assert relerr(ops.add(a, b), a.float() + b.float()) < 1e-3
+    assert relerr(ops.scale(a, 0.25), a.float() * 0.25) < 1e-3
+    B, H, W, C = 2, 8, 8, 64
+    g = rnd(B * 4 * H * W, C, dev=dev, seed=5).half()
+    gx = ops.upsample2x_bwd(g, B, H, W, C)
+    ref = g.float().reshape(B, H, 2, W, 2, C).sum(dim=(2, 4)).reshape(-1, C)
+    assert relerr(gx, ref) < 2e-3
+
+
+def test_cfg_ddim_step(dev):
+    B, C, L, T = 2, 4, 64, 5
+    eps = rnd(2 * B, C, L, L, dev=dev, seed=1)
+    x = rnd(B, C, L, L, dev=dev, seed=2)
+    table = torch.tensor([[0.5 + 0.05 * i, 0.6 + 0.05 * i, 7.5, 0.0] for i in range(T)], device=dev)
+    ref_lat = rnd(T + 1, B, C, L, L, dev=dev, seed=3)
+    mask = (rnd(B, L * L, dev=dev, seed=4) > 0).float()
+    hist = torch.zeros(T + 1, B, C, L, L, device=dev)
+    for step, frozen_steps, vpred in [(1, 3, 0.0), (4, 3, 0.0), (2, 0, 1.0)]:
+        table[:, 3] = vpred
+        idx = torch.tensor([step], device=dev, dtype=torch.int32)
+        out = torch.empty_like(x)
+        ops.cfg_ddim_step(eps, x, out, table, idx, frozen_ref=ref_lat, mask=mask,
+                          frozen_steps=frozen_steps, hist=hist)
+        a_t, a_p = table[step, 0], table[step, 1]
+        e = eps[:B] + 7.5 * (eps[B:] - eps[:B])
+        if vpred:
+            x0 = a_t.sqrt() * x - (1 - a_t).sqrt() * e
+            e = a_t.sqrt() * e + (1 - a_t).sqrt() * x
+        else:
+            x0 = (x - (1 - a_t).sqrt() * e) / a_t.sqrt()
+        xn = a_p.sqrt() * x0 + (1 - a_p).sqrt() * e
+        if step < frozen_steps:
+            m = mask.reshape(B, 1, L, L)
+            xn = ref_lat[step + 1] * m + xn * (1 - m)
+        assert relerr(out, xn) < 1e-5
+        assert relerr(hist[step + 1], xn) < 1e-5
+    g = rnd(B, C, L, L, dev=dev, seed=9)
+    x2 = x.clone()
+    ops.axpy(g, x2, table, torch.tensor([2], device=dev, dtype=torch.int32), 1)
+    assert relerr(x2, x - table[2, 1] * g) < 1e-6
+    out = torch.empty(4, device=dev)
+    ops.select_row(table, torch.tensor([3], device=dev, dtype=torch.int32), out)
+    assert torch.equal(out, table[3])
