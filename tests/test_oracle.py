@@ -1,0 +1,151 @@
+"""CPU suite: the oracle restatement (oracle/restate.py) against the committed golden fixtures
+(tests/golden/*.npz), which were produced by the REFERENCE'S OWN code (oracle/make_golden.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import restate as R  # noqa: E402
+import lgd_amd  # noqa: E402,F401
+from lgd_amd import weights  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+KEYS = R.DEFAULT_GUIDANCE_ATTN_KEYS
+OBJ_KEY = ("down", 2, 1, 0)
+BBOXES = [[74 / 512, 177 / 512, (74 + 183) / 512, (177 + 235) / 512],
+          [314 / 512, 193 / 512, (314 + 189) / 512, (193 + 216) / 512]]
+OBJ_POS = [[1, 2, 3], [5, 6, 7]]
+WORD_TOK = [3, 7]
+TOL = 2e-4
+
+
+def ks(k):
+    return "_".join(str(x) for x in k)
+
+
+def maxrel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def cfg_dict(cfg):
+    return dict(block_out_channels=cfg.block_out_channels, layers_per_block=cfg.layers_per_block,
+                attention_head_dim=cfg.attention_head_dim, norm_num_groups=cfg.norm_num_groups,
+                norm_eps=cfg.norm_eps, gligen_positive_len=cfg.gligen_positive_len)
+
+
+@pytest.fixture(scope="module", params=["tiny", "tiny_gligen"])
+def model(request):
+    cfg = weights.CONFIGS[request.param]
+    return request.param, cfg_dict(cfg), weights.synth_state_dict(cfg, 0)
+
+
+def test_unet_forward_and_maps(model):
+    name, cd, sd = model
+    g = np.load(os.path.join(GOLD, f"unet_fwd_{name}.npz"))
+    gl = None
+    if "gl_boxes" in g:
+        gl = dict(boxes=torch.from_numpy(g["gl_boxes"]), positive_embeddings=torch.from_numpy(g["gl_emb"]),
+                  masks=torch.from_numpy(g["gl_masks"]))
+        b, e, m, _ = R.prepare_gligen_condition([BBOXES], [torch.from_numpy(g["phrase_emb"])])
+        assert torch.equal(b, gl["boxes"]) and torch.equal(e, gl["positive_embeddings"]) and torch.equal(m, gl["masks"])
+    saved = {}
+    with torch.no_grad():
+        eps = R.unet_forward(sd, cd, torch.from_numpy(g["x"]), int(g["t"]), torch.from_numpy(g["ehs"]),
+                             saved=saved, save_keys=[OBJ_KEY, *KEYS], gligen=gl)
+    assert maxrel(eps, g["eps"]) < TOL
+    for k in [OBJ_KEY, *KEYS]:
+        assert maxrel(saved[k], g["map_" + ks(k)]) < TOL
+
+
+def test_backward_guidance(model):
+    name, cd, sd = model
+    g = np.load(os.path.join(GOLD, f"guidance_{name}.npz"))
+    sched = R.DDIM()
+    sched.set_timesteps(10)
+    assert int(sched.timesteps[1]) == int(g["t"])
+    gl = None
+    if name == "tiny_gligen":
+        f = np.load(os.path.join(GOLD, f"unet_fwd_{name}.npz"))
+        gl = dict(boxes=torch.from_numpy(f["gl_boxes"][:1]), positive_embeddings=torch.from_numpy(f["gl_emb"][:1]),
+                  masks=torch.from_numpy(f["gl_masks"][:1]))
+    lat, loss = R.latent_backward_guidance(
+        sd, cd, sched, torch.from_numpy(g["cond"]), 1, BBOXES, OBJ_POS, sched.timesteps[1],
+        torch.from_numpy(g["latents_in"]), torch.tensor(10000.), loss_scale=5, loss_threshold=0.0, max_iter=3,
+        max_index_step=10, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0,
+        gligen=gl)
+    assert maxrel(lat, g["latents_out"]) < TOL
+    assert maxrel(loss, g["loss_out"]) < TOL
+
+
+def test_energy_value_and_map_gradients():
+    g = np.load(os.path.join(GOLD, "energy.npz"))
+    maps = {k: torch.from_numpy(g["map_" + ks(k)]).requires_grad_(True) for k in KEYS}
+    refs = [[None, {k: torch.from_numpy(g[f"ref_{o}_{ks(k)}"]) for k in KEYS}] for o in range(2)]
+    base = dict(fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+    for tag, kw in (("noref", {}), ("ref", dict(ref_ca_saved_attns=refs, ref_ca_word_token_only=True,
+                                                 ref_ca_last_token_only=True, word_token_indices=WORD_TOK, index=1,
+                                                 ref_ca_loss_weight=2.0))):
+        loss = R.compute_ca_lossv3(maps, BBOXES, OBJ_POS, KEYS, **kw, **base)
+        grads = torch.autograd.grad(loss, [maps[k] for k in KEYS])
+        assert maxrel(loss, g[f"loss_{tag}"]) < 1e-6
+        for k, gr in zip(KEYS, grads):
+            assert maxrel(gr, g[f"grad_{tag}_{ks(k)}"]) < 1e-6
+
+
+def test_sampler_loops_tiny():
+    cfg = weights.CONFIGS["tiny"]
+    cd, sd = cfg_dict(cfg), weights.synth_state_dict(cfg, 0)
+    g = np.load(os.path.join(GOLD, "loops_tiny.npz"))
+    ehs = torch.from_numpy(g["ehs"])
+    inp = (ehs, ehs[:1], ehs[1:])
+    sg = dict(loss_scale=5, loss_threshold=0.0, max_iter=[2, 1], max_index_step=2, guidance_attn_keys=KEYS,
+              fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+    out = R.generate_partial_frozen(sd, cd, R.DDIM(), torch.from_numpy(g["lat_all_in"]),
+                                    torch.from_numpy(g["frozen_mask"]), inp, 4, 2, bboxes=BBOXES,
+                                    object_positions=OBJ_POS, semantic_guidance_kwargs=sg)
+    assert maxrel(out, g["partial_frozen_out"]) < TOL
+    _, saved, lat_all = R.generate_semantic_guidance(
+        sd, cd, R.DDIM(), torch.from_numpy(g["lat0"]), inp, 4, BBOXES, OBJ_POS, semantic_guidance_kwargs=sg,
+        saved_cross_attn_keys=[OBJ_KEY, *KEYS], return_cond_ca_only=True, return_token_ca_only=3)
+    assert maxrel(lat_all, g["sg_latents_all"]) < TOL
+    assert maxrel(saved[0][("up", 1, 1, 0)], g["sg_saved_up11_step0"]) < TOL
+
+
+def test_sampler_loop_gligen():
+    cfg = weights.CONFIGS["tiny_gligen"]
+    cd, sd = cfg_dict(cfg), weights.synth_state_dict(cfg, 0)
+    g = np.load(os.path.join(GOLD, "loops_tiny_gligen.npz"))
+    ehs = torch.from_numpy(g["ehs"])
+    inp = (ehs, ehs[:1], ehs[1:])
+    sg = dict(loss_scale=5, loss_threshold=0.0, max_iter=[2, 1], max_index_step=3, guidance_attn_keys=KEYS,
+              fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+    _, saved, lat_all = R.generate_gligen(
+        sd, cd, R.DDIM(), torch.from_numpy(g["lat_all_in"]), inp, 4, BBOXES, torch.from_numpy(g["phrase_emb"]),
+        gligen_scheduled_sampling_beta=0.5, frozen_steps=2, frozen_mask=torch.from_numpy(g["frozen_mask"]),
+        return_saved_cross_attn=True, saved_cross_attn_keys=[OBJ_KEY, *KEYS], return_cond_ca_only=True,
+        return_token_ca_only=7, semantic_guidance=True, semantic_guidance_bboxes=BBOXES,
+        semantic_guidance_object_positions=OBJ_POS, semantic_guidance_kwargs=sg)
+    assert maxrel(lat_all, g["gligen_latents_all"]) < TOL
+    assert maxrel(saved[1][("up", 1, 1, 0)], g["gligen_saved_up11_step1"]) < TOL
+
+
+def test_host_latent_prep():
+    g = np.load(os.path.join(GOLD, "latents_host.npz"))
+    lst, bg = R.get_input_latents_list(3, 3 + 123456789, BBOXES, 0.1)
+    assert np.array_equal(bg.numpy(), g["bg"]) and np.array_equal(lst[0].numpy(), g["in0"])
+    assert np.array_equal(lst[1].numpy(), g["in1"])
+    masks = [R.proportion_to_mask(b, 64, 64).bool() for b in BBOXES]
+    comp, fg = R.compose_latents([torch.from_numpy(g["lall0"]), torch.from_numpy(g["lall1"])], masks, 3, bg)
+    assert np.array_equal(comp.numpy(), g["composed"]) and np.array_equal(fg.numpy(), g["fg_idx"])
+
+
+def test_parameter_inventory_counts():
+    """structural anchor: SD1.5 = 859.5 M params, GLIGEN = 1068.6 M."""
+    assert weights.num_params(weights.CONFIGS["sd15"]) == 859520964
+    assert weights.num_params(weights.CONFIGS["sd14_gligen"]) == 1068623204
+    assert len(weights.attn_keys(weights.CONFIGS["sd15"])) == 16
