@@ -164,6 +164,8 @@ int lgd_cross_attn_bwd_f16(const void* q, int64_t ldq, int64_t q_bs, const void*
 /* GEGLU backward (attention.py:333-335): h = proj(x) packed [16 value|16 gate] blocks, width 2*n;
  * gy [rows][n] -> gh [rows][2n] in the same packed layout. */
 int lgd_geglu_bwd_f16(const void* h, const void* gy, void* gh, int64_t rows, int n, void* stream);
+/* GEGLU forward on a stored packed pre-activation h [rows][2n] -> y [rows][n] (grad-enabled pass). */
+int lgd_geglu_fwd_f16(const void* h, void* y, int64_t rows, int n, void* stream);
 /* y = a + b (fp16), n elements (gradient fan-in / residual). */
 int lgd_add_f16(const void* a, const void* b, void* y, int64_t n, void* stream);
 /* y = alpha * x (fp16) */
@@ -200,11 +202,13 @@ int lgd_select_row_f32(const float* table, const int32_t* idx, float* out, int n
  *   map_hw: int32[n_maps]; masks: fp32 [n_masks][max_hw] (1 inside the box); refs: fp32
  *   [n_refs][H][max_hw] reference maps R_b (guidance.py:201)
  *   partial: fp32 [n_items*H] workspace; loss: fp32[1] = sum of all terms.
+ *   grad_scale multiplies the map gradients only (static loss scaling for the fp16 backward pass;
+ *   undone by the out_scale of the final conv_in dgrad).
  * ------------------------------------------------------------------------------------------- */
 int lgd_ca_energy_f32(const float* const* maps, float* const* gmaps, const int32_t* map_hw,
                       const int32_t* items, const float* coefs, const float* masks, const float* refs,
-                      int n_items, int H, int T, int max_hw, float* partial, float* loss,
-                      void* stream);
+                      int n_items, int H, int T, int max_hw, float grad_scale, float* partial,
+                      float* loss, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void ca_energy_kernel(
     const float* const* __restrict__ maps, float* const* __restrict__ gmaps,
     const int32_t* __restrict__ map_hw, const int32_t* __restrict__ items,
     const float* __restrict__ coefs, const float* __restrict__ masks,
-    const float* __restrict__ refs, int H, int T, int max_hw, float* __restrict__ partial) {
+    const float* __restrict__ refs, int H, int T, int max_hw, float gscale,
+    float* __restrict__ partial) {
   __shared__ float s_v[E_MAXHW];   // A * M      (fg) / A*M (ref)
   __shared__ float s_w[E_MAXHW];   // A * (1-M)  (bg) / R*M (ref)
   __shared__ float s_red[4];
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void ca_energy_kernel(
       const float m = M[i];
       if (rf < k_fg) { fg_sum += vi; g -= c_fg / (float)k_fg * m; }
       if (rb < k_bg) { bg_sum += wi; g += c_bg / (float)k_bg * (1.f - m); }
-      if (G && g != 0.f) atomicAdd(&G[(long)i * T], g);
+      if (G && g != 0.f) atomicAdd(&G[(long)i * T], g * gscale);
     }
     fg_sum = block_sum_256(fg_sum, s_red);
     bg_sum = block_sum_256(bg_sum, s_red);
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void ca_energy_kernel(
         if (m != 0.f) {
           float df = s_v[i] * ia - s_w[i] * ir;
           float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-          float g = c_ref * m * (sg * ia - dot * ia * ia);
+          float g = gscale * c_ref * m * (sg * ia - dot * ia * ia);
           if (g != 0.f) atomicAdd(&G[(long)i * T], g);
         }
       }
@@ -115,12 +116,13 @@ __global__ __launch_bounds__(256) void energy_sum_kernel(const float* __restrict
 extern "C" int lgd_ca_energy_f32(const float* const* maps, float* const* gmaps,
                                  const int32_t* map_hw, const int32_t* items, const float* coefs,
                                  const float* masks, const float* refs, int n_items, int H, int T,
-                                 int max_hw, float* partial, float* loss, void* stream) {
+                                 int max_hw, float grad_scale, float* partial, float* loss,
+                                 void* stream) {
   if (n_items < 0 || H < 1 || max_hw > E_MAXHW) return LGD_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (n_items > 0)
     hipLaunchKernelGGL(ca_energy_kernel, dim3(H, n_items), dim3(256), 0, st, maps, gmaps, map_hw,
-                       items, coefs, masks, refs, H, T, max_hw, partial);
+                       items, coefs, masks, refs, H, T, max_hw, grad_scale, partial);
   hipLaunchKernelGGL(energy_sum_kernel, dim3(1), dim3(256), 0, st, partial, n_items * H, loss);
   return lgd_check_launch();
 }

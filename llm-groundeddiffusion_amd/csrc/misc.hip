@@ -125,6 +125,25 @@ __global__ __launch_bounds__(256) void scale_kernel(const half_t* a, half_t* y, 
   }
 }
 
+// GEGLU forward on a stored pre-activation (the grad-enabled guidance pass keeps h for backward;
+// the no-grad pass uses the fused GEMM epilogue instead).  h packed [16 value | 16 gate] blocks.
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const half_t* __restrict__ h,
+                                                         half_t* __restrict__ y, long rows, int n) {
+  const long nvec_row = n / 8;
+  const long total = rows * nvec_row;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    long r = i / nvec_row;
+    int j = (int)(i - r * nvec_row) * 8;
+    long base = r * 2L * n + (j / 16) * 32 + (j % 16);
+    half8_t v = *reinterpret_cast<const half8_t*>(h + base);
+    half8_t g = *reinterpret_cast<const half8_t*>(h + base + 16);
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)v[e] * gelu_f((float)g[e]));
+    *reinterpret_cast<half8_t*>(y + r * (long)n + j) = o;
+  }
+}
+
 // GEGLU backward.  h packed as [.. 16 value | 16 gate ..] blocks (the layout the GEMM epilogue
 // consumes); y[j] = v[j]*gelu(g[j]);  gv = gy*gelu(g), gg = gy*v*gelu'(g).
 __global__ __launch_bounds__(256) void geglu_bwd_kernel(const half_t* __restrict__ h,
@@ -284,6 +303,13 @@ extern "C" int lgd_scale_f16(const void* x, void* y, float alpha, int64_t n, voi
   hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), (const half_t*)x, (half_t*)y, alpha,
                      (long)(n / 8));
+  return lgd_check_launch();
+}
+
+extern "C" int lgd_geglu_fwd_f16(const void* h, void* y, int64_t rows, int n, void* stream) {
+  if (n % 16) return LGD_ERR_ARG;
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(ew_blocks(rows * (n / 8))), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), (const half_t*)h, (half_t*)y, (long)rows, n);
   return lgd_check_launch();
 }
 

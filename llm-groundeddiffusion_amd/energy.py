@@ -1,0 +1,129 @@
+"""Host side of the cross-attention energy (utils/guidance.py:91-286): turns the layout (boxes, token
+positions, hyper-parameters) into the item / coefficient / mask tables that the single-launch HIP
+kernel `lgd_ca_energy_f32` consumes.  Everything here is tiny integer/box bookkeeping and follows
+the reference's rounding rules exactly (utils/utils.py:57-70: Python round = banker's rounding).
+"""
+import math
+from collections.abc import Iterable
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+F32 = torch.float32
+
+
+def scale_proportion(obj_box, H, W):
+    """utils/utils.py:57-70 (non-legacy branch)."""
+    x_min, y_min = round(obj_box[0] * W), round(obj_box[1] * H)
+    box_w, box_h = round((obj_box[2] - obj_box[0]) * W), round((obj_box[3] - obj_box[1]) * H)
+    x_max, y_max = x_min + box_w, y_min + box_h
+    return max(x_min, 0), max(y_min, 0), min(x_max, W), min(y_max, H)
+
+
+def box_mask(obj_boxes, H, W) -> torch.Tensor:
+    """guidance.py:104-114: union of an object's boxes at map resolution."""
+    mask = torch.zeros(H, W)
+    if not isinstance(obj_boxes[0], Iterable):
+        obj_boxes = [obj_boxes]
+    for b in obj_boxes:
+        x0, y0, x1, y1 = scale_proportion(b, H, W)
+        mask[y0:y1, x0:x1] = 1
+    return mask
+
+
+class EnergyTables:
+    """Static description of one guidance problem (one layout): built once per run() call."""
+
+    def __init__(self, device, bboxes, object_positions, guidance_attn_keys: Sequence[Tuple],
+                 map_hw: Dict[Tuple, int], heads: int, text_len: int = 77, *, loss_scale=30.0,
+                 fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=1.0,
+                 ref_boxes: bool = False, ref_ca_loss_weight=1.0, ref_ca_word_token_only=False,
+                 ref_ca_last_token_only=True, word_token_indices=None):
+        self.device = device
+        self.keys = [tuple(k) for k in guidance_attn_keys]
+        self.heads, self.T = heads, text_len
+        self.n_obj = len(bboxes)
+        self.max_hw = max([map_hw[k] for k in self.keys] + [1])
+        n_keys = len(self.keys)
+        items, coefs, masks = [], [], []
+        self.ref_slots: List[Tuple[int, int, int]] = []     # (obj, box, key index) per ref_id
+        denom = max(self.n_obj * n_keys, 1)                 # guidance.py:270,284
+        for ki, key in enumerate(self.keys):
+            hw = map_hw[key]
+            Hs = int(math.sqrt(hw))
+            for o in range(self.n_obj):
+                m = box_mask(bboxes[o], Hs, Hs)
+                # guidance.py:136-137 — computed with the same fp32 tensor ops as the reference
+                k_fg = int((m.sum() * fg_top_p).long().clamp_(min=1))
+                k_bg = int(((1 - m).sum() * bg_top_p).long().clamp_(min=1))
+                mid = len(masks)
+                masks.append(torch.nn.functional.pad(m.reshape(-1), (0, self.max_hw - hw)))
+                toks = object_positions[o]
+                for p in toks:
+                    items.append([ki, 0, int(p), mid, k_fg, k_bg, 0, 0])
+                    coefs.append([loss_scale * fg_weight / (len(toks) * denom),
+                                  loss_scale * bg_weight / (len(toks) * denom), 0.0, 0.0])
+        if ref_boxes and ref_ca_loss_weight != 0.0:
+            for o in range(self.n_obj):
+                obj_boxes = bboxes[o]
+                if not isinstance(obj_boxes[0], Iterable):
+                    obj_boxes = [obj_boxes]
+                if ref_ca_word_token_only:                   # guidance.py:213-219
+                    toks = [word_token_indices[o]]
+                elif ref_ca_last_token_only:
+                    toks = [object_positions[o][-1]]
+                else:
+                    toks = object_positions[o]
+                for bi, box in enumerate(obj_boxes):
+                    for ki, key in enumerate(self.keys):
+                        hw = map_hw[key]
+                        Hs = int(math.sqrt(hw))
+                        m = box_mask(box, Hs, Hs)
+                        mid = len(masks)
+                        masks.append(torch.nn.functional.pad(m.reshape(-1), (0, self.max_hw - hw)))
+                        rid = len(self.ref_slots)
+                        self.ref_slots.append((o, bi, ki))
+                        for p in toks:
+                            items.append([ki, 1, int(p), mid, 1, 1, rid, 0])
+                            coefs.append([0.0, 0.0, loss_scale * ref_ca_loss_weight /
+                                          (heads * len(obj_boxes) * len(toks) * denom), 0.0])
+        self.n_items = len(items)
+        self.items = torch.tensor(items if items else [[0] * 8], dtype=torch.int32, device=device)
+        self.coefs = torch.tensor(coefs if coefs else [[0.0] * 4], dtype=F32, device=device)
+        self.masks = (torch.stack(masks) if masks else torch.zeros(1, self.max_hw)).to(device, F32).contiguous()
+        self.map_hw = torch.tensor([map_hw[k] for k in self.keys] or [1], dtype=torch.int32, device=device)
+        self.partial = torch.zeros(max(self.n_items * heads, 1), dtype=F32, device=device)
+        self.loss = torch.zeros(1, dtype=F32, device=device)
+        self.n_refs = len(self.ref_slots)
+        self.refs = None        # fp32 [T][n_refs][heads][max_hw], filled by set_refs
+        self._ptrs = None
+
+    def bind(self, maps: Dict[Tuple, torch.Tensor], gmaps: Optional[Dict[Tuple, torch.Tensor]]):
+        """Device pointer tables to the (static) map / map-gradient buffers of a guidance plan."""
+        mp = torch.tensor([maps[k].data_ptr() for k in self.keys] or [0], dtype=torch.int64, device=self.device)
+        gp = None
+        if gmaps is not None:
+            gp = torch.tensor([gmaps[k].data_ptr() for k in self.keys] or [0], dtype=torch.int64, device=self.device)
+        self._ptrs = (mp, gp, maps, gmaps)
+
+    def set_refs(self, refs: torch.Tensor):
+        """refs: fp32 [T][n_refs][heads][max_hw] — stage-A maps R_b of guidance.py:201 per step."""
+        assert refs.shape[1:] == (self.n_refs, self.heads, self.max_hw), refs.shape
+        self.refs = refs.to(self.device, F32).contiguous()
+
+    def run(self, index: int = 0, grad_scale: float = 1.0, with_grad: bool = True) -> torch.Tensor:
+        """Launches the energy (+ map gradients into the bound, pre-zeroed gmaps). Returns the device
+        scalar loss (already multiplied by loss_scale, pipelines.py:48)."""
+        mp, gp, maps, gmaps = self._ptrs
+        if with_grad and gmaps is not None:
+            for k in self.keys:
+                gmaps[k].zero_()
+        refs_ptr = None
+        if self.refs is not None:
+            refs_ptr = self.refs[index].data_ptr()
+        ops.ca_energy(mp, gp if with_grad else None, self.map_hw, self.items, self.coefs, self.masks,
+                      None, self.n_items, self.heads, self.T, self.max_hw, self.partial, self.loss,
+                      grad_scale=grad_scale, refs_ptr=refs_ptr or 0)
+        return self.loss

@@ -261,6 +261,14 @@ def geglu_bwd(h, gy, gh=None):
     return gh
 
 
+def geglu_fwd(h, out=None):
+    rows, n2 = h.shape
+    if out is None:
+        out = torch.empty((rows, n2 // 2), device=h.device, dtype=F16)
+    _call("lgd_geglu_fwd_f16", _p(h), _p(out), rows, n2 // 2, _stream())
+    return out
+
+
 def add(a, b, out=None):
     if out is None:
         out = torch.empty_like(a)
@@ -299,6 +307,7 @@ def select_row(table, idx, out):
 
 
 def ca_energy(map_ptrs, gmap_ptrs, map_hw, items, coefs, masks, refs, n_items, H, T, max_hw,
-              partial, loss):
+              partial, loss, grad_scale=1.0, refs_ptr=None):
+    rp = C.c_void_p(refs_ptr) if refs_ptr is not None else _p(refs)
     _call("lgd_ca_energy_f32", _p(map_ptrs), _p(gmap_ptrs), _p(map_hw), _p(items), _p(coefs),
-          _p(masks), _p(refs), n_items, H, T, max_hw, _p(partial), _p(loss), _stream())
+          _p(masks), rp, n_items, H, T, max_hw, float(grad_scale), _p(partial), _p(loss), _stream())

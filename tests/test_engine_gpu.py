@@ -1,0 +1,189 @@
+"""HIP engine vs the golden fixtures produced by the REFERENCE'S OWN code (tests/golden) and vs the
+CPU oracle restatement (oracle/restate.py): UNet forward with cross-attention map capture, GLIGEN
+fuser, the energy kernel, one backward-guidance call, and the sampler loops.
+
+Tolerances: the HIP path computes in fp16 (fp32 accumulate) against an fp32 oracle; errors are
+reported relative to the tensor's max magnitude."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import lgd_amd  # noqa: E402,F401
+from lgd_amd import weights  # noqa: E402
+from lgd_amd.unet import UNetEngine  # noqa: E402
+from lgd_amd.sampler import LMDSampler, prepare_gligen_condition  # noqa: E402
+from lgd_amd.energy import EnergyTables  # noqa: E402
+from lgd_amd.scheduler import DDIMScheduler  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+KEYS = [("mid", 0, 0, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 1, 2, 0)]
+OBJ_KEY = ("down", 2, 1, 0)
+BBOXES = [[74 / 512, 177 / 512, (74 + 183) / 512, (177 + 235) / 512],
+          [314 / 512, 193 / 512, (314 + 189) / 512, (193 + 216) / 512]]
+OBJ_POS = [[1, 2, 3], [5, 6, 7]]
+WORD_TOK = [3, 7]
+L = 32
+
+
+def ks(k):
+    return "_".join(str(x) for x in k)
+
+
+def relerr(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-20))
+
+
+def cosine(a, b):
+    a, b = torch.as_tensor(a).double().cpu().reshape(-1), torch.as_tensor(b).double().cpu().reshape(-1)
+    return float(a @ b / (a.norm() * b.norm()).clamp_min(1e-30))
+
+
+_ENG = {}
+
+
+def engine(name, dev):
+    if name not in _ENG:
+        cfg = weights.CONFIGS[name]
+        _ENG[name] = UNetEngine(cfg, dev, weights.synth_state_dict(cfg, 0))
+    return _ENG[name]
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_gligen"])
+def test_unet_forward_and_maps_vs_reference_golden(dev, name):
+    g = np.load(os.path.join(GOLD, f"unet_fwd_{name}.npz"))
+    eng = engine(name, dev)
+    gl = "gl_boxes" in g
+    plan = eng.plan(2, L, fuser=gl, save_keys=[OBJ_KEY, *KEYS])
+    eng.prepare_timesteps([int(g["t"])])
+    eng.set_step(0)
+    eng.prepare_text(torch.from_numpy(g["ehs"]))
+    if gl:
+        eng.prepare_gligen(boxes=torch.from_numpy(g["gl_boxes"]), masks=torch.from_numpy(g["gl_masks"]),
+                           positive_embeddings=torch.from_numpy(g["gl_emb"]))
+    eps = plan.forward(torch.from_numpy(g["x"]).to(dev))
+    torch.cuda.synchronize()
+    e = relerr(eps, g["eps"])
+    print(f"[{name}] eps relerr {e:.3e}")
+    assert e < 2e-2
+    for k in [OBJ_KEY, *KEYS]:
+        em = relerr(plan.maps[k], g["map_" + ks(k)])
+        print(f"[{name}] map {k} relerr {em:.3e}")
+        assert em < 2e-2
+
+
+def test_energy_kernel_vs_reference_golden(dev):
+    g = np.load(os.path.join(GOLD, "energy.npz"))
+    maps = {k: torch.from_numpy(g["map_" + ks(k)])[0].to(dev).contiguous() for k in KEYS}
+    hw = {k: maps[k].shape[1] for k in KEYS}
+    for tag in ("noref", "ref"):
+        gmaps = {k: torch.zeros_like(v) for k, v in maps.items()}
+        kw = dict(loss_scale=1.0, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+        if tag == "ref":
+            kw.update(ref_boxes=True, ref_ca_loss_weight=2.0, ref_ca_word_token_only=True,
+                      ref_ca_last_token_only=True, word_token_indices=WORD_TOK)
+        en = EnergyTables(dev, BBOXES, OBJ_POS, KEYS, hw, 8, 77, **kw)
+        if tag == "ref":
+            refs = torch.zeros(2, en.n_refs, 8, en.max_hw)
+            for rid, (o, bi, ki) in enumerate(en.ref_slots):
+                r = torch.from_numpy(g[f"ref_{o}_{ks(KEYS[ki])}"])[0, :, :, 0]
+                refs[1, rid, :, :r.shape[1]] = r
+            en.set_refs(refs)
+        en.bind(maps, gmaps)
+        loss = en.run(index=1, grad_scale=1.0)
+        torch.cuda.synchronize()
+        assert relerr(loss, g[f"loss_{tag}"]) < 1e-5
+        for k in KEYS:
+            assert relerr(gmaps[k], g[f"grad_{tag}_{ks(k)}"][0]) < 1e-4, (tag, k)
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_gligen"])
+def test_backward_guidance_vs_reference_golden(dev, name):
+    """One latent_backward_guidance call, loss_threshold=0 (iteration count pinned to max_iter=3)."""
+    g = np.load(os.path.join(GOLD, f"guidance_{name}.npz"))
+    eng = engine(name, dev)
+    sm = LMDSampler(eng, DDIMScheduler())
+    sm.scheduler.set_timesteps(10)
+    gl = name == "tiny_gligen"
+    plan_g = eng.plan(1, L, grad=True, fuser=gl, stop_key=KEYS[-1], save_keys=KEYS, text_batch_offset=1)
+    eng.prepare_timesteps([int(t) for t in sm.scheduler.timesteps])
+    eng.set_step(1)
+    cond = torch.from_numpy(g["cond"])
+    eng.prepare_text(torch.cat([torch.zeros_like(cond), cond]))
+    if gl:
+        f = np.load(os.path.join(GOLD, f"unet_fwd_{name}.npz"))
+        eng.prepare_gligen(boxes=torch.from_numpy(f["gl_boxes"]), masks=torch.from_numpy(f["gl_masks"]),
+                           positive_embeddings=torch.from_numpy(f["gl_emb"]))
+    gs = sm.make_guidance(L, BBOXES, OBJ_POS, loss_scale=5, loss_threshold=0.0, max_iter=3, max_index_step=10,
+                          guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+    lat = torch.from_numpy(g["latents_in"]).to(dev).clone()
+    tr = []
+    sm.backward_guidance(gs, plan_g, 1, lat, sm.scheduler.guidance_step_table(dev), trace=tr)
+    torch.cuda.synchronize()
+    assert gs.iterations == 3
+    a_t = float(sm.scheduler.alphas_cumprod[int(g["t"])])
+    print(f"[{name}] losses hip {[round(t['loss'], 4) for t in tr]} ref {g['losses'].tolist()}")
+    c0 = cosine(tr[0]["grad"], g["grad0"])
+    r0 = rel_l2(tr[0]["grad"], g["grad0"])
+    print(f"[{name}] first-iteration latent gradient: cosine {c0:.5f} rel-L2 {r0:.3e}")
+    assert abs(tr[0]["loss"] - float(g["losses"][0])) / float(g["losses"][0]) < 2e-2
+    assert c0 > 0.98 and r0 < 0.2
+    d_hip = lat.cpu() - torch.from_numpy(g["latents_in"])
+    d_ref = torch.from_numpy(g["latents_out"]) - torch.from_numpy(g["latents_in"])
+    c = cosine(d_hip, d_ref)
+    print(f"[{name}] total latent update: cosine {c:.5f} rel-L2 {rel_l2(d_hip, d_ref):.3e}")
+    assert c > 0.95
+
+
+def test_partial_frozen_and_semantic_guidance_loops(dev):
+    g = np.load(os.path.join(GOLD, "loops_tiny.npz"))
+    eng = engine("tiny", dev)
+    sm = LMDSampler(eng, DDIMScheduler())
+    ehs = torch.from_numpy(g["ehs"])
+    guid = dict(bboxes=BBOXES, object_positions=OBJ_POS, loss_scale=5, loss_threshold=0.0, max_iter=[2, 1],
+                max_index_step=2, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0,
+                bg_weight=4.0)
+    out = sm.denoise(torch.from_numpy(g["lat_all_in"]), ehs, 4, guidance=guid, frozen_steps=2,
+                     frozen_mask=torch.from_numpy(g["frozen_mask"]))
+    torch.cuda.synchronize()
+    e = relerr(out["latents"], g["partial_frozen_out"])
+    print(f"partial_frozen final latents relerr {e:.3e} (guidance iters {out['guidance_iters']})")
+    assert out["guidance_iters"] == 3 and e < 5e-2
+    out = sm.denoise(torch.from_numpy(g["lat0"]), ehs, 4, guidance=guid,
+                     saved_cross_attn_keys=[OBJ_KEY, *KEYS], return_cond_ca_only=True, return_token_ca_only=3)
+    torch.cuda.synchronize()
+    e = relerr(out["latents_all"], g["sg_latents_all"])
+    em = relerr(out["saved"][("up", 1, 1, 0)][0], g["sg_saved_up11_step0"])
+    print(f"semantic_guidance latents_all relerr {e:.3e}, saved map relerr {em:.3e}")
+    assert e < 5e-2 and em < 5e-2
+
+
+def test_gligen_loop(dev):
+    g = np.load(os.path.join(GOLD, "loops_tiny_gligen.npz"))
+    eng = engine("tiny_gligen", dev)
+    sm = LMDSampler(eng, DDIMScheduler())
+    ehs = torch.from_numpy(g["ehs"])
+    guid = dict(bboxes=BBOXES, object_positions=OBJ_POS, loss_scale=5, loss_threshold=0.0, max_iter=[2, 1],
+                max_index_step=3, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0,
+                bg_weight=4.0)
+    gl = prepare_gligen_condition(BBOXES, torch.from_numpy(g["phrase_emb"]), dev)
+    out = sm.denoise(torch.from_numpy(g["lat_all_in"]), ehs, 4, gligen=gl, gligen_scheduled_sampling_beta=0.5,
+                     guidance=guid, frozen_steps=2, frozen_mask=torch.from_numpy(g["frozen_mask"]),
+                     saved_cross_attn_keys=[OBJ_KEY, *KEYS], return_cond_ca_only=True, return_token_ca_only=7)
+    torch.cuda.synchronize()
+    e = relerr(out["latents_all"], g["gligen_latents_all"])
+    em = relerr(out["saved"][("up", 1, 1, 0)][1], g["gligen_saved_up11_step1"])
+    print(f"gligen latents_all relerr {e:.3e}, saved map relerr {em:.3e}, iters {out['guidance_iters']}")
+    assert out["guidance_iters"] == 4 and e < 5e-2 and em < 5e-2
