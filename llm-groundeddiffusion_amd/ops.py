@@ -110,7 +110,7 @@ def conv3x3(x, w, B, H, W, *, x1=None, bias=None, bias2=None, res=None, stride=1
         ws = torch.empty((splits, M, Cout), device=x.device, dtype=F32)
     d = gemm_desc(x, w, out, M, Cout, K, a1=x1, c0=c0, c1=c1, lda0=x.stride(0),
                   lda1=(x1.stride(0) if x1 is not None else 0), taps=9, hin=H, win=W, hout=Ho,
-                  wout=Wo, stride=stride, ups=1 if ups else 0, bias=bias, bias2=bias2, res=res,
+                  wout=Wo, stride=stride, ups=int(ups), bias=bias, bias2=bias2, res=res,
                   ldr=(res.stride(0) if res is not None else 0), splits=splits, ws=ws, tile=tile,
                   alpha=alpha, ldc=out.stride(0))
     gemm_launch(d)

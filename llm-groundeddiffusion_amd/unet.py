@@ -74,6 +74,8 @@ class Plan:
         self.text_off = text_batch_offset
         self.save_cond_only = save_cond_only
         self.ops: List[Op] = []
+        self._buffers: List[torch.Tensor] = []
+        self.dbg: Dict[str, Act] = {}                 # named activations (debugging / tests)
         self.maps: Dict[Tuple, torch.Tensor] = {}     # key -> fp32 [Bp,H,HW,Tp] (default save target)
         self.gmaps: Dict[Tuple, torch.Tensor] = {}    # key -> fp32 gradient of the map
         self.map_sink: Dict[Tuple, List] = {}         # key -> [tensor, tok] (mutable save target)
@@ -84,7 +86,15 @@ class Plan:
 
     # --------------------------------------------------------------------------------------
     def _new(self, rows, C, dtype=F16):
-        return torch.empty((rows, C), device=self.eng.device, dtype=dtype)
+        # kernels see raw pointers only, so the plan itself must own every buffer it launches on
+        t = torch.empty((rows, C), device=self.eng.device, dtype=dtype)
+        self._buffers.append(t)
+        return t
+
+    def _alloc(self, shape, dtype=F32):
+        t = torch.empty(shape, device=self.eng.device, dtype=dtype)
+        self._buffers.append(t)
+        return t
 
     def _act(self, rows, C):
         return Act(self._new(rows, C))
@@ -235,8 +245,8 @@ class Plan:
         C = x.C + (x1.C if x1 else 0)
         y = self._act(x.rows, C)
         nch = ops.gn_chunks(B, HW)
-        part = torch.empty((B, nch, G, 2), device=eng.device, dtype=F32)
-        stats = torch.empty((B, G, 2), device=eng.device, dtype=F32) if self.grad else None
+        part = self._alloc((B, nch, G, 2))
+        stats = self._alloc((B, G, 2)) if self.grad else None
         xt1 = x1.t if x1 else None
         fwd = lambda: ops.groupnorm(x.t, B, HW, G, eps, gm, bt, silu, x1=xt1, out=y.t, part=part, stats=stats)
         if not self.grad:
@@ -260,7 +270,7 @@ class Plan:
         gm, bt = eng.w.f[f"{name}.g"], eng.w.f[f"{name}.b"]
         C = x.C
         y = Act(out_t) if out_t is not None else self._act(x.rows, C)
-        stats = torch.empty((x.rows, 2), device=eng.device, dtype=F32) if self.grad else None
+        stats = self._alloc((x.rows, 2)) if self.grad else None
         rpb = S or 0
         x_bs = (S or 0) * C
         fwd = lambda: ops.layernorm(x.t, gm, bt, out=y.t, ldy=ldy or C, stats=stats, rows=x.rows,
@@ -286,7 +296,7 @@ class Plan:
         d = C // heads
         o = self._act(B * S, C)
         view = (3 * C, Sk * 3 * C)
-        lse = torch.empty((B, heads, S), device=self.eng.device, dtype=F32) if self.grad else None
+        lse = self._alloc((B, heads, S)) if self.grad else None
         scale = d ** -0.5
         qt, kt, vt = qkv.t, qkv.t[:, C:], qkv.t[:, 2 * C:]
         fwd = lambda: ops.attn_fwd(qt, kt, vt, o.t, B, heads, S, Sk, d, scale, lse=lse,
@@ -297,7 +307,7 @@ class Plan:
 
         def make_bwd(acc):
             assert not acc[0]
-            delta = torch.empty((B, heads, S), device=self.eng.device, dtype=F32)
+            delta = self._alloc((B, heads, S))
             g = qkv.g
             gq, gk, gv = g, g[:, C:], g[:, 2 * C:]
             pad = Sk > S
@@ -372,7 +382,9 @@ class Plan:
         else:
             assert skip is None
             sc = x
-        return self.conv(h, f"{r.prefix}.conv2", H, res=sc)
+        out = self.conv(h, f"{r.prefix}.conv2", H, res=sc)
+        self.dbg[f"{r.prefix}.out"] = out
+        return out
 
     def _transformer(self, a, x: Act, H: int) -> Optional[Act]:
         eng, B = self.eng, self.B
@@ -384,6 +396,7 @@ class Plan:
         # 1. self-attention (attention.py:185-195)
         qkv = self.linear(self.layernorm(h, f"{t}.norm1"), f"{t}.attn1.qkv", bias=False)
         h = self.linear(self.self_attn(qkv, heads, S), f"{t}.attn1.to_out.0", res=h)
+        self.dbg[f"{a.prefix}.after_attn1"] = h
         # 1.5 GLIGEN gated self-attention (attention.py:43-53, 198-200)
         if self.fuser:
             f = f"{t}.fuser"
@@ -395,7 +408,9 @@ class Plan:
             qkv_f = self.linear(cat_act, f"{f}.attn.qkv", bias=False)
             o = self.self_attn(qkv_f, heads, S, Sk)
             h = self.linear(o, f"{f}.attn.to_out.0", res=h, alpha=eng.w.scalars[f"{f}.alpha_attn"])
+            self.dbg[f"{a.prefix}.after_fuser_attn"] = h
             h = self.ff(self.layernorm(h, f"{f}.norm2"), h, f"{f}.ff", alpha=eng.w.scalars[f"{f}.alpha_dense"])
+            self.dbg[f"{a.prefix}.after_fuser"] = h
         # 2. cross-attention (attention.py:204-220) — the hook of attention_processor.py:377-483
         q = self.linear(self.layernorm(h, f"{t}.norm2"), f"{t}.attn2.to_q", bias=False)
         last = self.stop_key is not None and a.key == self.stop_key
@@ -403,9 +418,12 @@ class Plan:
         if last:
             return None
         h = self.linear(o, f"{t}.attn2.to_out.0", res=h)
+        self.dbg[f"{a.prefix}.after_attn2"] = h
         # 3. feed-forward (attention.py:223-233)
         h = self.ff(self.layernorm(h, f"{t}.norm3"), h, f"{t}.ff")
-        return self.linear(h, f"{a.prefix}.proj_out", res=x)                     # transformer_2d.py:319-327
+        out = self.linear(h, f"{a.prefix}.proj_out", res=x)                      # transformer_2d.py:319-327
+        self.dbg[f"{a.prefix}.out"] = out
+        return out
 
     def _build(self):
         eng, B, L = self.eng, self.B, self.L
@@ -416,7 +434,8 @@ class Plan:
         x = self._act(B * L * L, c0)
         lat = self.latents_in
         self._x0 = x
-        self._add(lambda: ops.conv_in(lat, w.h["conv_in.w"], w.f["conv_in.b"], out=x.t))
+        x0 = x
+        self._add(lambda: ops.conv_in(lat, w.h["conv_in.w"], w.f["conv_in.b"], out=x0.t))
         skips = [(x, L)]
         H = L
         done = False

@@ -41,7 +41,12 @@ def resnet(sd, p, x, temb, groups, eps):
     h = F.conv2d(h, sd[f"{p}.conv2.weight"], sd[f"{p}.conv2.bias"], padding=1)
     if f"{p}.conv_shortcut.weight" in sd:
         x = F.conv2d(x, sd[f"{p}.conv_shortcut.weight"], sd[f"{p}.conv_shortcut.bias"])
+    if _TAPS is not None:
+        _TAPS[f"{p}.out"] = (x + h).detach()
     return x + h
+
+
+_TAPS = None  # optional dict collecting named intermediate activations (debugging only)
 
 
 def attention(sd, p, x, ctx, heads, hook=None):
@@ -77,6 +82,8 @@ def fuser(sd, p, x, objs, heads):
     objs = F.linear(objs, sd[f"{p}.linear.weight"], sd[f"{p}.linear.bias"])
     h = layer_norm(sd, f"{p}.norm1", torch.cat([x, objs], dim=1))
     x = x + sd[f"{p}.alpha_attn"].tanh() * attention(sd, f"{p}.attn", h, None, heads)[:, :n_visual]
+    if _TAPS is not None:
+        _TAPS[p.replace(".transformer_blocks.0.fuser", "") + ".after_fuser_attn"] = x.detach()
     x = x + sd[f"{p}.alpha_dense"].tanh() * feed_forward(sd, f"{p}.ff", layer_norm(sd, f"{p}.norm2", x))
     return x
 
@@ -98,8 +105,12 @@ def transformer(sd, p, x, ctx, heads, groups, key, st):
         h = F.linear(h.permute(0, 2, 3, 1).reshape(B, H * W, C), w_in, sd[f"{p}.proj_in.bias"])
     t = f"{p}.transformer_blocks.0"
     h = attention(sd, f"{t}.attn1", layer_norm(sd, f"{t}.norm1", h), None, heads) + h
+    if _TAPS is not None:
+        _TAPS[f"{p}.after_attn1"] = h.detach()
     if st["objs"] is not None and st["fuser_enabled"]:
         h = fuser(sd, f"{t}.fuser", h, st["objs"], heads)          # attention.py:198-200
+        if _TAPS is not None:
+            _TAPS[f"{p}.after_fuser"] = h.detach()
     hook = None
     if st["saved"] is not None and (st["save_keys"] is None or key in st["save_keys"]):
         def hook(probs, key=key):                                   # attention_processor.py:463-480
@@ -110,6 +121,8 @@ def transformer(sd, p, x, ctx, heads, groups, key, st):
                 probs = probs[probs.shape[0] // 2:]
             st["saved"][key] = probs
     h = attention(sd, f"{t}.attn2", layer_norm(sd, f"{t}.norm2", h), ctx, heads, hook) + h
+    if _TAPS is not None:
+        _TAPS[f"{p}.after_attn2"] = h.detach()
     if st["stop_after"] is not None and key == st["stop_after"]:
         raise _Stop()
     h = feed_forward(sd, f"{t}.ff", layer_norm(sd, f"{t}.norm3", h)) + h
@@ -118,6 +131,8 @@ def transformer(sd, p, x, ctx, heads, groups, key, st):
         h = F.conv2d(h.reshape(B, H, W, C).permute(0, 3, 1, 2), w_out, sd[f"{p}.proj_out.bias"])
     else:
         h = F.linear(h, w_out, sd[f"{p}.proj_out.bias"]).reshape(B, H, W, C).permute(0, 3, 1, 2)
+    if _TAPS is not None:
+        _TAPS[f"{p}.out"] = (h + res).detach()
     return h + res
 
 
@@ -136,7 +151,7 @@ def position_net(sd, boxes, masks, positive_embeddings):
 
 
 def unet_forward(sd, cfg, sample, t, ehs, *, saved=None, save_keys=None, token_only=None,
-                 cond_only=False, gligen=None, fuser_enabled=True, stop_after=None):
+                 cond_only=False, gligen=None, fuser_enabled=True, stop_after=None, taps=None):
     """UNet2DConditionModel.forward (unet_2d_condition.py:704-980) for the SD 1.x/2.x configs.
 
     cfg: dict-like with block_out_channels, layers_per_block, attention_head_dim, norm_num_groups,
@@ -144,6 +159,8 @@ def unet_forward(sd, cfg, sample, t, ehs, *, saved=None, save_keys=None, token_o
     stop_after: attn key after whose cross-attention the forward is abandoned (returns None) — the
     algorithmic minimum for the guidance pass (TODO at pipelines.py:46); loss/grad are identical.
     """
+    global _TAPS
+    _TAPS = taps
     boc = list(cfg["block_out_channels"])
     heads_l = list(cfg["attention_head_dim"])
     groups, eps, lpb = cfg["norm_num_groups"], cfg["norm_eps"], cfg["layers_per_block"]
