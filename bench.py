@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the LMD+ stage-2 hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of cached layouts on every rank: `--layouts`
+(default 4, BASELINE config[1] "batch=4 cached layouts") two-box layouts of the lmd_v0.1 cache, each
+taken through the full LMD+ stage 2 (per-box GLIGEN generations, composition, overall generation with
+cross-attention guidance, 50 DDIM steps each, VAE decodes; SAM replaced by box masks, text encoder
+outputs synthetic = "cached layouts").  Weights: seeded random SD1.4+GLIGEN architecture
+(no checkpoints in the sandbox).  Ranks shard layouts (weak scaling, one process per GPU); rank 0
+builds the weights and RCCL-broadcasts the two weight arenas; no collective inside the step loop.
+
+Prints ONE JSON line (rank 0) with the contract's fields plus `roofline` (dominant kernel, live HIP
+event timing of sampled launches inside the timed region) and, at N=1, `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_F16 = 2.5e15       # dense fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12
+
+
+def load_layouts(n_boxes=2):
+    rows = json.load(open(os.path.join(ROOT, "tests", "golden", "layouts_lmd_v0.1_gpt-4.json")))
+    return [r for r in rows if len(r["gen_boxes"]) == n_boxes]
+
+
+def algorithmic_tflop_per_image(cfg_name, n_boxes, iters_on, iters_off):
+    """SURVEY.md §8d per-unit figure (analytic, 2*MAC): LMD+ image = (N+1)(20*fwd_on + 30*fwd_off) +
+    guidance iterations (fwd to up.1.2 + dgrad back to the latents)."""
+    if cfg_name != "sd14_gligen":
+        return None
+    return (n_boxes + 1) * (20 * 2.2736 + 30 * 1.6065) + iters_on * (0.5872 + 0.6885) + iters_off * (0.4086 + 0.4585)
+
+
+def cpu_baseline(cfg, n_boxes, iters_on, iters_off, max_seconds=40.0):
+    """The CPU oracle (oracle/restate.py: fp32 restatement of the reference path, pinned against the
+    reference's own code) timed on this box's host cores on a bounded sample: one CFG UNet call with
+    the GLIGEN fuser on, one with it off, one guidance iteration (fwd+bwd); extrapolated to a full
+    LMD+ image with the iteration counts the GPU run took."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import restate as R
+    from lgd_amd import weights
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = weights.synth_state_dict(cfg, 0)
+    cd = dict(block_out_channels=cfg.block_out_channels, layers_per_block=cfg.layers_per_block,
+              attention_head_dim=cfg.attention_head_dim, norm_num_groups=cfg.norm_num_groups,
+              norm_eps=cfg.norm_eps, gligen_positive_len=cfg.gligen_positive_len)
+    L = 64
+    x = torch.randn(2, 4, L, L)
+    unc, cond = weights.synth_embeddings(cfg, 1)
+    ehs = torch.cat([unc, cond])
+    boxes = [[0.15, 0.35, 0.5, 0.8], [0.6, 0.38, 0.98, 0.8]]
+    b, e, m, _ = R.prepare_gligen_condition([boxes], [torch.randn(2, 768)])
+    gl = dict(boxes=b, positive_embeddings=e, masks=m)
+    t0 = time.time()
+    with torch.no_grad():
+        R.unet_forward(sd, cd, x, 500, ehs, gligen=gl, fuser_enabled=True)
+        t_on = time.time() - t0
+        t0 = time.time()
+        R.unet_forward(sd, cd, x, 500, ehs, gligen=gl, fuser_enabled=False)
+        t_off = time.time() - t0
+    sched = R.DDIM()
+    sched.set_timesteps(50)
+    t0 = time.time()
+    R.latent_backward_guidance(sd, cd, sched, cond, 0, boxes, [[1, 2, 3], [5, 6, 7]], sched.timesteps[0], x[:1],
+                               torch.tensor(1e4), loss_scale=5, loss_threshold=0.0, max_iter=1, max_index_step=30,
+                               guidance_attn_keys=R.DEFAULT_GUIDANCE_ATTN_KEYS, fg_top_p=0.2, bg_top_p=0.2,
+                               fg_weight=1.0, bg_weight=4.0,
+                               gligen=dict(boxes=b[:1], positive_embeddings=e[:1], masks=m[:1]))
+    t_g = time.time() - t0
+    per_image = (n_boxes + 1) * (20 * t_on + 30 * t_off) + (iters_on + iters_off) * t_g
+    return dict(value=1.0 / per_image, unit="images/s", cores=cores, kind="port",
+                sample=(f"oracle/restate.py fp32 on {cores} host threads: 1 CFG UNet call fuser-on {t_on:.2f}s, "
+                        f"1 fuser-off {t_off:.2f}s, 1 guidance iteration (fwd+bwd, early exit) {t_g:.2f}s; "
+                        f"extrapolated to one {n_boxes}-box LMD+ image = (N+1)(20 on + 30 off) UNet calls + "
+                        f"{iters_on + iters_off} guidance iterations (VAE excluded)"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--layouts", type=int, default=4, help="cached layouts per rank per step")
+    ap.add_argument("--config", default="sd14_gligen")
+    ap.add_argument("--num-inference-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import lgd_amd  # noqa: F401
+    from lgd_amd import dist as ldist, ops, weights
+    from lgd_amd.pipeline import CachedLayout, lmd_plus_generate
+    from lgd_amd.sampler import LMDSampler
+    from lgd_amd.scheduler import DDIMScheduler
+    from lgd_amd.unet import UNetEngine
+    from lgd_amd.vae import make_vae
+
+    if world > 1:
+        ldist.init(backend="nccl")
+    cfg = weights.CONFIGS[args.config]
+    # rank 0 materialises the weights; everyone else receives the two arenas over RCCL/xGMI
+    eng = UNetEngine(cfg, dev, weights.synth_state_dict(cfg, 0) if rank == 0 else None)
+    bcast_s = ldist.broadcast_weights(eng.w, src=0) if world > 1 else 0.0
+    vae = None if args.no_decode else make_vae(dev)
+    sm = LMDSampler(eng, DDIMScheduler(prediction_type=cfg.prediction_type), vae=vae)
+
+    pool = load_layouts(2)
+    mine = [pool[(rank * args.layouts + i) % len(pool)] for i in range(args.layouts)]
+    lays = [CachedLayout.synthetic(cfg, [(n, b) for n, b in r["gen_boxes"]], index=rank * args.layouts + i)
+            for i, r in enumerate(mine)]
+    T = args.num_inference_steps
+
+    def one_step():
+        it = 0
+        for lay in lays:
+            out = lmd_plus_generate(sm, lay, num_inference_steps=T, decode=not args.no_decode)
+            it += out["guidance_iters"]
+        return it
+
+    for _ in range(args.warmup):
+        one_step()
+    prof = ops.LaunchProfiler()
+    ldist.barrier()
+    torch.cuda.synchronize()
+    ops.PROFILER = prof
+    t0 = time.perf_counter()
+    iters = 0
+    for _ in range(args.steps):
+        iters += one_step()
+    torch.cuda.synchronize()
+    ldist.barrier()
+    dt = time.perf_counter() - t0
+    ops.PROFILER = None
+    dt = ldist.max_over_ranks(dt)
+    n_images = args.steps * args.layouts * world
+    if rank != 0:
+        return
+    agg = prof.summary()
+    dom = max(agg.items(), key=lambda kv: kv[1]["ms"]) if agg else None
+    roofline = None
+    if dom is not None:
+        name, a = dom
+        ach = a["flops"] / (a["ms"] * 1e-3)
+        roofline = dict(bound="mfma", kernel=name, achieved=round(ach / 1e12, 2), peak=MFMA_PEAK_F16 / 1e12,
+                        unit="TFLOP/s", frac=round(ach / MFMA_PEAK_F16, 4), traffic=None,
+                        launches=a["n"], avg_launch_us=round(a["ms"] * 1e3 / a["n"], 2),
+                        sampled_ms=round(a["ms"], 1),
+                        all_kernels={k: dict(ms=round(v["ms"], 1), n=v["n"],
+                                             tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1))
+                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])})
+    it_per_image = iters / max(args.steps * args.layouts, 1)
+    res = dict(metric="images/sec (50-step SD1.5 512^2, LMD+ guidance)", value=round(n_images / dt, 4),
+               unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=round(dt * 1e3 / args.steps, 1), higher_is_better=True, scaling="weak",
+               vs_baseline=None, dtype="fp16", data="synthetic",
+               config=dict(workload=f"LMD+ stage 2, {args.layouts} cached 2-box layouts/GPU/step (lmd_v0.1 cache), "
+                                    f"{T} DDIM steps, 512x512, {args.config} (SD1.4+GLIGEN architecture, seeded random "
+                                    f"weights), VAE decodes {'excluded' if args.no_decode else 'included'}",
+                           layouts_per_gpu=args.layouts, num_inference_steps=T, parallelism=f"dp{world}",
+                           guidance_iters_per_image=round(it_per_image, 1),
+                           algorithmic_tflop_per_image=algorithmic_tflop_per_image(args.config, 2, it_per_image, 0),
+                           weight_broadcast_s=round(bcast_s, 3)),
+               roofline=roofline)
+    tf = res["config"]["algorithmic_tflop_per_image"]
+    if tf:
+        res["config"]["whole_path_frac_of_mfma_peak"] = round(tf * 1e12 * (n_images / dt) / world / MFMA_PEAK_F16, 4)
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            res["cpu_baseline"] = cpu_baseline(cfg, 2, it_per_image, 0)
+        except Exception as e:  # the baseline is reported, never gating
+            res["cpu_baseline"] = dict(value=None, unit="images/s", cores=os.cpu_count(), kind="port",
+                                       sample=f"failed: {e}")
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

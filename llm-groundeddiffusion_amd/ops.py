@@ -60,11 +60,69 @@ def gemm_desc(a0, w, c, M, N, K, *, a1=None, lda0=None, lda1=0, c0=None, c1=0, t
     d.c = ptr(c)
     n_out = N // 2 if (epi & EPI_GEGLU) else N
     d.ldc = n_out if ldc is None else ldc
-    d.splits, d.ws, d.tile = splits, ptr(ws), tile
+    d.splits, d.ws = splits, ptr(ws)
+    d.tile = tile if tile else choose_tile(M, N, nb_o * nb_i * max(splits, 1))
     return d
 
 
+TILE_NAMES = {1: "gemm_kernel<4,4> 128x128", 2: "gemm_kernel<4,2> 128x64", 3: "gemm_kernel<2,4> 64x128",
+              4: "gemm_kernel<2,2> 64x64", 5: "gemm_kernel<1,4> 32x128"}
+
+
+def choose_tile(M, N, batches=1):
+    """Tile heuristic (same rule as the library's auto mode, done here so the choice is known to the
+    profiler): the largest tile that still yields enough workgroups for 256 CUs."""
+    wgs = lambda bm, bn: batches * ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+    if M <= 32:
+        return 5
+    if wgs(128, 128) >= 384 and N % 128 == 0:
+        return 1
+    if wgs(128, 64) >= 256:
+        return 2
+    return 4
+
+
+class LaunchProfiler:
+    """Samples kernel durations with HIP events on the launch stream (torch.cuda.Event records on
+    torch's current stream, which is the stream every lgd_* call is enqueued on)."""
+
+    def __init__(self, max_records=20000):
+        self.recs = []
+        self.max = max_records
+        self.enabled = True
+
+    def wrap(self, name, flops, nbytes, fn):
+        if not self.enabled or len(self.recs) >= self.max:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.recs.append((name, flops, nbytes, e0, e1))
+        return r
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, fl, nb, e0, e1 in self.recs:
+            a = agg.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += fl
+            a["bytes"] += nb
+            a["n"] += 1
+        return agg
+
+
+PROFILER = None
+
+
 def gemm_launch(desc):
+    if PROFILER is not None:
+        nb = desc.nb_o * desc.nb_i
+        flops = 2.0 * desc.M * desc.N * desc.K * nb
+        nbytes = 2.0 * nb * (desc.M * desc.K / max(desc.taps, 1) + desc.N * desc.K + desc.M * desc.N)
+        return PROFILER.wrap(TILE_NAMES.get(desc.tile, "gemm"), flops, nbytes,
+                             lambda: _call("lgd_gemm_f16", C.byref(desc), _stream()))
     _call("lgd_gemm_f16", C.byref(desc), _stream())
 
 
@@ -208,8 +266,12 @@ def attn_fwd(q, k, v, o, B, H, Sq, Sk, d, scale, *, lse=None, q_view=None, k_vie
     kv = k_view or (H * d, Sk * H * d)
     vv = v_view or (H * d, Sk * H * d)
     ov = o_view or (H * d, Sq * H * d)
-    _call("lgd_attn_fwd_f16", _p(q), qv[0], qv[1], _p(k), kv[0], kv[1], _p(v), vv[0], vv[1], _p(o),
-          ov[0], ov[1], _p(lse), B, H, Sq, Sk, d, float(scale), _stream())
+    fn = lambda: _call("lgd_attn_fwd_f16", _p(q), qv[0], qv[1], _p(k), kv[0], kv[1], _p(v), vv[0], vv[1],
+                       _p(o), ov[0], ov[1], _p(lse), B, H, Sq, Sk, d, float(scale), _stream())
+    if PROFILER is not None:
+        PROFILER.wrap(f"attn_fwd_kernel d={d}", 4.0 * B * H * Sq * Sk * d, 2.0 * B * H * d * (2 * Sq + 2 * Sk), fn)
+    else:
+        fn()
     return o
 
 

@@ -1,0 +1,276 @@
+"""Stage-2 generation of one cached layout on the HIP engine: LMD+ (generation/lmd_plus.py:193-520),
+training-free LMD (generation/lmd.py:215-551) and the backward-guidance baseline
+(generation/backward_guidance.py).
+
+"Cached layout" = everything stage 1 and the text encoder produce for a prompt, computed ahead of
+the hot path: boxes, CLIP hidden states of the per-box / overall / negative
+prompts, pooled phrase embeddings for GLIGEN, token positions of the phrases.  SAM mask refinement
+(models/sam.py, out of scope: §8f rank 2) is replaced by the box mask `proportion_to_mask`.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .energy import scale_proportion
+from .sampler import DEFAULT_GUIDANCE_ATTN_KEYS, LMDSampler, prepare_gligen_condition
+from .weights import UNetConfig
+
+F32 = torch.float32
+OBJ_ATTN_KEY = ("down", 2, 1, 0)                     # generation/lmd_plus.py:380
+DEFAULT_MAX_ITER = [4] * 5 + [3] * 5 + [2] * 5 + [2] * 5 + [1] * 10   # lmd_plus.py:202
+
+
+def convert_box(box, height=512, width=512):
+    """utils/parse.py:302-309: (x, y, w, h) in pixels -> (x_min, y_min, x_max, y_max) in [0,1]."""
+    x_min, y_min = box[0] / width, box[1] / height
+    return x_min, y_min, x_min + box[2] / width, y_min + box[3] / height
+
+
+@dataclass
+class CachedLayout:
+    """One prompt's stage-1 + text-encoder products (order follows parse.convert_spec: boxes sorted
+    by object name; `overall_groups[g]` lists the box indices that share phrase g)."""
+    boxes: List[Tuple[float, float, float, float]]          # xyxy in [0,1], per box
+    so_uncond: torch.Tensor                                  # (1,77,Cx) negative prompt (per-box stage)
+    so_cond: torch.Tensor                                    # (N,77,Cx) per-box prompts
+    so_object_positions: List[List[int]]                     # token positions of the phrase in so prompt i
+    so_word_token_index: List[int]
+    overall_uncond: torch.Tensor                             # (1,77,Cx)
+    overall_cond: torch.Tensor                               # (1,77,Cx)
+    overall_groups: List[List[int]]
+    overall_object_positions: List[List[int]]                # per group
+    overall_word_token_indices: List[int]                    # per group
+    phrase_embeddings: torch.Tensor                          # (N,768) CLIP pooler_output per box phrase
+    bg_seed: int = 0
+    fg_seed_start: int = 20
+
+    @property
+    def n_boxes(self):
+        return len(self.boxes)
+
+    @staticmethod
+    def synthetic(cfg: UNetConfig, gen_boxes, index: int = 0, height=512, width=512) -> "CachedLayout":
+        """Synthetic text side for a real cached layout: seeded random CLIP states,
+        object o occupies tokens [1+4o, 2+4o, 3+4o] (word = last), seeds as generate.py:226-229."""
+        gen_boxes = sorted(gen_boxes, key=lambda gb: gb[0])                       # parse.py:315
+        names = [n for n, _ in gen_boxes]
+        boxes = [convert_box(b, height, width) for _, b in gen_boxes]
+        uniq = sorted(set(names))                                                 # np.unique order
+        groups = [[i for i, n in enumerate(names) if n == u] for u in uniq]
+        cx = cfg.cross_attention_dim
+        g = lambda seed, shape: torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+        n = len(boxes)
+        return CachedLayout(
+            boxes=boxes,
+            so_uncond=g(7000 + index, (1, 77, cx)), so_cond=g(7100 + index, (max(n, 1), 77, cx))[:n],
+            so_object_positions=[[1, 2, 3] for _ in range(n)], so_word_token_index=[3] * n,
+            overall_uncond=g(7200 + index, (1, 77, cx)), overall_cond=g(7300 + index, (1, 77, cx)),
+            overall_groups=groups,
+            overall_object_positions=[[1 + 4 * o, 2 + 4 * o, 3 + 4 * o] for o in range(len(groups))],
+            overall_word_token_indices=[3 + 4 * o for o in range(len(groups))],
+            phrase_embeddings=g(7400 + index, (max(n, 1), cfg.gligen_positive_len))[:n],
+            bg_seed=index, fg_seed_start=index + 123456789)                      # generate.py:226-229,317-344
+
+
+# -------------------------------------------------------------------------------------------------
+# host-side latent preparation (utils/latents.py) — tiny tensors, same arithmetic as the reference
+# -------------------------------------------------------------------------------------------------
+def proportion_to_mask(box, H, W) -> torch.Tensor:
+    x0, y0, x1, y1 = scale_proportion(box, H, W)                                 # utils/utils.py:46-55
+    m = torch.zeros(H, W)
+    m[y0:y1, x0:x1] = 1.
+    return m
+
+
+def get_input_latents_list(bg_seed, fg_seed_start, so_boxes, fg_blending_ratio, in_channels=4, H=64, W=64):
+    """utils/latents.py:120-161: CPU-generator seeded noise, foreground blended inside each box."""
+    rnd = lambda seed: torch.randn((1, in_channels, H, W), generator=torch.manual_seed(seed), dtype=F32)
+    bg = rnd(bg_seed)
+    out = []
+    for idx, box in enumerate(so_boxes):
+        m = proportion_to_mask(box, H, W)
+        fg_seed = fg_seed_start + idx
+        if fg_seed == bg_seed:
+            fg_seed += 12345
+        fg = rnd(fg_seed)
+        out.append(bg * (1. - m) + (bg * np.sqrt(1. - fg_blending_ratio) + fg * np.sqrt(fg_blending_ratio)) * m)
+    return out, bg
+
+
+def binary_mask_to_box_mask(mask: torch.Tensor) -> torch.Tensor:
+    """utils/utils.py:72-100."""
+    loc = torch.where(mask)
+    h, w = mask.shape
+    ymin, ymax = max(int(loc[0].min()) - 1, 0), min(int(loc[0].max()) + 1, h)
+    xmin, xmax = max(int(loc[1].min()) - 1, 0), min(int(loc[1].max()) + 1, w)
+    m = torch.zeros(h, w)
+    m[ymin:ymax + 1, xmin:xmax + 1] = 1.
+    return m
+
+
+def compose_latents(latents_all_list, mask_list, steps, latents_bg):
+    """utils/latents.py:38-83 (compose_box_to_bg=True, no fast schedule), on whatever device the
+    histories live (the reference does it on CPU after offloading every step)."""
+    dev = latents_bg.device
+    composed = torch.zeros((steps + 1, *latents_bg.shape), device=dev, dtype=F32)
+    composed[0] = latents_bg
+    fg_idx = torch.zeros(latents_bg.shape[-2:], dtype=torch.long)
+    order = np.argsort(-np.array([float(m.sum()) for m in mask_list])) if mask_list else []
+    for i in order:
+        bm = binary_mask_to_box_mask(mask_list[i]).to(dev)[None, None, None]
+        composed[0] = composed[0] * (1. - bm) + latents_all_list[i][0] * bm
+    for i in order:
+        m = mask_list[i]
+        fg_idx = fg_idx * (~m) + (i + 1) * m
+        me = m.to(dev)[None, None, None].float()
+        composed = composed * (1. - me) + latents_all_list[i] * me
+    return composed, fg_idx
+
+
+# -------------------------------------------------------------------------------------------------
+def _ref_maps(sampler: LMDSampler, saved_list, keys, L, T):
+    """Stage-A maps R_b (guidance.py:201) -> fp32 [T][n_boxes][n_keys][heads][max_hw]."""
+    hw = sampler.map_hw(L)
+    heads = sampler.heads_of(keys[0])
+    max_hw = max(hw[k] for k in keys)
+    out = torch.zeros((T, len(saved_list), len(keys), heads, max_hw), device=sampler.dev, dtype=F32)
+    for b, saved in enumerate(saved_list):
+        for ki, k in enumerate(keys):
+            out[:, b, ki, :, :hw[k]] = saved[k][:, 0, :, :, 0]      # [T,1,H,HW,1] (cond only, word token)
+    return out
+
+
+def lmd_plus_generate(sampler: LMDSampler, lay: CachedLayout, *, num_inference_steps=50,
+                      frozen_step_ratio=0.5, guidance_scale=7.5, so_gligen_scheduled_sampling_beta=0.4,
+                      overall_gligen_scheduled_sampling_beta=0.4, overall_loss_scale=5,
+                      overall_loss_threshold=5.0, overall_max_iter=None, overall_max_index_step=30,
+                      overall_fg_top_p=0.2, overall_bg_top_p=0.2, overall_fg_weight=1.0,
+                      overall_bg_weight=4.0, ref_ca_loss_weight=2.0, fg_blending_ratio=0.1,
+                      use_ref_ca=True, height=512, width=512, decode=True, guidance_attn_keys=None):
+    """LMD+ for one layout (generation/lmd_plus.py:193-520 with its default arguments; per-box
+    guidance is off there: max_index_step=0, :203)."""
+    L = height // 8
+    T = num_inference_steps
+    frozen_steps = int(T * min(max(frozen_step_ratio, 0.0), 1.0))
+    keys = [tuple(k) for k in (guidance_attn_keys or DEFAULT_GUIDANCE_ATTN_KEYS)]
+    dev = sampler.dev
+    C = sampler.eng.cfg.in_channels
+    input_latents, latents_bg = get_input_latents_list(lay.bg_seed, lay.fg_seed_start, lay.boxes,
+                                                       fg_blending_ratio, C, L, L)
+    # ---- stage A: one GLIGEN generation per box (lmd_plus.py:44-145,162-188)
+    latents_all_list, mask_list, saved_list, so_images = [], [], [], []
+    if use_ref_ca or frozen_steps > 0:
+        for i, box in enumerate(lay.boxes):
+            text = torch.cat([lay.so_uncond, lay.so_cond[i:i + 1]])
+            gl = prepare_gligen_condition([list(box)], lay.phrase_embeddings[i:i + 1], dev)
+            r = sampler.denoise(input_latents[i], text, T, guidance_scale=guidance_scale, gligen=gl,
+                                gligen_scheduled_sampling_beta=so_gligen_scheduled_sampling_beta,
+                                saved_cross_attn_keys=[OBJ_ATTN_KEY, *keys] if use_ref_ca else [OBJ_ATTN_KEY],
+                                return_cond_ca_only=True, return_token_ca_only=lay.so_word_token_index[i])
+            if decode:
+                so_images.append(sampler.decode(r["latents"]))       # feeds SAM in the reference
+            latents_all_list.append(r["latents_all"])
+            saved_list.append(r["saved"])
+            mask_list.append(proportion_to_mask(box, L, L).bool())  # SAM stand-in
+    # ---- composition (lmd_plus.py:398-416)
+    composed, fg_idx = compose_latents(latents_all_list, mask_list, T, latents_bg.to(dev))
+    # ---- stage B: overall generation with attention guidance (lmd_plus.py:440-511)
+    overall_bboxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
+    flat = [i for grp in lay.overall_groups for i in grp]
+    guid = None
+    if overall_bboxes:
+        guid = dict(bboxes=overall_bboxes, object_positions=lay.overall_object_positions,
+                    loss_scale=overall_loss_scale, loss_threshold=overall_loss_threshold,
+                    max_iter=overall_max_iter or DEFAULT_MAX_ITER, max_index_step=overall_max_index_step,
+                    fg_top_p=overall_fg_top_p, bg_top_p=overall_bg_top_p, fg_weight=overall_fg_weight,
+                    bg_weight=overall_bg_weight, ref_ca_word_token_only=True, ref_ca_last_token_only=True,
+                    word_token_indices=lay.overall_word_token_indices, ref_ca_loss_weight=ref_ca_loss_weight,
+                    guidance_attn_keys=keys,
+                    ref_maps=_ref_maps(sampler, [saved_list[i] for i in flat], keys, L, T) if use_ref_ca else None)
+    gl = prepare_gligen_condition([list(lay.boxes[i]) for i in flat], lay.phrase_embeddings[flat], dev)
+    text = torch.cat([lay.overall_uncond, lay.overall_cond])
+    r = sampler.denoise(composed, text, T, guidance_scale=guidance_scale, gligen=gl,
+                        gligen_scheduled_sampling_beta=overall_gligen_scheduled_sampling_beta, guidance=guid,
+                        frozen_steps=frozen_steps, frozen_mask=(fg_idx != 0), save_all_latents=False)
+    image = sampler.decode(r["latents"])[0] if decode else None
+    return dict(image=image, latents=r["latents"], so_images=so_images, guidance_iters=r["guidance_iters"],
+                composed=composed, fg_idx=fg_idx)
+
+
+def lmd_generate(sampler: LMDSampler, lay: CachedLayout, *, num_inference_steps=50, frozen_step_ratio=0.4,
+                 guidance_scale=7.5, loss_scale=5, loss_threshold=5.0, max_iter=None, max_index_step=30,
+                 overall_loss_scale=5, overall_loss_threshold=5.0, overall_max_iter=None,
+                 overall_max_index_step=30, fg_top_p=0.2, bg_top_p=0.2, overall_fg_top_p=0.2,
+                 overall_bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0, overall_fg_weight=1.0,
+                 overall_bg_weight=4.0, ref_ca_loss_weight=2.0, fg_blending_ratio=0.01, use_ref_ca=True,
+                 height=512, width=512, decode=True, guidance_attn_keys=None):
+    """Training-free LMD for one layout (generation/lmd.py:215-551, defaults :215-256): per-box stage
+    = generate_semantic_guidance WITH guidance (lmd.py:340-352), overall stage = generate_partial_frozen
+    with the reference-attention term (lmd.py:530-542)."""
+    L = height // 8
+    T = num_inference_steps
+    frozen_steps = int(T * min(max(frozen_step_ratio, 0.0), 1.0))
+    keys = [tuple(k) for k in (guidance_attn_keys or DEFAULT_GUIDANCE_ATTN_KEYS)]
+    dev = sampler.dev
+    C = sampler.eng.cfg.in_channels
+    input_latents, latents_bg = get_input_latents_list(lay.bg_seed, lay.fg_seed_start, lay.boxes,
+                                                       fg_blending_ratio, C, L, L)
+    latents_all_list, mask_list, saved_list, so_images = [], [], [], []
+    for i, box in enumerate(lay.boxes):
+        text = torch.cat([lay.so_uncond, lay.so_cond[i:i + 1]])
+        guid = dict(bboxes=[list(box)], object_positions=[lay.so_object_positions[i]], loss_scale=loss_scale,
+                    loss_threshold=loss_threshold, max_iter=max_iter or DEFAULT_MAX_ITER,
+                    max_index_step=max_index_step, fg_top_p=fg_top_p, bg_top_p=bg_top_p, fg_weight=fg_weight,
+                    bg_weight=bg_weight, guidance_attn_keys=keys)
+        r = sampler.denoise(input_latents[i], text, T, guidance_scale=guidance_scale, guidance=guid,
+                            saved_cross_attn_keys=[OBJ_ATTN_KEY, *keys], return_cond_ca_only=True,
+                            return_token_ca_only=lay.so_word_token_index[i])
+        if decode:
+            so_images.append(sampler.decode(r["latents"]))
+        latents_all_list.append(r["latents_all"])
+        saved_list.append(r["saved"])
+        mask_list.append(proportion_to_mask(box, L, L).bool())
+    composed, fg_idx = compose_latents(latents_all_list, mask_list, T, latents_bg.to(dev))
+    overall_bboxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
+    flat = [i for grp in lay.overall_groups for i in grp]
+    guid = None
+    if overall_bboxes:
+        guid = dict(bboxes=overall_bboxes, object_positions=lay.overall_object_positions,
+                    loss_scale=overall_loss_scale, loss_threshold=overall_loss_threshold,
+                    max_iter=overall_max_iter or DEFAULT_MAX_ITER, max_index_step=overall_max_index_step,
+                    fg_top_p=overall_fg_top_p, bg_top_p=overall_bg_top_p, fg_weight=overall_fg_weight,
+                    bg_weight=overall_bg_weight, ref_ca_word_token_only=True, ref_ca_last_token_only=True,
+                    word_token_indices=lay.overall_word_token_indices, ref_ca_loss_weight=ref_ca_loss_weight,
+                    guidance_attn_keys=keys,
+                    ref_maps=_ref_maps(sampler, [saved_list[i] for i in flat], keys, L, T) if use_ref_ca else None)
+    text = torch.cat([lay.overall_uncond, lay.overall_cond])
+    r = sampler.denoise(composed, text, T, guidance_scale=guidance_scale, guidance=guid,
+                        frozen_steps=frozen_steps, frozen_mask=(fg_idx != 0), save_all_latents=False)
+    image = sampler.decode(r["latents"])[0] if decode else None
+    return dict(image=image, latents=r["latents"], so_images=so_images, guidance_iters=r["guidance_iters"])
+
+
+def backward_guidance_generate(sampler: LMDSampler, lay: CachedLayout, *, num_inference_steps=50,
+                               guidance_scale=7.5, loss_scale=30, loss_threshold=0.2, max_iter=5,
+                               max_index_step=10, height=512, width=512, decode=True,
+                               guidance_attn_keys=None, **energy_kw):
+    """Layout-guidance baseline (generation/backward_guidance.py:46-49,99-120): one
+    generate_semantic_guidance call on seeded noise, no per-box stage (BASELINE config 3)."""
+    L = height // 8
+    C = sampler.eng.cfg.in_channels
+    lat = torch.randn((1, C, L, L), generator=torch.manual_seed(lay.bg_seed), dtype=F32)
+    overall_bboxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
+    guid = None
+    if overall_bboxes:
+        guid = dict(bboxes=overall_bboxes, object_positions=lay.overall_object_positions, loss_scale=loss_scale,
+                    loss_threshold=loss_threshold, max_iter=max_iter, max_index_step=max_index_step,
+                    guidance_attn_keys=[tuple(k) for k in (guidance_attn_keys or DEFAULT_GUIDANCE_ATTN_KEYS)],
+                    **energy_kw)
+    text = torch.cat([lay.overall_uncond, lay.overall_cond])
+    r = sampler.denoise(lat, text, num_inference_steps, guidance_scale=guidance_scale, guidance=guid,
+                        save_all_latents=False)
+    image = sampler.decode(r["latents"])[0] if decode else None
+    return dict(image=image, latents=r["latents"], guidance_iters=r["guidance_iters"])
