@@ -7,6 +7,11 @@ kernels; a missing / stale .so raises at import of the first op.
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process
+# BEFORE liblgd_hip.so is dlopen'ed so that the library's libamdhip64.so.7 dependency resolves to
+# that same runtime (one HIP runtime per process: device pointers and streams are shared with torch).
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgd_hip.so")
 ABI_VERSION = 1

@@ -316,6 +316,7 @@ extern "C" int lgd_attn_fwd_f16(const void* q, int64_t ldq, int64_t q_bs, const 
                                 int64_t ldk, int64_t k_bs, const void* v, int64_t ldv, int64_t v_bs,
                                 void* o, int64_t ldo, int64_t o_bs, float* lse, int B, int H, int Sq,
                                 int Sk, int d, float scale, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if (B < 1 || H < 1 || Sq < 1 || Sk < 1 || d < 8) return LGD_ERR_ARG;
   if (bad_view(ldq, d) || bad_view(ldk, d) || bad_view(ldv, d) || (ldo % 4)) return LGD_ERR_ARG;
   AttnArgs a;
@@ -334,6 +335,7 @@ extern "C" int lgd_cross_attn_fwd_f16(const void* q, int64_t ldq, int64_t q_bs, 
                                       int64_t v_bs, void* o, int64_t ldo, int64_t o_bs, float* probs,
                                       int tok, int cond_only, int B, int H, int Sq, int Sk, int d,
                                       float scale, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if (B < 1 || H < 1 || Sq < 1 || Sk < 1 || d < 8) return LGD_ERR_ARG;
   if (bad_view(ldq, d) || bad_view(ldk, d) || bad_view(ldv, d) || (ldo % 4)) return LGD_ERR_ARG;
   if (cond_only && (B % 2)) return LGD_ERR_ARG;  // attention_processor.py:475

@@ -434,6 +434,7 @@ extern "C" int lgd_attn_bwd_f16(const void* q, int64_t ldq, int64_t q_bs, const 
                                 int64_t ldgq, int64_t gq_bs, void* gk, int64_t ldgk, int64_t gk_bs,
                                 void* gv, int64_t ldgv, int64_t gv_bs, int B, int H, int Sq, int Sk,
                                 int d, float scale, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if (B < 1 || H < 1 || Sq < 1 || Sk < 1 || d < 8 || (d % 8)) return LGD_ERR_ARG;
   if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 8) || (ldgo % 8) || (ldgq % 4) || (ldgk % 4) ||
       (ldgv % 4) || !lse || !delta)
@@ -465,6 +466,7 @@ extern "C" int lgd_cross_attn_bwd_f16(const void* q, int64_t ldq, int64_t q_bs, 
                                       int64_t v_bs, const void* go, int64_t ldgo, int64_t go_bs,
                                       const float* gp, void* gq, int64_t ldgq, int64_t gq_bs, int B,
                                       int H, int Sq, int Sk, int d, float scale, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if (B < 1 || H < 1 || Sq < 1 || Sk < 1 || Sk > XB_MAXSK || d < 8 || (d % 8) || d > XB_MAXD ||
       (ldq % 1) || (ldk % 8) || (ldv % 8))
     return LGD_ERR_ARG;

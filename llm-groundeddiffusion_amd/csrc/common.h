@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 typedef _Float16 half_t;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
@@ -22,7 +23,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int lgd_check_launch() {
   hipError_t e = hipGetLastError();
-  return e == hipSuccess ? LGD_OK : LGD_ERR_LAUNCH;
+  if (e != hipSuccess) {
+    fprintf(stderr, "[lgd_hip] launch error: %s (%d)\n", hipGetErrorString(e), (int)e);
+    return LGD_ERR_LAUNCH;
+  }
+  return LGD_OK;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -118,6 +118,7 @@ extern "C" int lgd_ca_energy_f32(const float* const* maps, float* const* gmaps,
                                  const float* masks, const float* refs, int n_items, int H, int T,
                                  int max_hw, float grad_scale, float* partial, float* loss,
                                  void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if (n_items < 0 || H < 1 || max_hw > E_MAXHW) return LGD_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (n_items > 0)

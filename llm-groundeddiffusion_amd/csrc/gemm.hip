@@ -347,6 +347,7 @@ int launch_gemm(const GemmArgs& ga, hipStream_t st) {
 extern "C" int lgd_abi_version(void) { return LGD_ABI_VERSION; }
 
 extern "C" int lgd_gemm_f16(const LgdGemmDesc* desc, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if (!desc) return LGD_ERR_ARG;
   GemmArgs ga;
   ga.d = *desc;

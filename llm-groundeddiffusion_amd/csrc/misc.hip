@@ -262,6 +262,7 @@ inline int ew_blocks(long n) {
 
 extern "C" int lgd_conv_in_f16(const float* x_nchw, const void* w, const float* bias, void* y, int B,
                                int Cin, int L, int Cout, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if (Cin < 1 || Cin > 8 || Cout < 1) return LGD_ERR_ARG;
   const int K = 9 * Cin;
   size_t smem = (size_t)((K * Cout * 2 + 15) & ~15) + (size_t)CI_PIX * K * 4;
@@ -275,6 +276,7 @@ extern "C" int lgd_conv_in_f16(const float* x_nchw, const void* w, const float* 
 
 extern "C" int lgd_conv_out_f16(const void* x, const void* w, const float* bias, float* y_nchw, int B,
                                 int Cin, int L, int Cout, float out_scale, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if ((Cin % 8) || Cin < 8) return LGD_ERR_ARG;
   long npix = (long)B * L * L;
   dim3 grid((unsigned)((npix + 3) / 4));
@@ -291,6 +293,7 @@ extern "C" int lgd_conv_out_f16(const void* x, const void* w, const float* bias,
 }
 
 extern "C" int lgd_add_f16(const void* a, const void* b, void* y, int64_t n, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if (n % 8) return LGD_ERR_ARG;
   hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), (const half_t*)a, (const half_t*)b,
@@ -299,6 +302,7 @@ extern "C" int lgd_add_f16(const void* a, const void* b, void* y, int64_t n, voi
 }
 
 extern "C" int lgd_scale_f16(const void* x, void* y, float alpha, int64_t n, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if (n % 8) return LGD_ERR_ARG;
   hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), (const half_t*)x, (half_t*)y, alpha,
@@ -307,6 +311,7 @@ extern "C" int lgd_scale_f16(const void* x, void* y, float alpha, int64_t n, voi
 }
 
 extern "C" int lgd_geglu_fwd_f16(const void* h, void* y, int64_t rows, int n, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if (n % 16) return LGD_ERR_ARG;
   hipLaunchKernelGGL(geglu_fwd_kernel, dim3(ew_blocks(rows * (n / 8))), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), (const half_t*)h, (half_t*)y, (long)rows, n);
@@ -315,6 +320,7 @@ extern "C" int lgd_geglu_fwd_f16(const void* h, void* y, int64_t rows, int n, vo
 
 extern "C" int lgd_geglu_bwd_f16(const void* h, const void* gy, void* gh, int64_t rows, int n,
                                  void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if (n % 16) return LGD_ERR_ARG;
   hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_blocks(rows * (n / 8))), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), (const half_t*)h, (const half_t*)gy,
@@ -324,6 +330,7 @@ extern "C" int lgd_geglu_bwd_f16(const void* h, const void* gy, void* gh, int64_
 
 extern "C" int lgd_upsample2x_bwd_f16(const void* gy, void* gx, int B, int H, int W, int C,
                                       void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if (C % 8) return LGD_ERR_ARG;
   hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_blocks((long)B * H * W * (C / 8))), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), (const half_t*)gy, (half_t*)gx, B, H, W,
@@ -335,6 +342,7 @@ extern "C" int lgd_cfg_ddim_step_f32(const float* eps, const float* x, float* x_
                                      const float* coef_table, const int32_t* step_idx,
                                      const float* frozen_ref, const float* mask, int frozen_steps,
                                      float* hist, int B, int C, int HW, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(cfg_ddim_kernel, dim3(ew_blocks((long)B * C * HW)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), eps, x, x_out, coef_table, step_idx,
                      frozen_ref, mask, frozen_steps, hist, B, C * HW, HW);
@@ -343,6 +351,7 @@ extern "C" int lgd_cfg_ddim_step_f32(const float* eps, const float* x, float* x_
 
 extern "C" int lgd_axpy_f32(const float* g, float* x, const float* coef_table,
                             const int32_t* step_idx, int col, int64_t n, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(n)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), g, x, coef_table, step_idx, col, (long)n);
   return lgd_check_launch();
@@ -350,6 +359,7 @@ extern "C" int lgd_axpy_f32(const float* g, float* x, const float* coef_table,
 
 extern "C" int lgd_select_row_f32(const float* table, const int32_t* idx, float* out, int n,
                                   void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(select_row_kernel, dim3(ew_blocks(n)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), table, idx, out, n);
   return lgd_check_launch();

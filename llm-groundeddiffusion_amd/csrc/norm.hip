@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
 extern "C" int lgd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, int B, int HW,
                                  int G, float eps, const float* gamma, const float* beta, int silu,
                                  void* y, float* part, int nchunk, float* stats, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   const int C = c0 + c1;
   if (G > 64 || C > GN_MAXC || (C % G) || (c0 % 8) || (c1 % 8) || nchunk < 1) return LGD_ERR_ARG;
   if (c1 > 0 && !x1) return LGD_ERR_ARG;
@@ -414,6 +415,7 @@ extern "C" int lgd_groupnorm_bwd_f16(const void* gy, const void* x0, const void*
                                      int B, int HW, int G, const float* gamma, const float* beta,
                                      int silu, const float* stats, void* gx0, void* gx1, float* part,
                                      int nchunk, int accumulate, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   const int C = c0 + c1;
   if (G > 64 || C > GN_MAXC || (C % G) || (c0 % 8) || (c1 % 8) || nchunk < 1) return LGD_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -432,6 +434,7 @@ extern "C" int lgd_groupnorm_bwd_f16(const void* gy, const void* x0, const void*
 extern "C" int lgd_layernorm_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int rows, int C,
                                  float eps, const float* gamma, const float* beta, float* stats,
                                  int rows_per_batch, int64_t x_bs, int64_t y_bs, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if ((C % 8) || C > 64 * 8 * LN_MAXV || rows < 1) return LGD_ERR_ARG;
   if (rows_per_batch < 1) rows_per_batch = rows;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -445,6 +448,7 @@ extern "C" int lgd_layernorm_bwd_f16(const void* gy, int64_t ldgy, const void* x
                                      void* gx, int64_t ldgx, int rows, int C, const float* gamma,
                                      const float* stats, int rows_per_batch, int64_t gy_bs,
                                      int64_t x_bs, int64_t gx_bs, int accumulate, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if ((C % 8) || C > 64 * 8 * LN_MAXV || rows < 1 || !stats) return LGD_ERR_ARG;
   if (rows_per_batch < 1) rows_per_batch = rows;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
