@@ -170,6 +170,9 @@ int lgd_geglu_fwd_f16(const void* h, void* y, int64_t rows, int n, void* stream)
 int lgd_add_f16(const void* a, const void* b, void* y, int64_t n, void* stream);
 /* y = alpha * x (fp16) */
 int lgd_scale_f16(const void* x, void* y, float alpha, int64_t n, void* stream);
+/* y = softmax(scale * x) over the last dim, rows x n fp16 (VAE decoder mid-block attention, [ext]
+ * AutoencoderKL; pipelines.py:117-127 decode). */
+int lgd_softmax_rows_f16(const void* x, void* y, int64_t rows, int n, float scale, void* stream);
 /* sum over the 2x2 children of a nearest-2x upsampling: gy [B][2H*2W][C] -> gx [B][H*W][C] */
 int lgd_upsample2x_bwd_f16(const void* gy, void* gx, int B, int H, int W, int C, void* stream);
 
@@ -178,12 +181,13 @@ int lgd_upsample2x_bwd_f16(const void* gy, void* gx, int B, int H, int W, int C,
  *   e = eu + gs*(ec-eu); epsilon or v prediction; x0 = (x - sqrt(1-a_t) e)/sqrt(a_t);
  *   x' = sqrt(a_p) x0 + sqrt(1-a_p) e;
  *   if step < frozen_steps: x' = frozen_ref[step+1]*mask + x'*(1-mask)   (mask [B][HW] fp32)
- *   hist[step+1] = x'  (save_all_latents) when hist != NULL
- * coef_table: device fp32 [T][4] = {a_t, a_prev, guidance_scale, v_prediction flag}; the step is
- * read from the device int32 *step_idx so that a captured hipGraph can be replayed for every step. */
+ *   hist[step+1] = x'  (save_all_latents) when hist != NULL.   x_out may alias x.
+ * coef_table: device fp32 [T][4] = {a_t, a_prev, guidance_scale, v_prediction flag}.
+ * dyn: device int32[2] = {step, frozen_steps} — read on the device so that one captured hipGraph
+ * replays for every step and for both stages. */
 int lgd_cfg_ddim_step_f32(const float* eps, const float* x, float* x_out, const float* coef_table,
-                          const int32_t* step_idx, const float* frozen_ref, const float* mask,
-                          int frozen_steps, float* hist, int B, int C, int HW, void* stream);
+                          const int32_t* dyn, const float* frozen_ref, const float* mask, float* hist,
+                          int B, int C, int HW, void* stream);
 /* guidance latent update (pipelines.py:60-69): x -= coef_table[*step_idx][col] * g */
 int lgd_axpy_f32(const float* g, float* x, const float* coef_table, const int32_t* step_idx, int col,
                  int64_t n, void* stream);
@@ -200,15 +204,16 @@ int lgd_select_row_f32(const float* table, const int32_t* idx, float* out, int n
  *   coefs: fp32  [n_items][4] = {fg_coef, bg_coef, ref_coef, 0} (all normalisations folded in)
  *   maps:  device array of n_maps pointers to fp32 [H][HW][T]; gmaps likewise (pre-zeroed) or NULL
  *   map_hw: int32[n_maps]; masks: fp32 [n_masks][max_hw] (1 inside the box); refs: fp32
- *   [n_refs][H][max_hw] reference maps R_b (guidance.py:201)
+ *   [T][n_refs][H][max_hw] reference maps R_b (guidance.py:201); the slice of step dyn[0] (device
+ *   int32) is used: refs + dyn[0]*refs_step_stride
  *   partial: fp32 [n_items*H] workspace; loss: fp32[1] = sum of all terms.
  *   grad_scale multiplies the map gradients only (static loss scaling for the fp16 backward pass;
  *   undone by the out_scale of the final conv_in dgrad).
  * ------------------------------------------------------------------------------------------- */
 int lgd_ca_energy_f32(const float* const* maps, float* const* gmaps, const int32_t* map_hw,
                       const int32_t* items, const float* coefs, const float* masks, const float* refs,
-                      int n_items, int H, int T, int max_hw, float grad_scale, float* partial,
-                      float* loss, void* stream);
+                      int64_t refs_step_stride, const int32_t* dyn, int n_items, int H, int T,
+                      int max_hw, float grad_scale, float* partial, float* loss, void* stream);
 
 #ifdef __cplusplus
 }

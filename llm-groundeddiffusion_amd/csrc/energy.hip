@@ -22,8 +22,8 @@ __global__ __launch_bounds__(256) void ca_energy_kernel(
     const float* const* __restrict__ maps, float* const* __restrict__ gmaps,
     const int32_t* __restrict__ map_hw, const int32_t* __restrict__ items,
     const float* __restrict__ coefs, const float* __restrict__ masks,
-    const float* __restrict__ refs, int H, int T, int max_hw, float gscale,
-    float* __restrict__ partial) {
+    const float* __restrict__ refs, long refs_step_stride, const int32_t* __restrict__ dyn, int H,
+    int T, int max_hw, float gscale, float* __restrict__ partial) {
   __shared__ float s_v[E_MAXHW];   // A * M      (fg) / A*M (ref)
   __shared__ float s_w[E_MAXHW];   // A * (1-M)  (bg) / R*M (ref)
   __shared__ float s_red[4];
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void ca_energy_kernel(
     if (tid == 0)
       partial[item * H + h] = c_fg * (1.f - fg_sum / (float)k_fg) + c_bg * (bg_sum / (float)k_bg);
   } else {
-    const float* R = refs + ((long)ref_id * H + h) * max_hw;
+    const float* R = refs + (long)dyn[0] * refs_step_stride + ((long)ref_id * H + h) * max_hw;
     float sa = 0.f, sr = 0.f;
     for (int i = tid; i < HW; i += 256) {
       float m = M[i];
@@ -115,15 +115,16 @@ __global__ __launch_bounds__(256) void energy_sum_kernel(const float* __restrict
 
 extern "C" int lgd_ca_energy_f32(const float* const* maps, float* const* gmaps,
                                  const int32_t* map_hw, const int32_t* items, const float* coefs,
-                                 const float* masks, const float* refs, int n_items, int H, int T,
-                                 int max_hw, float grad_scale, float* partial, float* loss,
-                                 void* stream) {
+                                 const float* masks, const float* refs, int64_t refs_step_stride,
+                                 const int32_t* dyn, int n_items, int H, int T, int max_hw,
+                                 float grad_scale, float* partial, float* loss, void* stream) {
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if (n_items < 0 || H < 1 || max_hw > E_MAXHW) return LGD_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (n_items > 0)
     hipLaunchKernelGGL(ca_energy_kernel, dim3(H, n_items), dim3(256), 0, st, maps, gmaps, map_hw,
-                       items, coefs, masks, refs, H, T, max_hw, grad_scale, partial);
+                       items, coefs, masks, refs, (long)refs_step_stride, dyn, H, T, max_hw,
+                       grad_scale, partial);
   hipLaunchKernelGGL(energy_sum_kernel, dim3(1), dim3(256), 0, st, partial, n_items * H, loss);
   return lgd_check_launch();
 }

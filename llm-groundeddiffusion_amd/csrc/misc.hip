@@ -199,13 +199,49 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const half_t* __res
   }
 }
 
+// Row softmax of scale*x (fp16 in/out, fp32 math), one wave per row; used by the single-head
+// 512-channel attention of the VAE decoder mid block (the flash kernel covers head dims <= 160).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const half_t* __restrict__ x,
+                                                            half_t* __restrict__ y, long rows, int n,
+                                                            float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const half_t* xr = x + row * n;
+  half_t* yr = y + row * n;
+  const int nvec = n / 8;
+  float mx = -1.0e30f;
+  for (int v = lane; v < nvec; v += 64) {
+    half8_t h = *reinterpret_cast<const half8_t*>(xr + v * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)h[e] * scale);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int v = lane; v < nvec; v += 64) {
+    half8_t h = *reinterpret_cast<const half8_t*>(xr + v * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += __expf((float)h[e] * scale - mx);
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  for (int v = lane; v < nvec; v += 64) {
+    half8_t h = *reinterpret_cast<const half8_t*>(xr + v * 8);
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)(__expf((float)h[e] * scale - mx) * inv);
+    *reinterpret_cast<half8_t*>(yr + v * 8) = o;
+  }
+}
+
 // per-step fused update, see lgd_hip.h
 __global__ __launch_bounds__(256) void cfg_ddim_kernel(
     const float* __restrict__ eps, const float* __restrict__ x, float* __restrict__ x_out,
-    const float* __restrict__ coef_table, const int32_t* __restrict__ step_idx,
-    const float* __restrict__ frozen_ref, const float* __restrict__ mask, int frozen_steps,
+    const float* __restrict__ coef_table, const int32_t* __restrict__ dyn,
+    const float* __restrict__ frozen_ref, const float* __restrict__ mask,
     float* __restrict__ hist, int B, int CHW, int HW) {
-  const int step = *step_idx;
+  const int step = dyn[0];
+  const int frozen_steps = dyn[1];
   const float a_t = coef_table[step * 4 + 0], a_p = coef_table[step * 4 + 1];
   const float gs = coef_table[step * 4 + 2];
   const bool vpred = coef_table[step * 4 + 3] != 0.f;
@@ -338,14 +374,24 @@ extern "C" int lgd_upsample2x_bwd_f16(const void* gy, void* gx, int B, int H, in
   return lgd_check_launch();
 }
 
+extern "C" int lgd_softmax_rows_f16(const void* x, void* y, int64_t rows, int n, float scale,
+                                    void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  if (n % 8 || rows < 1) return LGD_ERR_ARG;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), (const half_t*)x, (half_t*)y, (long)rows, n,
+                     scale);
+  return lgd_check_launch();
+}
+
 extern "C" int lgd_cfg_ddim_step_f32(const float* eps, const float* x, float* x_out,
-                                     const float* coef_table, const int32_t* step_idx,
-                                     const float* frozen_ref, const float* mask, int frozen_steps,
-                                     float* hist, int B, int C, int HW, void* stream) {
+                                     const float* coef_table, const int32_t* dyn,
+                                     const float* frozen_ref, const float* mask, float* hist, int B,
+                                     int C, int HW, void* stream) {
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(cfg_ddim_kernel, dim3(ew_blocks((long)B * C * HW)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), eps, x, x_out, coef_table, step_idx,
-                     frozen_ref, mask, frozen_steps, hist, B, C * HW, HW);
+                     reinterpret_cast<hipStream_t>(stream), eps, x, x_out, coef_table, dyn, frozen_ref,
+                     mask, hist, B, C * HW, HW);
   return lgd_check_launch();
 }
 

@@ -13,11 +13,34 @@ namespace {
 // ------------------------------------------------------------------------------------------
 constexpr int GN_MAXC = 2560;
 
+// Deterministic block reduction of per-thread (group, value) contributions: every thread deposits
+// up to two (group id, a, b) records in LDS, then thread g < G sums the records of its group in
+// thread order.  (Replaces LDS float atomics, whose order would make results vary run to run.)
+struct GnRec { int g0, g1; float a0, b0, a1, b1; };
+
+__device__ __forceinline__ void gn_group_reduce(GnRec* recs, const GnRec& mine, int G, float* out_a,
+                                                float* out_b) {
+  recs[threadIdx.x] = mine;
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += 256) {
+    float a = 0.f, b = 0.f;
+    for (int t = 0; t < 256; ++t) {
+      const GnRec r = recs[t];
+      if (r.g0 == g) { a += r.a0; b += r.b0; }
+      if (r.g1 == g) { a += r.a1; b += r.b1; }
+    }
+    out_a[g] += a;
+    out_b[g] += b;
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x0,
                                                         const half_t* __restrict__ x1, int c0,
                                                         int c1, int HW, int G, float* part,
                                                         int nchunk) {
   __shared__ float s_sum[64], s_sq[64];  // G <= 64
+  __shared__ GnRec s_rec[256];
   const int C = c0 + c1;
   const int cpg = C / G;
   const int b = blockIdx.y, chunk = blockIdx.x;
@@ -33,42 +56,44 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
   const int vs = nvec < 256 ? nvec : 256;
   const int pl = 256 / vs;
   const int plane = threadIdx.x / vs;
-  for (int v = threadIdx.x % vs; v < nvec && plane < pl; v += vs) {
-    const int c = v * 8;
-    const bool second = c >= c0;
-    const half_t* src = second ? x1 : x0;
-    const int cc = second ? c - c0 : c;
-    const int ld = second ? c1 : c0;
-    float s[8], q[8];
+  const int n_pass = (nvec + vs - 1) / vs;       // uniform trip count: the reduction has barriers
+  for (int pass = 0; pass < n_pass; ++pass) {
+    const int v = threadIdx.x % vs + pass * vs;
+    GnRec rec = {-1, -1, 0.f, 0.f, 0.f, 0.f};
+    if (v < nvec && plane < pl) {
+      const int c = v * 8;
+      const bool second = c >= c0;
+      const half_t* src = second ? x1 : x0;
+      const int cc = second ? c - c0 : c;
+      const int ld = second ? c1 : c0;
+      float s[8], q[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-    for (int p = p_beg + plane; p < p_end; p += pl) {
-      half8_t h = *reinterpret_cast<const half8_t*>(src + ((long)b * HW + p) * ld + cc);
+      for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+      for (int p = p_beg + plane; p < p_end; p += pl) {
+        half8_t h = *reinterpret_cast<const half8_t*>(src + ((long)b * HW + p) * ld + cc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = (float)h[e];
+          s[e] += f;
+          q[e] += f * f;
+        }
+      }
+      // channels c..c+7 may straddle one group boundary when cpg % 8 != 0 (cpg >= 2 -> at most 4
+      // groups in theory; cpg >= 8 in every SD config -> at most 2; smaller cpg handled below)
+      rec.g0 = c / cpg;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float f = (float)h[e];
-        s[e] += f;
-        q[e] += f * f;
+        int g = (c + e) / cpg;
+        if (g == rec.g0) { rec.a0 += s[e]; rec.b0 += q[e]; }
+        else if (rec.g1 < 0 || g == rec.g1) { rec.g1 = g; rec.a1 += s[e]; rec.b1 += q[e]; }
+        else {  // third group inside one 8-channel vector (cpg < 4): rare, keep it exact via atomics
+          atomicAdd(&s_sum[g], s[e]);
+          atomicAdd(&s_sq[g], q[e]);
+        }
       }
     }
-    // channels c..c+7 may straddle a group boundary when cpg % 8 != 0
-    int g_prev = c / cpg;
-    float as = 0.f, aq = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int g = (c + e) / cpg;
-      if (g != g_prev) {
-        atomicAdd(&s_sum[g_prev], as);
-        atomicAdd(&s_sq[g_prev], aq);
-        as = 0.f; aq = 0.f; g_prev = g;
-      }
-      as += s[e];
-      aq += q[e];
-    }
-    atomicAdd(&s_sum[g_prev], as);
-    atomicAdd(&s_sq[g_prev], aq);
+    gn_group_reduce(s_rec, rec, G, s_sum, s_sq);
   }
-  __syncthreads();
   for (int i = threadIdx.x; i < G; i += 256) {
     float* o = part + (((long)b * nchunk + chunk) * G + i) * 2;
     o[0] = s_sum[i];
@@ -91,13 +116,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
   const int C = c0 + c1;
   const int cpg = C / G;
   const int b = blockIdx.y;
+  // partial table [nchunk][G][2] -> (mean, rstd): 256 threads = (G groups) x (256/G slices), fixed
+  // summation order (deterministic)
+  __shared__ float s_ps[256], s_pq[256];
+  {
+    const int gi = threadIdx.x % G, sl = threadIdx.x / G, nsl = 256 / G;
+    float s = 0.f, q = 0.f;
+    if (sl < nsl)
+      for (int ch = sl; ch < nchunk; ch += nsl) {
+        const float* p = part + (((long)b * nchunk + ch) * G + gi) * 2;
+        s += p[0];
+        q += p[1];
+      }
+    s_ps[threadIdx.x] = s;
+    s_pq[threadIdx.x] = q;
+  }
+  __syncthreads();
   if (threadIdx.x < G) {
     float s = 0.f, q = 0.f;
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const float* p = part + (((long)b * nchunk + ch) * G + threadIdx.x) * 2;
-      s += p[0];
-      q += p[1];
-    }
+    for (int sl = 0; sl < 256 / G; ++sl) { s += s_ps[sl * G + threadIdx.x]; q += s_pq[sl * G + threadIdx.x]; }
     float n = (float)HW * cpg;
     float mean = s / n;
     float var = q / n - mean * mean;
@@ -154,6 +191,7 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(
     int c0, int c1, int HW, int G, const float* __restrict__ gamma, const float* __restrict__ beta,
     int silu, const float* __restrict__ stats, float* part, int nchunk) {
   __shared__ float s_1[64], s_2[64];
+  __shared__ GnRec s_rec[256];
   const int C = c0 + c1;
   const int cpg = C / G;
   const int b = blockIdx.y, chunk = blockIdx.x;
@@ -167,52 +205,53 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(
   const int vs = nvec < 256 ? nvec : 256;
   const int pl = 256 / vs;
   const int plane = threadIdx.x / vs;
-  for (int v = threadIdx.x % vs; v < nvec && plane < pl; v += vs) {
-    const int c = v * 8;
-    const bool second = c >= c0;
-    const half_t* src = second ? x1 : x0;
-    const int cc = second ? c - c0 : c;
-    const int ld = second ? c1 : c0;
-    float mean[8], rstd[8], gm[8], bt[8], a1[8], a2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int g = (c + e) / cpg;
-      mean[e] = stats[((long)b * G + g) * 2];
-      rstd[e] = stats[((long)b * G + g) * 2 + 1];
-      gm[e] = gamma[c + e];
-      bt[e] = beta[c + e];
-      a1[e] = 0.f; a2[e] = 0.f;
-    }
-    for (int p = p_beg + plane; p < p_end; p += pl) {
-      half8_t hx = *reinterpret_cast<const half8_t*>(src + ((long)b * HW + p) * ld + cc);
-      half8_t hg = *reinterpret_cast<const half8_t*>(gy + ((long)b * HW + p) * C + c);
+  const int n_pass = (nvec + vs - 1) / vs;
+  for (int pass = 0; pass < n_pass; ++pass) {
+    const int v = threadIdx.x % vs + pass * vs;
+    GnRec rec = {-1, -1, 0.f, 0.f, 0.f, 0.f};
+    if (v < nvec && plane < pl) {
+      const int c = v * 8;
+      const bool second = c >= c0;
+      const half_t* src = second ? x1 : x0;
+      const int cc = second ? c - c0 : c;
+      const int ld = second ? c1 : c0;
+      float mean[8], rstd[8], gm[8], bt[8], a1[8], a2[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float xh = ((float)hx[e] - mean[e]) * rstd[e];
-        float dz = (float)hg[e];
-        if (silu) dz *= silu_grad_f(gm[e] * xh + bt[e]);
-        float dxh = dz * gm[e];
-        a1[e] += dxh;
-        a2[e] += dxh * xh;
+        int g = (c + e) / cpg;
+        mean[e] = stats[((long)b * G + g) * 2];
+        rstd[e] = stats[((long)b * G + g) * 2 + 1];
+        gm[e] = gamma[c + e];
+        bt[e] = beta[c + e];
+        a1[e] = 0.f; a2[e] = 0.f;
       }
-    }
-    int g_prev = c / cpg;
-    float t1 = 0.f, t2 = 0.f;
+      for (int p = p_beg + plane; p < p_end; p += pl) {
+        half8_t hx = *reinterpret_cast<const half8_t*>(src + ((long)b * HW + p) * ld + cc);
+        half8_t hg = *reinterpret_cast<const half8_t*>(gy + ((long)b * HW + p) * C + c);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int g = (c + e) / cpg;
-      if (g != g_prev) {
-        atomicAdd(&s_1[g_prev], t1);
-        atomicAdd(&s_2[g_prev], t2);
-        t1 = 0.f; t2 = 0.f; g_prev = g;
+        for (int e = 0; e < 8; ++e) {
+          float xh = ((float)hx[e] - mean[e]) * rstd[e];
+          float dz = (float)hg[e];
+          if (silu) dz *= silu_grad_f(gm[e] * xh + bt[e]);
+          float dxh = dz * gm[e];
+          a1[e] += dxh;
+          a2[e] += dxh * xh;
+        }
       }
-      t1 += a1[e];
-      t2 += a2[e];
+      rec.g0 = c / cpg;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int g = (c + e) / cpg;
+        if (g == rec.g0) { rec.a0 += a1[e]; rec.b0 += a2[e]; }
+        else if (rec.g1 < 0 || g == rec.g1) { rec.g1 = g; rec.a1 += a1[e]; rec.b1 += a2[e]; }
+        else {
+          atomicAdd(&s_1[g], a1[e]);
+          atomicAdd(&s_2[g], a2[e]);
+        }
+      }
     }
-    atomicAdd(&s_1[g_prev], t1);
-    atomicAdd(&s_2[g_prev], t2);
+    gn_group_reduce(s_rec, rec, G, s_1, s_2);
   }
-  __syncthreads();
   for (int i = threadIdx.x; i < G; i += 256) {
     float* o = part + (((long)b * nchunk + chunk) * G + i) * 2;
     o[0] = s_1[i];
@@ -229,13 +268,23 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
   const int C = c0 + c1;
   const int cpg = C / G;
   const int b = blockIdx.y;
+  __shared__ float s_ps[256], s_pq[256];
+  {
+    const int gi = threadIdx.x % G, sl = threadIdx.x / G, nsl = 256 / G;
+    float s = 0.f, q = 0.f;
+    if (sl < nsl)
+      for (int ch = sl; ch < nchunk; ch += nsl) {
+        const float* p = part + (((long)b * nchunk + ch) * G + gi) * 2;
+        s += p[0];
+        q += p[1];
+      }
+    s_ps[threadIdx.x] = s;
+    s_pq[threadIdx.x] = q;
+  }
+  __syncthreads();
   if (threadIdx.x < G) {
     float s1 = 0.f, s2 = 0.f;
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const float* p = part + (((long)b * nchunk + ch) * G + threadIdx.x) * 2;
-      s1 += p[0];
-      s2 += p[1];
-    }
+    for (int sl = 0; sl < 256 / G; ++sl) { s1 += s_ps[sl * G + threadIdx.x]; s2 += s_pq[sl * G + threadIdx.x]; }
     float n = (float)HW * cpg;
     s_m1[threadIdx.x] = s1 / n;
     s_m2[threadIdx.x] = s2 / n;

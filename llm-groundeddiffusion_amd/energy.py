@@ -113,17 +113,16 @@ class EnergyTables:
         assert refs.shape[1:] == (self.n_refs, self.heads, self.max_hw), refs.shape
         self.refs = refs.to(self.device, F32).contiguous()
 
-    def run(self, index: int = 0, grad_scale: float = 1.0, with_grad: bool = True) -> torch.Tensor:
-        """Launches the energy (+ map gradients into the bound, pre-zeroed gmaps). Returns the device
-        scalar loss (already multiplied by loss_scale, pipelines.py:48)."""
+    def run(self, dyn: torch.Tensor, grad_scale: float = 1.0, with_grad: bool = True) -> torch.Tensor:
+        """Launches the energy (+ map gradients into the bound gmaps, zeroed here) for the step held in
+        the device int32 `dyn[0]`.  Returns the device scalar loss (already multiplied by loss_scale,
+        pipelines.py:48)."""
         mp, gp, maps, gmaps = self._ptrs
         if with_grad and gmaps is not None:
             for k in self.keys:
                 gmaps[k].zero_()
-        refs_ptr = None
-        if self.refs is not None:
-            refs_ptr = self.refs[index].data_ptr()
+        stride = self.refs[0].numel() if self.refs is not None else 0
         ops.ca_energy(mp, gp if with_grad else None, self.map_hw, self.items, self.coefs, self.masks,
-                      None, self.n_items, self.heads, self.T, self.max_hw, self.partial, self.loss,
-                      grad_scale=grad_scale, refs_ptr=refs_ptr or 0)
+                      self.refs, stride, dyn, self.n_items, self.heads, self.T, self.max_hw, self.partial,
+                      self.loss, grad_scale=grad_scale)
         return self.loss

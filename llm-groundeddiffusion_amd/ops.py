@@ -331,6 +331,14 @@ def geglu_fwd(h, out=None):
     return out
 
 
+def softmax_rows(x, scale=1.0, out=None):
+    rows, n = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _call("lgd_softmax_rows_f16", _p(x), _p(out), rows, n, float(scale), _stream())
+    return out
+
+
 def add(a, b, out=None):
     if out is None:
         out = torch.empty_like(a)
@@ -352,11 +360,11 @@ def upsample2x_bwd(gy, B, H, W, C_, out=None):
     return out
 
 
-def cfg_ddim_step(eps, x, x_out, coef_table, step_idx, *, frozen_ref=None, mask=None,
-                  frozen_steps=0, hist=None):
+def cfg_ddim_step(eps, x, x_out, coef_table, dyn, *, frozen_ref=None, mask=None, hist=None):
+    """dyn: device int32[2] = {step, frozen_steps}."""
     B, C_, L, _ = x.shape
-    _call("lgd_cfg_ddim_step_f32", _p(eps), _p(x), _p(x_out), _p(coef_table), _p(step_idx),
-          _p(frozen_ref), _p(mask), int(frozen_steps), _p(hist), B, C_, L * L, _stream())
+    _call("lgd_cfg_ddim_step_f32", _p(eps), _p(x), _p(x_out), _p(coef_table), _p(dyn),
+          _p(frozen_ref), _p(mask), _p(hist), B, C_, L * L, _stream())
     return x_out
 
 
@@ -368,8 +376,8 @@ def select_row(table, idx, out):
     _call("lgd_select_row_f32", _p(table), _p(idx), _p(out), out.numel(), _stream())
 
 
-def ca_energy(map_ptrs, gmap_ptrs, map_hw, items, coefs, masks, refs, n_items, H, T, max_hw,
-              partial, loss, grad_scale=1.0, refs_ptr=None):
-    rp = C.c_void_p(refs_ptr) if refs_ptr is not None else _p(refs)
+def ca_energy(map_ptrs, gmap_ptrs, map_hw, items, coefs, masks, refs, refs_step_stride, dyn, n_items,
+              H, T, max_hw, partial, loss, grad_scale=1.0):
     _call("lgd_ca_energy_f32", _p(map_ptrs), _p(gmap_ptrs), _p(map_hw), _p(items), _p(coefs),
-          _p(masks), rp, n_items, H, T, max_hw, float(grad_scale), _p(partial), _p(loss), _stream())
+          _p(masks), _p(refs), int(refs_step_stride), _p(dyn), n_items, H, T, max_hw, float(grad_scale),
+          _p(partial), _p(loss), _stream())

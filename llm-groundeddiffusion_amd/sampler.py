@@ -24,6 +24,7 @@ from .unet import N_OBJ_TOKENS, UNetEngine
 
 F32 = torch.float32
 DEFAULT_GUIDANCE_ATTN_KEYS = [("mid", 0, 0, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 1, 2, 0)]  # pipelines.py:14
+OBJ_KEY_DEFAULT = ("down", 2, 1, 0)                                                                  # lmd_plus.py:380
 
 
 def prepare_gligen_condition(bboxes, phrase_embeddings, device, positive_len=768):
@@ -67,15 +68,52 @@ class GuidanceState:
         return int(m)
 
 
+class HipGraph:
+    """A captured hipGraph of a launch sequence (torch.cuda.CUDAGraph drives hipStreamBeginCapture on
+    torch's current stream — the stream every lgd_* call is enqueued on).  Replaces ~400 host-side
+    launches per UNet call by one hipGraphLaunch; everything that varies between replays (timestep,
+    frozen-step count, latents, maps) lives in device memory at fixed addresses."""
+
+    def __init__(self, fn, warmup: int = 1):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn()                       # also triggers one-time hipFuncSetAttribute calls
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            fn()
+
+    def __call__(self):
+        self.graph.replay()
+
+
+class _State:
+    """Persistent device buffers of one (latent shape, step count): fixed addresses for the graphs."""
+
+    def __init__(self, dev, C, L, T):
+        self.lat = torch.zeros((1, C, L, L), device=dev, dtype=F32)
+        self.hist = torch.zeros((T + 1, 1, C, L, L), device=dev, dtype=F32)
+        self.frozen_ref = torch.zeros((T + 1, 1, C, L, L), device=dev, dtype=F32)
+        self.mask = torch.zeros((1, L * L), device=dev, dtype=F32)
+        self.ctab = torch.zeros((T, 4), device=dev, dtype=F32)
+        self.gtab = torch.zeros((T, 4), device=dev, dtype=F32)
+        self.graphs = {}
+
+
 class LMDSampler:
     def __init__(self, engine: UNetEngine, scheduler: Optional[DDIMScheduler] = None, vae=None,
-                 grad_scale: float = 1024.0):
+                 grad_scale: float = 1024.0, use_graphs: bool = True):
         self.eng = engine
         self.dev = engine.device
         self.scheduler = scheduler or DDIMScheduler(prediction_type=engine.cfg.prediction_type)
         self.vae = vae
         self.grad_scale = grad_scale
+        self.use_graphs = use_graphs
         self.stats = dict(unet_main=0, guidance_iters=0)
+        self._states = {}
 
     # ------------------------------------------------------------------------------------------
     def map_hw(self, L: int) -> Dict[Tuple, int]:
@@ -113,9 +151,23 @@ class LMDSampler:
         return GuidanceState(en, loss_scale, loss_threshold, max_iter, max_index_step)
 
     # ------------------------------------------------------------------------------------------
-    def backward_guidance(self, gs: GuidanceState, plan_g, index: int, latents: torch.Tensor,
-                          gtable: torch.Tensor, trace: Optional[list] = None):
-        """latent_backward_guidance (pipelines.py:16-82).  `latents` (1,C,L,L) fp32 is updated in place."""
+    def _state(self, C, L, T) -> _State:
+        key = (C, L, T)
+        if key not in self._states:
+            self._states[key] = _State(self.dev, C, L, T)
+        return self._states[key]
+
+    def _runner(self, st: _State, name, fn):
+        """fn enqueued eagerly or as a cached hipGraph."""
+        if not self.use_graphs:
+            return fn
+        if name not in st.graphs:
+            st.graphs[name] = HipGraph(fn)
+        return st.graphs[name]
+
+    def backward_guidance(self, gs: GuidanceState, plan_g, index: int, st: _State, fwd_run, bwd_run,
+                          trace: Optional[list] = None):
+        """latent_backward_guidance (pipelines.py:16-82) on the persistent latent buffer st.lat."""
         if gs is None or index >= gs.max_index_step:
             return
         en = gs.energy
@@ -123,15 +175,71 @@ class LMDSampler:
         it = 0
         en.bind(plan_g.maps, plan_g.gmaps)
         while it < max_it and gs.current_loss() / gs.loss_scale > gs.loss_threshold:
-            plan_g.forward(latents)
-            gs.loss_dev = en.run(index, grad_scale=self.grad_scale)
-            grad = plan_g.backward(self.grad_scale)
+            fwd_run()                                               # grad-plan forward from st.lat
+            gs.loss_dev = en.run(self.eng.dyn, grad_scale=self.grad_scale)
+            bwd_run()                                               # backward + latent update
             if trace is not None:
-                trace.append(dict(index=index, it=it, loss=float(gs.loss_dev.item()), grad=grad.clone()))
-            ops.axpy(grad, latents, gtable, self.eng.step_idx, 0)
+                trace.append(dict(index=index, it=it, loss=float(gs.loss_dev.item()),
+                                  grad=plan_g.g_latents.clone()))
             it += 1
             gs.iterations += 1
             self.stats["guidance_iters"] += 1
+
+    # ------------------------------------------------------------------------------------------
+    def profile_passes(self, L: int, T: int, gligen: bool, guidance_keys=None):
+        """Eager (non-graph) launch sequences of the plans the sampler replays, for per-kernel HIP-event
+        timing by bench.py: [(name, callable)].  Uses whatever run constants are currently loaded."""
+        eng = self.eng
+        st = self._state(eng.cfg.in_channels, L, T)
+        keys = [tuple(k) for k in (guidance_keys or DEFAULT_GUIDANCE_ATTN_KEYS)]
+        plan_keys = sorted({OBJ_KEY_DEFAULT, *DEFAULT_GUIDANCE_ATTN_KEYS})
+        out = []
+        for f in ([True, False] if gligen else [False]):
+            plan = eng.plan(2, L, fuser=f, save_keys=plan_keys)
+            out.append((f"main_fuser_{'on' if f else 'off'}", plan.forward))
+            pg = eng.plan(1, L, grad=True, fuser=f, stop_key=keys[-1], save_keys=keys, text_batch_offset=1)
+
+            def guide(pg=pg):
+                pg.forward(st.lat)
+                pg.backward(self.grad_scale)
+            out.append((f"guide_fuser_{'on' if f else 'off'}", guide))
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def guidance_only(self, latents: torch.Tensor, cond_embeddings: torch.Tensor, num_inference_steps: int,
+                      index: int, guidance: dict, *, gligen=None, fuser: bool = False,
+                      trace: Optional[list] = None):
+        """One latent_backward_guidance call (pipelines.py:16-82) at step `index` of a T-step schedule.
+        Returns (latents, loss) like the reference."""
+        eng, sch, dev = self.eng, self.scheduler, self.dev
+        _, C, L, _ = latents.shape
+        T = num_inference_steps
+        st = self._state(C, L, T)
+        sch.set_timesteps(T)
+        st.gtab.copy_(sch.guidance_step_table(dev))
+        g = dict(guidance)
+        gkeys = [tuple(k) for k in (g.get("guidance_attn_keys") or DEFAULT_GUIDANCE_ATTN_KEYS)]
+        gs = g.pop("state", None) or self.make_guidance(L, g.pop("bboxes"), g.pop("object_positions"), **g)
+        pg = eng.plan(1, L, grad=True, fuser=fuser, stop_key=gkeys[-1], save_keys=gkeys,
+                      text_batch_offset=1, obj_batch_offset=0)
+        eng.prepare_timesteps([int(t) for t in sch.timesteps])
+        cond = cond_embeddings.to(dev)
+        eng.prepare_text(torch.cat([torch.zeros_like(cond), cond]))
+        if gligen is not None:
+            eng.prepare_gligen(boxes=gligen[0], positive_embeddings=gligen[1], masks=gligen[2])
+        eng.set_step(index)
+
+        def g_fwd():
+            pg.forward(st.lat)
+
+        def g_bwd():
+            ops.axpy(pg.backward(self.grad_scale), st.lat, st.gtab, eng.dyn, 0)
+        name = ("guide", fuser, tuple(gkeys))
+        gf, gb = self._runner(st, name + ("fwd",), g_fwd), self._runner(st, name + ("bwd",), g_bwd)
+        st.lat.copy_(latents.to(dev, F32))
+        if gs is not None:
+            self.backward_guidance(gs, pg, index, st, gf, gb, trace)
+        return st.lat.clone(), (gs.current_loss() if gs is not None else None), gs
 
     # ------------------------------------------------------------------------------------------
     def denoise(self, latents: torch.Tensor, text_embeddings: torch.Tensor, num_inference_steps: int, *,
@@ -154,24 +262,23 @@ class LMDSampler:
         guidance_iters).
         """
         eng, sch, dev = self.eng, self.scheduler, self.dev
-        latents_all_input = None
-        if latents.dim() == 5:
-            latents_all_input = latents.to(dev, F32).contiguous()
-            latents = latents_all_input[0]
-        lat = latents.to(dev, F32).clone().contiguous()
-        B1, C, L, _ = lat.shape
+        latents_all_input = latents if latents.dim() == 5 else None
+        lat0 = latents[0] if latents_all_input is not None else latents
+        B1, C, L, _ = lat0.shape
         assert B1 == 1
         T = num_inference_steps
+        st = self._state(C, L, T)
         sch.set_timesteps(T)
-        ctab = sch.coef_table(guidance_scale, dev)
-        gtab = sch.guidance_step_table(dev)
+        st.ctab.copy_(sch.coef_table(guidance_scale, dev))
+        st.gtab.copy_(sch.guidance_step_table(dev))
         use_gligen = gligen is not None
         n_ground = int(gligen_scheduled_sampling_beta * T) if use_gligen else 0
         save_keys = [tuple(k) for k in saved_cross_attn_keys]
+        # a superset of keys is always captured by the main plans so that one graph serves every caller
+        plan_keys = sorted(set(save_keys) | {OBJ_KEY_DEFAULT, *DEFAULT_GUIDANCE_ATTN_KEYS}) if save_keys else []
 
-        # ---- plans (built once per shape, cached on the engine)
-        def main_plan(fuser):
-            return eng.plan(2, L, fuser=fuser, save_keys=save_keys, save_cond_only=return_cond_ca_only)
+        def fuser_at(index):
+            return bool(use_gligen and index < n_ground)                     # pipelines.py:408-414
         gs = None
         gkeys = None
         if guidance is not None:
@@ -179,55 +286,71 @@ class LMDSampler:
             gkeys = [tuple(k) for k in (g.get("guidance_attn_keys") or DEFAULT_GUIDANCE_ATTN_KEYS)]
             gs = self.make_guidance(L, g.pop("bboxes"), g.pop("object_positions"), **g)
 
-        def guide_plan(fuser):
-            return eng.plan(1, L, grad=True, fuser=fuser, stop_key=gkeys[-1], save_keys=gkeys,
-                            text_batch_offset=1, obj_batch_offset=0)
-        def fuser_at(index):
-            return bool(use_gligen and index < n_ground)                     # pipelines.py:408-414
-        plans_main = {f: main_plan(f) for f in {fuser_at(i) for i in range(T)}}
-        plans_guide = {}
-        if gs is not None:
-            plans_guide = {f: guide_plan(f) for f in {fuser_at(i) for i in range(min(gs.max_index_step, T))}}
+        # ---- plans + launch sequences (built/captured once per shape, cached)
+        main_run, guide_run, plans_main, plans_guide = {}, {}, {}, {}
+        for f in {fuser_at(i) for i in range(T)}:
+            plan = plans_main[f] = eng.plan(2, L, fuser=f, save_keys=plan_keys)
 
-        # ---- per-run constants
+            def main_fn(plan=plan):
+                plan.latents_in.copy_(st.lat.expand(2, C, L, L))             # torch.cat([latents]*2)
+                plan.forward()
+                ops.cfg_ddim_step(plan.eps_out, st.lat, st.lat, st.ctab, eng.dyn, frozen_ref=st.frozen_ref,
+                                  mask=st.mask, hist=st.hist)
+            main_run[f] = (main_fn, ("main", f, tuple(plan_keys)))
+        if gs is not None:
+            for f in {fuser_at(i) for i in range(min(gs.max_index_step, T))}:
+                pg = plans_guide[f] = eng.plan(1, L, grad=True, fuser=f, stop_key=gkeys[-1], save_keys=gkeys,
+                                               text_batch_offset=1, obj_batch_offset=0)
+
+                def g_fwd(pg=pg):
+                    pg.forward(st.lat)
+
+                def g_bwd(pg=pg):
+                    grad = pg.backward(self.grad_scale)
+                    ops.axpy(grad, st.lat, st.gtab, eng.dyn, 0)              # pipelines.py:62-69
+                guide_run[f] = (g_fwd, g_bwd, ("guide", f, tuple(gkeys)))
+
+        # ---- per-run constants (before graph capture so that warm-up launches see valid inputs)
         eng.prepare_timesteps([int(t) for t in sch.timesteps])
         eng.prepare_text(text_embeddings)
         if use_gligen:
             eng.prepare_gligen(boxes=gligen[0], positive_embeddings=gligen[1], masks=gligen[2])
+        eng.set_step(0)
+        eng.dyn[1:2].fill_(0)
+        runners_main = {f: self._runner(st, name, fn) for f, (fn, name) in main_run.items()}
+        runners_guide = {f: (self._runner(st, name + ("fwd",), gf), self._runner(st, name + ("bwd",), gb))
+                         for f, (gf, gb, name) in guide_run.items()}
 
-        hist = torch.zeros((T + 1, 1, C, L, L), device=dev, dtype=F32) if save_all_latents else None
-        if hist is not None:
-            hist[0].copy_(lat)
+        # ---- state of this call
+        st.lat.copy_(lat0.to(dev, F32))
+        st.hist[0].copy_(st.lat)
+        if frozen_mask is not None and frozen_steps > 0 and latents_all_input is not None:
+            st.frozen_ref.copy_(latents_all_input.to(dev, F32))
+            st.mask.copy_(frozen_mask.to(dev, F32).clamp(0., 1.).reshape(1, L * L))
+            eng.dyn[1:2].fill_(int(frozen_steps))
         saved = {}
         hw = self.map_hw(L)
+        tok = return_token_ca_only
         for k in save_keys:
-            Tp = 1 if return_token_ca_only is not None else eng.text_len
+            Tp = 1 if tok is not None else eng.text_len
             Bp = 1 if return_cond_ca_only else 2
             saved[k] = torch.zeros((T, Bp, self.heads_of(k), hw[k], Tp), device=dev, dtype=F32)
-        mask_dev = None
-        if frozen_mask is not None and frozen_steps > 0:
-            mask_dev = frozen_mask.to(dev, F32).clamp(0., 1.).reshape(1, L * L).contiguous()
-        lat_next = torch.empty_like(lat)
-        tok = -1 if return_token_ca_only is None else int(return_token_ca_only)
 
         for index in range(T):
             eng.set_step(index)
             fuser_on = fuser_at(index)
             if gs is not None and index < gs.max_index_step:
-                self.backward_guidance(gs, plans_guide[fuser_on], index, lat, gtab, trace)
-            plan = plans_main[fuser_on]
-            for k in save_keys:
-                plan.map_sink[k][0] = saved[k][index]
-                plan.map_sink[k][1] = tok
-            plan.latents_in.copy_(lat.expand(2, C, L, L))                    # torch.cat([latents]*2)
-            eps = plan.forward()
+                gf, gb = runners_guide[fuser_on]
+                self.backward_guidance(gs, plans_guide[fuser_on], index, st, gf, gb, trace)
+            runners_main[fuser_on]()
             self.stats["unet_main"] += 1
-            ops.cfg_ddim_step(eps, lat, lat_next, ctab, eng.step_idx,
-                              frozen_ref=latents_all_input if mask_dev is not None else None,
-                              mask=mask_dev, frozen_steps=frozen_steps, hist=hist)
-            lat, lat_next = lat_next, lat
-        return dict(latents=lat, latents_all=hist, saved=saved,
-                    guidance_iters=gs.iterations if gs is not None else 0)
+            if save_keys:
+                maps = plans_main[fuser_on].maps
+                for k in save_keys:                                   # attention_processor.py:466-476
+                    m = maps[k][1:] if return_cond_ca_only else maps[k]
+                    saved[k][index].copy_(m[..., int(tok):int(tok) + 1] if tok is not None else m)
+        return dict(latents=st.lat.clone(), latents_all=st.hist.clone() if save_all_latents else None,
+                    saved=saved, guidance_iters=gs.iterations if gs is not None else 0)
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -18,7 +18,7 @@ def run():
     from .sampler import LMDSampler, prepare_gligen_condition
     from .scheduler import DDIMScheduler
     from .unet import UNetEngine
-    from .vae import make_vae
+    from .vae import make_hip_vae
 
     dev = torch.device("cuda:0")
     cfg = weights.CONFIGS["tiny_gligen"]
@@ -54,16 +54,10 @@ def run():
     assert e < 2e-2 and em < 3e-2, "HIP UNet forward deviates from the oracle"
     # ---- 2. one backward-guidance iteration (energy + latent gradient) vs the oracle
     sm = LMDSampler(eng, DDIMScheduler())
-    sm.scheduler.set_timesteps(10)
-    eng.prepare_timesteps([int(t) for t in sm.scheduler.timesteps])
-    eng.set_step(1)
-    plan_g = eng.plan(1, L, grad=True, fuser=True, stop_key=keys[-1], save_keys=keys, text_batch_offset=1)
-    eng.prepare_gligen(boxes=gl[0], positive_embeddings=gl[1], masks=gl[2])
-    gs = sm.make_guidance(L, boxes, pos, loss_scale=5, loss_threshold=0.0, max_iter=1, max_index_step=10,
-                          guidance_attn_keys=keys, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
-    lat = x[:1].to(dev).clone()
+    guid = dict(bboxes=boxes, object_positions=pos, loss_scale=5, loss_threshold=0.0, max_iter=1, max_index_step=10,
+                guidance_attn_keys=keys, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
     tr = []
-    sm.backward_guidance(gs, plan_g, 1, lat, sm.scheduler.guidance_step_table(dev), trace=tr)
+    sm.guidance_only(x[:1], cond, 10, 1, guid, gligen=gl, fuser=True, trace=tr)
     rs = R.DDIM()
     rs.set_timesteps(10)
     tr_ref = []
@@ -77,7 +71,7 @@ def run():
     print(f"[smoke] guidance: loss hip {tr[0]['loss']:.4f} oracle {tr_ref[0]['loss']:.4f}, latent-grad cosine {cos:.5f}")
     assert abs(tr[0]["loss"] - tr_ref[0]["loss"]) / tr_ref[0]["loss"] < 2e-2 and cos > 0.98
     # ---- 3. a tiny end-to-end LMD+ run (2 boxes, 6 steps) just has to execute and stay finite
-    sm = LMDSampler(eng, DDIMScheduler(), vae=make_vae(dev))
+    sm = LMDSampler(eng, DDIMScheduler(), vae=make_hip_vae(dev))
     lay = CachedLayout.synthetic(cfg, [("a white deer", [74, 177, 183, 235]), ("a gray bear", [314, 193, 189, 216])], 3)
     t0 = time.time()
     out = lmd_plus_generate(sm, lay, num_inference_steps=6, height=8 * L, width=8 * L, overall_loss_threshold=0.0,

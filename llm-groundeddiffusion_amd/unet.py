@@ -65,20 +65,18 @@ def choose_splits(M, N, K, batches=1):
 class Plan:
     def __init__(self, eng: "UNetEngine", B: int, L: int, *, grad: bool, fuser: bool,
                  stop_key: Optional[Tuple] = None, save_keys: Sequence[Tuple] = (),
-                 text_batch_offset: int = 0, obj_batch_offset: int = 0, save_cond_only: bool = False):
+                 text_batch_offset: int = 0, obj_batch_offset: int = 0):
         self.eng, self.B, self.L = eng, B, L
         self.obj_off = obj_batch_offset
         self.grad, self.fuser = grad, fuser
         self.stop_key = tuple(stop_key) if stop_key else None
         self.save_keys = [tuple(k) for k in save_keys]
         self.text_off = text_batch_offset
-        self.save_cond_only = save_cond_only
         self.ops: List[Op] = []
         self._buffers: List[torch.Tensor] = []
         self.dbg: Dict[str, Act] = {}                 # named activations (debugging / tests)
-        self.maps: Dict[Tuple, torch.Tensor] = {}     # key -> fp32 [Bp,H,HW,Tp] (default save target)
-        self.gmaps: Dict[Tuple, torch.Tensor] = {}    # key -> fp32 gradient of the map
-        self.map_sink: Dict[Tuple, List] = {}         # key -> [tensor, tok] (mutable save target)
+        self.maps: Dict[Tuple, torch.Tensor] = {}     # key -> fp32 [B,H,HW,T] captured probabilities
+        self.gmaps: Dict[Tuple, torch.Tensor] = {}    # key -> fp32 gradient of the map (grad plans)
         self.latents_in = torch.zeros((B, eng.cfg.in_channels, L, L), device=eng.device, dtype=F32)
         self.eps_out = None
         self.g_latents = None
@@ -331,21 +329,19 @@ class Plan:
         k_view = (2 * C, T * 2 * C)
         o = self._act(B * S, C)
         scale = d ** -0.5
-        save = key in self.save_keys
-        if save:
-            Bp = B // 2 if self.save_cond_only else B
-            self.maps[key] = torch.zeros((Bp, heads, S, T), device=eng.device, dtype=F32)
-            self.map_sink[key] = [self.maps[key], -1]
+        probs = None
+        if key in self.save_keys:
+            # the map is always captured whole (all images, all 77 columns) into a static buffer, so
+            # the launch has no per-step arguments; callers slice what attention_processor.py:466-476
+            # would have kept (token column / conditional half) when they copy it out.
+            probs = self.maps[key] = torch.zeros((B, heads, S, T), device=eng.device, dtype=F32)
             if self.grad:
                 self.gmaps[key] = torch.zeros((B, heads, S, T), device=eng.device, dtype=F32)
-        sink = self.map_sink.get(key)
-        co = self.save_cond_only
         kt, vt = kv_t, kv_t[:, :, C:]
 
         def fwd():
-            ops.cross_attn_fwd(q.t, kt, vt, o.t, B, heads, S, T, d, scale,
-                               probs=sink[0] if sink else None, tok=sink[1] if sink else -1,
-                               cond_only=co and sink is not None, k_view=k_view, v_view=k_view)
+            ops.cross_attn_fwd(q.t, kt, vt, o.t, B, heads, S, T, d, scale, probs=probs,
+                               k_view=k_view, v_view=k_view)
         if not self.grad:
             self._add(fwd)
             return o
@@ -503,6 +499,7 @@ class Plan:
 
     # --------------------------------------------------------------------------------------
     def forward(self, latents: Optional[torch.Tensor] = None):
+        """Enqueues the whole forward plan (graph-capturable: static pointers, no allocation)."""
         if latents is not None:
             self.latents_in.copy_(latents)
         for op in self.ops:
@@ -534,7 +531,8 @@ class UNetEngine:
         self.max_text_batch = max_text_batch
         self.temb_cur = torch.zeros(self.w.temb_total, device=self.device, dtype=F32)
         self.temb_table = None
-        self.step_idx = torch.zeros(1, device=self.device, dtype=torch.int32)
+        self.dyn = torch.zeros(4, device=self.device, dtype=torch.int32)   # {step, frozen_steps, -, -}
+        self.step_idx = self.dyn[:1]
         self.text_kv: Dict[str, torch.Tensor] = {}
         for b in self.blocks:
             for a in b.attns:
@@ -631,11 +629,11 @@ class UNetEngine:
 
     # ---- plans ---------------------------------------------------------------------------------
     def plan(self, B: int, L: int, *, grad=False, fuser=False, stop_key=None, save_keys=(),
-             text_batch_offset=0, obj_batch_offset=0, save_cond_only=False) -> Plan:
+             text_batch_offset=0, obj_batch_offset=0) -> Plan:
         key = (B, L, grad, fuser, tuple(stop_key) if stop_key else None, tuple(map(tuple, save_keys)),
-               text_batch_offset, obj_batch_offset, save_cond_only)
+               text_batch_offset, obj_batch_offset)
         if key not in self._plans:
             self._plans[key] = Plan(self, B, L, grad=grad, fuser=fuser, stop_key=stop_key,
                                     save_keys=save_keys, text_batch_offset=text_batch_offset,
-                                    obj_batch_offset=obj_batch_offset, save_cond_only=save_cond_only)
+                                    obj_batch_offset=obj_batch_offset)
         return self._plans[key]

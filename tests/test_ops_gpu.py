@@ -319,10 +319,9 @@ def test_cfg_ddim_step(dev):
     hist = torch.zeros(T + 1, B, C, L, L, device=dev)
     for step, frozen_steps, vpred in [(1, 3, 0.0), (4, 3, 0.0), (2, 0, 1.0)]:
         table[:, 3] = vpred
-        idx = torch.tensor([step], device=dev, dtype=torch.int32)
+        idx = torch.tensor([step, frozen_steps], device=dev, dtype=torch.int32)
         out = torch.empty_like(x)
-        ops.cfg_ddim_step(eps, x, out, table, idx, frozen_ref=ref_lat, mask=mask,
-                          frozen_steps=frozen_steps, hist=hist)
+        ops.cfg_ddim_step(eps, x, out, table, idx, frozen_ref=ref_lat, mask=mask, hist=hist)
         a_t, a_p = table[step, 0], table[step, 1]
         e = eps[:B] + 7.5 * (eps[B:] - eps[:B])
         if vpred:
