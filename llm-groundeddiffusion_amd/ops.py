@@ -32,11 +32,27 @@ def _call(name, *args):
 # ---------------------------------------------------------------------------------------------
 # GEMM / conv
 # ---------------------------------------------------------------------------------------------
+WORKSPACE = None          # shared split-K workspace (fp32 tensor), registered by the engine
+WS_FLOATS = 1 << 26
+
+
+def choose_splits(M, N, K, batches=1):
+    """Split-K heuristic (used when the tuning table has no entry): spread small-M problems
+    (8x8 / 16x16 levels) over all 256 CUs."""
+    wgs = ((M + 127) // 128) * ((N + 63) // 64) * batches
+    if wgs >= 256:
+        return 1
+    ktiles = K // 64
+    s = min((512 + wgs - 1) // wgs, max(1, ktiles // 4), 16)
+    return max(1, s)
+
+
 def gemm_desc(a0, w, c, M, N, K, *, a1=None, lda0=None, lda1=0, c0=None, c1=0, taps=1,
               hin=0, win=0, hout=0, wout=0, stride=1, ups=0, ldw=None, bias=None, bias2=None,
-              res=None, ldr=0, alpha=1.0, epi=0, ldc=None, splits=1, ws=None, tile=0,
+              res=None, ldr=0, alpha=1.0, epi=0, ldc=None, splits=None, ws=None, tile=0,
               nb_o=1, nb_i=1, a_bs=(0, 0), w_bs=(0, 0), c_bs=(0, 0), r_bs=(0, 0)):
-    """Builds an LgdGemmDesc from raw pointers (ints) or tensors."""
+    """Builds an LgdGemmDesc from raw pointers (ints) or tensors.  splits=None / tile=0: taken from
+    the measured tuning table (tuning_gfx950.json) when the shape is listed, else from heuristics."""
     d = LgdGemmDesc()
     ptr = lambda t: (t.data_ptr() if torch.is_tensor(t) else (t or 0))
     d.a0, d.a1 = ptr(a0), ptr(a1)
@@ -60,8 +76,21 @@ def gemm_desc(a0, w, c, M, N, K, *, a1=None, lda0=None, lda1=0, c0=None, c1=0, t
     d.c = ptr(c)
     n_out = N // 2 if (epi & EPI_GEGLU) else N
     d.ldc = n_out if ldc is None else ldc
+    ent = tuning_table().get(shape_key(d)) if (splits is None or not tile) else None
+    if splits is None:
+        splits = ent["splits"] if ent else choose_splits(M, N, K, nb_o * nb_i)
+    if not tile:
+        tile = ent["tile"] if (ent and ent["splits"] == splits) else choose_tile(M, N, nb_o * nb_i * max(splits, 1))
+    if splits > 1 and ws is None:
+        global WORKSPACE
+        need = splits * M * N * nb_o * nb_i
+        if WORKSPACE is None or WORKSPACE.device != (c.device if torch.is_tensor(c) else WORKSPACE.device):
+            WORKSPACE = torch.empty(WS_FLOATS, device=c.device if torch.is_tensor(c) else "cuda", dtype=F32)
+        if need > WORKSPACE.numel():
+            raise RuntimeError(f"split-K workspace too small for {splits}x{M}x{N}")
+        ws = WORKSPACE
     d.splits, d.ws = splits, ptr(ws)
-    d.tile = tile if tile else choose_tile(M, N, nb_o * nb_i * max(splits, 1))
+    d.tile = tile
     return d
 
 
@@ -80,6 +109,25 @@ def choose_tile(M, N, batches=1):
     if wgs(128, 64) >= 256:
         return 2
     return 4
+
+
+def shape_key(d) -> str:
+    """Identity of a GEMM launch for the tuning table (everything that changes its cost)."""
+    return (f"M{d.M}_N{d.N}_K{d.K}_t{d.taps}_c{d.c0}+{d.c1}_h{d.hin}x{d.hout}_s{d.stride}_u{d.ups}"
+            f"_e{d.epi & 1}_b{d.nb_o * d.nb_i}")
+
+
+_TUNING = None
+
+
+def tuning_table():
+    global _TUNING
+    if _TUNING is None:
+        import json
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_gfx950.json")
+        _TUNING = json.load(open(path)) if os.path.exists(path) else {}
+    return _TUNING
 
 
 class LaunchProfiler:
@@ -127,7 +175,7 @@ def gemm_launch(desc):
 
 
 def linear(x, w, bias=None, res=None, out=None, *, alpha=1.0, geglu=False, out_f32=False,
-           splits=1, ws=None, tile=0, bias2=None):
+           splits=None, ws=None, tile=0, bias2=None):
     """y = x @ w.T (+bias) ... ; x [M,K] fp16 contiguous, w [N,K] fp16."""
     M, K = x.shape
     N = w.shape[0]
@@ -137,8 +185,6 @@ def linear(x, w, bias=None, res=None, out=None, *, alpha=1.0, geglu=False, out_f
     epi = (EPI_GEGLU if geglu else 0) | (EPI_OUT_F32 if out_f32 else 0)
     if res is not None and res.dtype == F32:
         epi |= EPI_RES_F32
-    if splits > 1 and ws is None:
-        ws = torch.empty((splits, M, N), device=x.device, dtype=F32)
     d = gemm_desc(x, w, out, M, N, K, bias=bias, bias2=bias2, res=res,
                   ldr=(res.stride(0) if res is not None else 0), alpha=alpha, epi=epi,
                   splits=splits, ws=ws, tile=tile, lda0=x.stride(0), ldw=w.stride(0),
@@ -148,7 +194,7 @@ def linear(x, w, bias=None, res=None, out=None, *, alpha=1.0, geglu=False, out_f
 
 
 def conv3x3(x, w, B, H, W, *, x1=None, bias=None, bias2=None, res=None, stride=1, ups=False,
-            out=None, splits=1, ws=None, tile=0, alpha=1.0):
+            out=None, splits=None, ws=None, tile=0, alpha=1.0):
     """3x3 conv, pad 1, channels-last.  x [B*H*W, C0] (stored map; with ups the logical input is
     2H x 2W), optional x1 [B*H*W, C1] concatenated on channels; w [Cout, 9*(C0+C1)]."""
     c0 = x.shape[1]
@@ -164,8 +210,6 @@ def conv3x3(x, w, B, H, W, *, x1=None, bias=None, bias2=None, res=None, stride=1
     M = B * Ho * Wo
     if out is None:
         out = torch.empty((M, Cout), device=x.device, dtype=F16)
-    if splits > 1 and ws is None:
-        ws = torch.empty((splits, M, Cout), device=x.device, dtype=F32)
     d = gemm_desc(x, w, out, M, Cout, K, a1=x1, c0=c0, c1=c1, lda0=x.stride(0),
                   lda1=(x1.stride(0) if x1 is not None else 0), taps=9, hin=H, win=W, hout=Ho,
                   wout=Wo, stride=stride, ups=int(ups), bias=bias, bias2=bias2, res=res,

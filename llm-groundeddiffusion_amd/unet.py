@@ -52,14 +52,7 @@ class Op:
         self.bwd = None
 
 
-def choose_splits(M, N, K, batches=1):
-    """Split-K factor: spread small-M problems (8x8 / 16x16 levels) over all 256 CUs."""
-    wgs = ((M + 127) // 128) * ((N + 63) // 64) * batches
-    if wgs >= 256:
-        return 1
-    ktiles = K // 64
-    s = min((512 + wgs - 1) // wgs, max(1, ktiles // 4), 16)
-    return max(1, s)
+choose_splits = ops.choose_splits
 
 
 class Plan:
@@ -113,10 +106,9 @@ class Plan:
         M = rows or x.rows
         n_out = N // 2 if geglu else N
         y = out or self._act(M, n_out)
-        sp = choose_splits(M, N, K)
         d = ops.gemm_desc(x.t, W, y.t, M, N, K, lda0=x.C, bias=b, res=res.t if res else None,
                           ldr=res.C if res else 0, alpha=alpha, epi=EPI_GEGLU if geglu else 0,
-                          ldc=y.C, splits=sp, ws=self._ws(sp * M * N) if sp > 1 else None)
+                          ldc=y.C)
         fwd = lambda: ops.gemm_launch(d)
         if not (self.grad and bwd):
             self._add(fwd)
@@ -126,10 +118,8 @@ class Plan:
         gouts = [x] + ([res] if res else [])
 
         def make_bwd(acc):
-            sp2 = choose_splits(M, K, N)
             dd = ops.gemm_desc(y.g, Wt, x.g, M, K, N, lda0=y.C, alpha=alpha, ldc=x.C,
-                               res=x.g if acc[0] else None, ldr=x.C, splits=sp2,
-                               ws=self._ws(sp2 * M * K) if sp2 > 1 else None)
+                               res=x.g if acc[0] else None, ldr=x.C)
             if res is None:
                 return lambda: ops.gemm_launch(dd)
             racc = acc[1]
@@ -156,13 +146,11 @@ class Plan:
         Ho = (Hl - 1) // stride + 1
         M = B * Ho * Ho
         y = self._act(M, Cout)
-        sp = choose_splits(M, Cout, K)
         bias2 = self.eng.temb_cur[temb_off:temb_off + Cout] if temb_off is not None else None
         d = ops.gemm_desc(x.t, W, y.t, M, Cout, K, a1=x1.t if x1 else None, c0=c0, c1=c1, lda0=c0,
                           lda1=c1, taps=9, hin=H, win=H, hout=Ho, wout=Ho, stride=stride,
                           ups=1 if ups else 0, bias=b, bias2=bias2, res=res.t if res else None,
-                          ldr=res.C if res else 0, ldc=Cout, splits=sp,
-                          ws=self._ws(sp * M * Cout) if sp > 1 else None)
+                          ldr=res.C if res else 0, ldc=Cout)
         fwd = lambda: ops.gemm_launch(d)
         if not self.grad:
             self._add(fwd)
@@ -176,27 +164,21 @@ class Plan:
             if stride == 1 and not ups:
                 # dIn = conv(dOut, flipped W^T); one launch per source (channel slice of Wd rows)
                 for i, (src, lo, cn) in enumerate([(x, 0, c0)] + ([(x1, c0, c1)] if x1 else [])):
-                    sp2 = choose_splits(src.rows, cn, Kd)
                     dd = ops.gemm_desc(y.g, Wd[lo:lo + cn], src.g, src.rows, cn, Kd, c0=Cout, lda0=Cout,
                                        taps=9, hin=H, win=H, hout=H, wout=H, ldc=cn,
-                                       res=src.g if acc[i] else None, ldr=cn, splits=sp2,
-                                       ws=self._ws(sp2 * src.rows * cn) if sp2 > 1 else None)
+                                       res=src.g if acc[i] else None, ldr=cn)
                     runs.append(lambda dd=dd: ops.gemm_launch(dd))
             elif stride == 2:
                 # zero-inserted gather of dOut (hin = Ho) produces the H x H input gradient
-                sp2 = choose_splits(x.rows, c0, Kd)
                 dd = ops.gemm_desc(y.g, Wd, x.g, x.rows, c0, Kd, c0=Cout, lda0=Cout, taps=9, hin=Ho,
                                    win=Ho, hout=H, wout=H, ups=2, ldc=c0,
-                                   res=x.g if acc[0] else None, ldr=c0, splits=sp2,
-                                   ws=self._ws(sp2 * x.rows * c0) if sp2 > 1 else None)
+                                   res=x.g if acc[0] else None, ldr=c0)
                 runs.append(lambda: ops.gemm_launch(dd))
             else:
                 # nearest-2x upsample folded in forward: dgrad at 2H x 2H, then 2x2 sum
                 tmp = self._new(B * Hl * Hl, c0)
-                sp2 = choose_splits(B * Hl * Hl, c0, Kd)
                 dd = ops.gemm_desc(y.g, Wd, tmp, B * Hl * Hl, c0, Kd, c0=Cout, lda0=Cout, taps=9,
-                                   hin=Hl, win=Hl, hout=Hl, wout=Hl, ldc=c0, splits=sp2,
-                                   ws=self._ws(sp2 * B * Hl * Hl * c0) if sp2 > 1 else None)
+                                   hin=Hl, win=Hl, hout=Hl, wout=Hl, ldc=c0)
                 assert not acc[0]
                 runs.append(lambda: (ops.gemm_launch(dd), ops.upsample2x_bwd(tmp, B, H, H, c0, out=x.g)))
             if res is not None:
@@ -214,10 +196,8 @@ class Plan:
         c0, c1 = x.C, (x1.C if x1 else 0)
         M = x.rows
         y = self._act(M, Cout)
-        sp = choose_splits(M, Cout, K)
         d = ops.gemm_desc(x.t, W, y.t, M, Cout, K, a1=x1.t if x1 else None, c0=c0, c1=c1, lda0=c0,
-                          lda1=c1, bias=b, ldc=Cout, splits=sp,
-                          ws=self._ws(sp * M * Cout) if sp > 1 else None)
+                          lda1=c1, bias=b, ldc=Cout)
         fwd = lambda: ops.gemm_launch(d)
         if not self.grad:
             self._add(fwd)
@@ -545,15 +525,11 @@ class UNetEngine:
         self._objs = None
 
     # ---- shared scratch ---------------------------------------------------------------------
-    WS_FLOATS = 1 << 26   # 256 MB: split-K only triggers for < 256 output tiles x <= 16 splits
-
-    def workspace(self, n_floats: int) -> torch.Tensor:
+    def workspace(self, n_floats: int = 0) -> torch.Tensor:
         """One split-K workspace shared by all ops (they run back-to-back on one stream)."""
-        if n_floats > self.WS_FLOATS:
-            raise RuntimeError(f"split-K workspace request too large: {n_floats} floats")
-        if self._ws is None:
-            self._ws = torch.empty(self.WS_FLOATS, device=self.device, dtype=F32)
-        return self._ws
+        if ops.WORKSPACE is None or ops.WORKSPACE.device != self.device:
+            ops.WORKSPACE = torch.empty(ops.WS_FLOATS, device=self.device, dtype=F32)
+        return ops.WORKSPACE
 
     def fuser_cat(self, prefix: str, B: int, S: int, text_off: int) -> torch.Tensor:
         key = (prefix, B, text_off)

@@ -1,0 +1,101 @@
+"""GPU-box tool: enumerates every GEMM / implicit-conv launch shape of the engine's plans (SD1.4+GLIGEN,
+64x64 latents: main B=2 fuser on/off, guidance B=1 fwd+bwd), times each (tile, split-K) candidate with
+HIP events and writes the winners to llm-groundeddiffusion_amd/tuning_gfx950.json.
+
+    python tools/tune_gemm.py [config] [out.json]
+"""
+import json, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import lgd_amd
+from lgd_amd import ops, weights, _lib
+from lgd_amd.unet import UNetEngine
+from lgd_amd.sampler import LMDSampler
+
+cfg_name = sys.argv[1] if len(sys.argv) > 1 else "sd14_gligen"
+out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "llm-groundeddiffusion_amd", "tuning_gfx950.json")
+dev = torch.device("cuda:0")
+cfg = weights.CONFIGS[cfg_name]
+eng = UNetEngine(cfg, dev, None)      # zero weights are fine for timing shapes
+L = cfg.sample_size if cfg_name.startswith("tiny") else 64
+
+shapes = {}
+orig = ops.gemm_launch
+def rec(d):
+    key = ops.shape_key(d)
+    shapes.setdefault(key, dict(M=d.M, N=d.N, K=d.K, taps=d.taps, c0=d.c0, c1=d.c1, hin=d.hin, win=d.win,
+                                hout=d.hout, wout=d.wout, stride=d.stride, ups=d.ups, epi=d.epi,
+                                has_res=bool(d.res), has_bias=bool(d.bias), count=0))
+    shapes[key]["count"] += 1
+    return orig(d)
+ops.gemm_launch = rec
+sm = LMDSampler(eng, use_graphs=False)
+eng.prepare_timesteps([500]); eng.set_step(0)
+for name, fn in sm.profile_passes(L, 50, cfg.use_gated_attention):
+    fn()
+torch.cuda.synchronize()
+ops.gemm_launch = orig
+print(f"{len(shapes)} distinct GEMM shapes")
+
+def bench(sh, tile, splits, reps=12):
+    M, N, K = sh["M"], sh["N"], sh["K"]
+    c0, c1, taps = sh["c0"], sh["c1"], sh["taps"]
+    rows_in = M if taps == 1 else max(1, (M // max(sh["hout"] * sh["wout"], 1))) * sh["hin"] * sh["win"]
+    a0 = torch.randn(rows_in, c0, device=dev).half()
+    a1 = torch.randn(rows_in, c1, device=dev).half() if c1 else None
+    w = (torch.randn(N, K, device=dev) * K ** -0.5).half()
+    geglu = bool(sh["epi"] & 1)
+    n_out = N // 2 if geglu else N
+    c = torch.empty(M, n_out, device=dev, dtype=torch.float16)
+    bias = torch.zeros(N, device=dev) if sh["has_bias"] else None
+    res = torch.zeros(M, n_out, device=dev, dtype=torch.float16) if sh["has_res"] else None
+    ws = torch.empty(splits * M * N, device=dev) if splits > 1 else None
+    d = ops.gemm_desc(a0, w, c, M, N, K, a1=a1, c0=c0, c1=c1, lda0=c0, lda1=c1, taps=taps, hin=sh["hin"],
+                      win=sh["win"], hout=sh["hout"], wout=sh["wout"], stride=sh["stride"], ups=sh["ups"],
+                      bias=bias, res=res, ldr=n_out, epi=sh["epi"] & 1, ldc=n_out, splits=splits, ws=ws, tile=tile)
+    try:
+        orig(d)
+    except RuntimeError:
+        return None
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        orig(d)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3   # us
+
+table = {}
+tot_old = tot_new = 0.0
+for key, sh in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"] * kv[1]["N"] * kv[1]["K"]):
+    M, N, K = sh["M"], sh["N"], sh["K"]
+    geglu = bool(sh["epi"] & 1)
+    cands = []
+    for tile in (1, 2, 3, 4, 5):
+        bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (32, 128)}[tile]
+        wgs = -(-M // bm) * -(-N // bn)
+        for sp in (1, 2, 3, 4, 6, 8, 12, 16):
+            if sp > 1 and (K // 64 < 4 * sp or wgs * sp > 2048 or sp * M * N > (1 << 26)):
+                continue
+            if wgs * sp < 48 and sp < 16 and K // 64 >= 8 * sp:
+                continue   # hopelessly under-filled, a larger split exists
+            cands.append((tile, sp))
+    best = None
+    d_tile = ops.choose_tile(M, N, 1)
+    from lgd_amd.unet import choose_splits
+    base = bench(sh, ops.choose_tile(M, N, choose_splits(M, N, K)), choose_splits(M, N, K))
+    for tile, sp in cands:
+        t = bench(sh, tile, sp)
+        if t is not None and (best is None or t < best[0]):
+            best = (t, tile, sp)
+    fl = 2.0 * M * N * K
+    table[key] = dict(tile=best[1], splits=best[2], us=round(best[0], 2), tflops=round(fl / best[0] / 1e6, 1),
+                      base_us=round(base, 2), count=sh["count"])
+    tot_old += base * sh["count"]; tot_new += best[0] * sh["count"]
+    print(f"{key:60s} n={sh['count']:3d} base {base:7.1f}us -> tile {best[1]} split {best[2]:2d} {best[0]:7.1f}us "
+          f"{fl / best[0] / 1e6:6.1f} TF/s")
+print(f"sum over passes: {tot_old/1e3:.2f} ms -> {tot_new/1e3:.2f} ms")
+json.dump(table, open(out_path, "w"), indent=0, sort_keys=True)
+print("wrote", out_path)
