@@ -13,24 +13,31 @@ namespace {
 // ------------------------------------------------------------------------------------------
 constexpr int GN_MAXC = 2560;
 
-// Deterministic block reduction of per-thread (group, value) contributions: every thread deposits
-// up to two (group id, a, b) records in LDS, then thread g < G sums the records of its group in
-// thread order.  (Replaces LDS float atomics, whose order would make results vary run to run.)
-struct GnRec { int g0, g1; float a0, b0, a1, b1; };
+// Deterministic per-group reduction: every thread deposits its 8 per-channel partial sums (two
+// quantities a, b) in LDS at [pixel lane][channel]; thread g < G then adds the channels of group g
+// over all pixel lanes in a fixed order.  (No float atomics: results are bit-reproducible.)
+constexpr int GN_PASS_C = 2048;   // channels covered by one pass of 256 8-channel vectors
 
-__device__ __forceinline__ void gn_group_reduce(GnRec* recs, const GnRec& mine, int G, float* out_a,
-                                                float* out_b) {
-  recs[threadIdx.x] = mine;
+__device__ __forceinline__ void gn_group_reduce(float* s_a, float* s_b, const float (&a)[8],
+                                                const float (&b)[8], bool active, int slot, int c_lo,
+                                                int c_n, int pl, int cpg, int G, float& acc_a,
+                                                float& acc_b) {
+  // slot = plane * (c_n) + (channel - c_lo) of this thread's first channel
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s_a[slot + e] = a[e]; s_b[slot + e] = b[e]; }
+  }
   __syncthreads();
-  for (int g = threadIdx.x; g < G; g += 256) {
-    float a = 0.f, b = 0.f;
-    for (int t = 0; t < 256; ++t) {
-      const GnRec r = recs[t];
-      if (r.g0 == g) { a += r.a0; b += r.b0; }
-      if (r.g1 == g) { a += r.a1; b += r.b1; }
-    }
-    out_a[g] += a;
-    out_b[g] += b;
+  if (threadIdx.x < G) {
+    const int g = threadIdx.x;
+    int lo = g * cpg, hi = lo + cpg;
+    if (lo < c_lo) lo = c_lo;
+    if (hi > c_lo + c_n) hi = c_lo + c_n;
+    for (int c = lo; c < hi; ++c)
+      for (int p = 0; p < pl; ++p) {
+        acc_a += s_a[p * c_n + (c - c_lo)];
+        acc_b += s_b[p * c_n + (c - c_lo)];
+      }
   }
   __syncthreads();
 }
@@ -39,8 +46,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
                                                         const half_t* __restrict__ x1, int c0,
                                                         int c1, int HW, int G, float* part,
                                                         int nchunk) {
-  __shared__ float s_sum[64], s_sq[64];  // G <= 64
-  __shared__ GnRec s_rec[256];
+  __shared__ float s_a[GN_PASS_C], s_b[GN_PASS_C];
   const int C = c0 + c1;
   const int cpg = C / G;
   const int b = blockIdx.y, chunk = blockIdx.x;
@@ -48,8 +54,6 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
   const int p_beg = chunk * p_per;
   int p_end = p_beg + p_per;
   if (p_end > HW) p_end = HW;
-  for (int i = threadIdx.x; i < G; i += 256) { s_sum[i] = 0.f; s_sq[i] = 0.f; }
-  __syncthreads();
   const int nvec = C / 8;
   // thread -> (vector column, pixel lane): consecutive threads read consecutive channels of one
   // pixel; when C/8 < 256 the spare threads take further pixels of the chunk.
@@ -57,18 +61,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
   const int pl = 256 / vs;
   const int plane = threadIdx.x / vs;
   const int n_pass = (nvec + vs - 1) / vs;       // uniform trip count: the reduction has barriers
+  float acc_s = 0.f, acc_q = 0.f;                // thread g < G: running sums of group g
   for (int pass = 0; pass < n_pass; ++pass) {
     const int v = threadIdx.x % vs + pass * vs;
-    GnRec rec = {-1, -1, 0.f, 0.f, 0.f, 0.f};
-    if (v < nvec && plane < pl) {
+    const bool active = v < nvec && plane < pl;
+    const int c_lo = pass * vs * 8;
+    const int c_n = (nvec - pass * vs < vs ? nvec - pass * vs : vs) * 8;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    if (active) {
       const int c = v * 8;
       const bool second = c >= c0;
       const half_t* src = second ? x1 : x0;
       const int cc = second ? c - c0 : c;
       const int ld = second ? c1 : c0;
-      float s[8], q[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
       for (int p = p_beg + plane; p < p_end; p += pl) {
         half8_t h = *reinterpret_cast<const half8_t*>(src + ((long)b * HW + p) * ld + cc);
 #pragma unroll
@@ -78,26 +85,13 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
           q[e] += f * f;
         }
       }
-      // channels c..c+7 may straddle one group boundary when cpg % 8 != 0 (cpg >= 2 -> at most 4
-      // groups in theory; cpg >= 8 in every SD config -> at most 2; smaller cpg handled below)
-      rec.g0 = c / cpg;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        int g = (c + e) / cpg;
-        if (g == rec.g0) { rec.a0 += s[e]; rec.b0 += q[e]; }
-        else if (rec.g1 < 0 || g == rec.g1) { rec.g1 = g; rec.a1 += s[e]; rec.b1 += q[e]; }
-        else {  // third group inside one 8-channel vector (cpg < 4): rare, keep it exact via atomics
-          atomicAdd(&s_sum[g], s[e]);
-          atomicAdd(&s_sq[g], q[e]);
-        }
-      }
     }
-    gn_group_reduce(s_rec, rec, G, s_sum, s_sq);
+    gn_group_reduce(s_a, s_b, s, q, active, plane * c_n + (v * 8 - c_lo), c_lo, c_n, pl, cpg, G, acc_s, acc_q);
   }
-  for (int i = threadIdx.x; i < G; i += 256) {
-    float* o = part + (((long)b * nchunk + chunk) * G + i) * 2;
-    o[0] = s_sum[i];
-    o[1] = s_sq[i];
+  if (threadIdx.x < G) {
+    float* o = part + (((long)b * nchunk + chunk) * G + threadIdx.x) * 2;
+    o[0] = acc_s;
+    o[1] = acc_q;
   }
 }
 
@@ -190,8 +184,7 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(
     const half_t* __restrict__ gy, const half_t* __restrict__ x0, const half_t* __restrict__ x1,
     int c0, int c1, int HW, int G, const float* __restrict__ gamma, const float* __restrict__ beta,
     int silu, const float* __restrict__ stats, float* part, int nchunk) {
-  __shared__ float s_1[64], s_2[64];
-  __shared__ GnRec s_rec[256];
+  __shared__ float s_a[GN_PASS_C], s_b[GN_PASS_C];
   const int C = c0 + c1;
   const int cpg = C / G;
   const int b = blockIdx.y, chunk = blockIdx.x;
@@ -199,23 +192,27 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(
   const int p_beg = chunk * p_per;
   int p_end = p_beg + p_per;
   if (p_end > HW) p_end = HW;
-  for (int i = threadIdx.x; i < G; i += 256) { s_1[i] = 0.f; s_2[i] = 0.f; }
-  __syncthreads();
   const int nvec = C / 8;
   const int vs = nvec < 256 ? nvec : 256;
   const int pl = 256 / vs;
   const int plane = threadIdx.x / vs;
   const int n_pass = (nvec + vs - 1) / vs;
+  float acc_1 = 0.f, acc_2 = 0.f;
   for (int pass = 0; pass < n_pass; ++pass) {
     const int v = threadIdx.x % vs + pass * vs;
-    GnRec rec = {-1, -1, 0.f, 0.f, 0.f, 0.f};
-    if (v < nvec && plane < pl) {
+    const bool active = v < nvec && plane < pl;
+    const int c_lo = pass * vs * 8;
+    const int c_n = (nvec - pass * vs < vs ? nvec - pass * vs : vs) * 8;
+    float a1[8], a2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+    if (active) {
       const int c = v * 8;
       const bool second = c >= c0;
       const half_t* src = second ? x1 : x0;
       const int cc = second ? c - c0 : c;
       const int ld = second ? c1 : c0;
-      float mean[8], rstd[8], gm[8], bt[8], a1[8], a2[8];
+      float mean[8], rstd[8], gm[8], bt[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         int g = (c + e) / cpg;
@@ -223,7 +220,6 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(
         rstd[e] = stats[((long)b * G + g) * 2 + 1];
         gm[e] = gamma[c + e];
         bt[e] = beta[c + e];
-        a1[e] = 0.f; a2[e] = 0.f;
       }
       for (int p = p_beg + plane; p < p_end; p += pl) {
         half8_t hx = *reinterpret_cast<const half8_t*>(src + ((long)b * HW + p) * ld + cc);
@@ -238,24 +234,13 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(
           a2[e] += dxh * xh;
         }
       }
-      rec.g0 = c / cpg;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        int g = (c + e) / cpg;
-        if (g == rec.g0) { rec.a0 += a1[e]; rec.b0 += a2[e]; }
-        else if (rec.g1 < 0 || g == rec.g1) { rec.g1 = g; rec.a1 += a1[e]; rec.b1 += a2[e]; }
-        else {
-          atomicAdd(&s_1[g], a1[e]);
-          atomicAdd(&s_2[g], a2[e]);
-        }
-      }
     }
-    gn_group_reduce(s_rec, rec, G, s_1, s_2);
+    gn_group_reduce(s_a, s_b, a1, a2, active, plane * c_n + (v * 8 - c_lo), c_lo, c_n, pl, cpg, G, acc_1, acc_2);
   }
-  for (int i = threadIdx.x; i < G; i += 256) {
-    float* o = part + (((long)b * nchunk + chunk) * G + i) * 2;
-    o[0] = s_1[i];
-    o[1] = s_2[i];
+  if (threadIdx.x < G) {
+    float* o = part + (((long)b * nchunk + chunk) * G + threadIdx.x) * 2;
+    o[0] = acc_1;
+    o[1] = acc_2;
   }
 }
 

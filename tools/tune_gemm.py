@@ -18,6 +18,7 @@ out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "llm-grounde
 dev = torch.device("cuda:0")
 cfg = weights.CONFIGS[cfg_name]
 eng = UNetEngine(cfg, dev, None)      # zero weights are fine for timing shapes
+eng.w.refresh_scalars()
 L = cfg.sample_size if cfg_name.startswith("tiny") else 64
 
 shapes = {}
