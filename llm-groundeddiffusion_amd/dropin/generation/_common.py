@@ -1,0 +1,100 @@
+"""Shared host-side front end of the generation plugins: spec -> CachedLayout (text encoder + tokenizer
+products), mirroring generation/lmd_plus.py:270-345,419-438 and utils/parse.py:311-367."""
+import numpy as np
+import torch
+
+import models
+from lgd_amd.pipeline import CachedLayout, convert_box
+from utils import guidance
+
+# prompt.py:43-44 of the reference (negative prompts are part of the plugin's default arguments)
+DEFAULT_SO_NEGATIVE_PROMPT = "artifacts, blurry, smooth texture, bad quality, distortions, unrealistic, distorted image, bad proportions, duplicate, two, many, group, occlusion, occluded, side, border, collate"
+DEFAULT_OVERALL_NEGATIVE_PROMPT = "artifacts, blurry, smooth texture, bad quality, distortions, unrealistic, distorted image, bad proportions, duplicate"
+
+
+def convert_spec(spec, height, width, include_counts=True, verbose=False):
+    """utils/parse.py:311-367.  Uses the reference's own parser (inflect pluralisation) when it is
+    importable through `utils.__path__`; otherwise a minimal pluraliser (only the overall prompt TEXT
+    differs — boxes, grouping and ordering are identical)."""
+    try:
+        from utils import parse
+        return parse.convert_spec(spec, height, width, include_counts=include_counts, verbose=verbose)
+    except Exception:
+        pass
+    prompt, gen_boxes, bg_prompt = spec['prompt'], spec['gen_boxes'], spec['bg_prompt']
+    gen_boxes = sorted(gen_boxes, key=lambda gb: gb[0])
+    gen_boxes = [(name, convert_box(box, height=height, width=width)) for name, box in gen_boxes]
+    so = [((f"{bg_prompt} with {name}" if bg_prompt else f"{name}"), name, name.split(" ")[-1], box)
+          for name, box in gen_boxes]
+    names = [n for n, _ in gen_boxes]
+    uniq, counts = np.unique(names, return_counts=True)
+    overall = []
+    for u, c in zip(uniq, counts):
+        bboxes = [box for name, box in gen_boxes if name == u]
+        phrase = u
+        if c > 1:
+            base = u.replace("an ", "").replace("a ", "")
+            phrase = (f"{c} " if include_counts else "") + base + "s"
+        overall.append((phrase, phrase.split(' ')[-1], bboxes))
+    objects_str = ", ".join(p for p, _, _ in overall)
+    overall_prompt = (f"{bg_prompt} with {objects_str}" if bg_prompt else objects_str) if objects_str else bg_prompt
+    return so, overall_prompt, overall
+
+
+def build_layout(spec, bg_seed, fg_seed_start, so_negative_prompt, overall_negative_prompt, height=512, width=512,
+                 overall_prompt_override="", so_center_box=False, so_horizontal_center_only=True, verbose=False):
+    """Text side of lmd_plus.run / lmd.run for one spec -> CachedLayout + overall bboxes."""
+    md = models.model_dict
+    tok, te = md.tokenizer, md.text_encoder
+    if tok is None or te is None:
+        raise RuntimeError("model_dict has no tokenizer/text_encoder (needed to turn a spec into embeddings); "
+                           "offline benchmarks use lgd_amd.pipeline.CachedLayout.synthetic instead")
+    so_list, overall_prompt, overall = convert_spec(spec, height, width, verbose=verbose)
+    if overall_prompt_override and overall_prompt_override.strip():
+        overall_prompt = overall_prompt_override.strip()
+    if so_center_box:
+        import utils
+        so_list = [(p, ph, w, utils.get_centered_box(b, horizontal_center_only=so_horizontal_center_only))
+                   for p, ph, w, b in so_list]
+    if spec.get("extra_neg_prompt"):
+        so_negative_prompt = spec["extra_neg_prompt"] + ", " + so_negative_prompt
+        overall_negative_prompt = spec["extra_neg_prompt"] + ", " + overall_negative_prompt
+    n = len(so_list)
+    cx = md.unet.config.cross_attention_dim
+    if n:
+        so_unc, so_cond = models.encode_prompts(prompts=[p for p, _, _, _ in so_list], tokenizer=tok, text_encoder=te,
+                                                negative_prompt=so_negative_prompt, one_uncond_input_only=True)
+    else:
+        so_unc, so_cond = torch.zeros(1, 77, cx), torch.zeros(0, 77, cx)
+    so_pos, so_word = [], []
+    for p, ph, w, _ in so_list:
+        pos, wi = guidance.get_phrase_indices(tok, p, [ph], words=[w], return_word_token_indices=True)
+        so_pos.append(pos[0])
+        so_word.append(wi[0])
+    phrases, words = [o[0] for o in overall], [o[1] for o in overall]
+    o_pos, o_word, overall_prompt = guidance.get_phrase_indices(tok, overall_prompt, phrases, words=words,
+                                                                return_word_token_indices=True,
+                                                                add_suffix_if_not_found=True)
+    _, o_unc, o_cond = models.encode_prompts(prompts=[overall_prompt], tokenizer=tok, text_encoder=te,
+                                             negative_prompt=overall_negative_prompt)
+    # GLIGEN phrase embeddings = CLIP pooler_output of each box's phrase (pipelines.py:303-304)
+    if n:
+        ti = tok([ph for _, ph, _, _ in so_list], padding=True, return_tensors="pt").to("cuda")
+        pe = te(**ti).pooler_output.float().cpu()
+    else:
+        pe = torch.zeros(0, 768)
+    names = [ph for _, ph, _, _ in so_list]
+    groups, k = [], 0
+    for _, _, bbs in overall:
+        groups.append(list(range(k, k + len(bbs))))
+        k += len(bbs)
+    return CachedLayout(boxes=[tuple(b) for _, _, _, b in so_list], so_uncond=so_unc.float().cpu(),
+                        so_cond=so_cond.float().cpu(), so_object_positions=so_pos, so_word_token_index=so_word,
+                        overall_uncond=o_unc.float().cpu(), overall_cond=o_cond.float().cpu(), overall_groups=groups,
+                        overall_object_positions=o_pos, overall_word_token_indices=o_word, phrase_embeddings=pe,
+                        bg_seed=bg_seed, fg_seed_start=fg_seed_start)
+
+
+class EasyDict(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__

@@ -1,0 +1,45 @@
+"""generation/lmd_plus.py of the reference: plugin `lmd_plus` (version + run), on the HIP engine.
+generate.py imports this module after `models.model_dict` is set (generate.py:118-153) and calls
+`run(spec, bg_seed=..., fg_seed_start=..., **run_kwargs)`; only `.image` of the result is read (:381)."""
+import models
+from lgd_amd.pipeline import DEFAULT_MAX_ITER, lmd_plus_generate
+
+from ._common import DEFAULT_OVERALL_NEGATIVE_PROMPT, DEFAULT_SO_NEGATIVE_PROMPT, EasyDict, build_layout
+
+version = "lmd_plus"
+height = width = 512
+guidance_scale = 7.5
+
+
+def run(spec, bg_seed=1, overall_prompt_override="", fg_seed_start=20, frozen_step_ratio=0.5, num_inference_steps=50,
+        loss_scale=5, loss_threshold=5.0, max_iter=DEFAULT_MAX_ITER, max_index_step=0, overall_loss_scale=5,
+        overall_loss_threshold=5.0, overall_max_iter=DEFAULT_MAX_ITER, overall_max_index_step=30,
+        so_gligen_scheduled_sampling_beta=0.4, overall_gligen_scheduled_sampling_beta=0.4, overall_fg_top_p=0.2,
+        overall_bg_top_p=0.2, overall_fg_weight=1.0, overall_bg_weight=4.0, ref_ca_loss_weight=2.0, so_center_box=False,
+        fg_blending_ratio=0.1, so_negative_prompt=DEFAULT_SO_NEGATIVE_PROMPT,
+        overall_negative_prompt=DEFAULT_OVERALL_NEGATIVE_PROMPT, so_horizontal_center_only=True,
+        align_with_overall_bboxes=False, horizontal_shift_only=True, use_fast_schedule=False, use_ref_ca=True,
+        use_autocast=True, verbose=False):
+    """Argument names and defaults of generation/lmd_plus.py:193-228.  `use_autocast` is accepted for
+    compatibility: the HIP path always computes fp16 with fp32 accumulation."""
+    if max_index_step != 0:
+        raise NotImplementedError("per-box attention guidance in LMD+ (max_index_step>0) is disabled in the reference "
+                                  "by default and not wired on the HIP path")
+    if align_with_overall_bboxes or use_fast_schedule:
+        raise NotImplementedError("align_with_overall_bboxes / use_fast_schedule are off by default in LMD+")
+    sm = models.model_dict.sampler
+    lay = build_layout(spec, bg_seed, fg_seed_start, so_negative_prompt, overall_negative_prompt, height, width,
+                       overall_prompt_override, so_center_box, so_horizontal_center_only, verbose)
+    print("Key generation settings:", spec, bg_seed, fg_seed_start, frozen_step_ratio,
+          so_gligen_scheduled_sampling_beta, overall_gligen_scheduled_sampling_beta, overall_max_index_step)
+    out = lmd_plus_generate(sm, lay, num_inference_steps=num_inference_steps, frozen_step_ratio=frozen_step_ratio,
+                            guidance_scale=guidance_scale,
+                            so_gligen_scheduled_sampling_beta=so_gligen_scheduled_sampling_beta,
+                            overall_gligen_scheduled_sampling_beta=overall_gligen_scheduled_sampling_beta,
+                            overall_loss_scale=overall_loss_scale, overall_loss_threshold=overall_loss_threshold,
+                            overall_max_iter=overall_max_iter, overall_max_index_step=overall_max_index_step,
+                            overall_fg_top_p=overall_fg_top_p, overall_bg_top_p=overall_bg_top_p,
+                            overall_fg_weight=overall_fg_weight, overall_bg_weight=overall_bg_weight,
+                            ref_ca_loss_weight=ref_ca_loss_weight, fg_blending_ratio=fg_blending_ratio,
+                            use_ref_ca=use_ref_ca, height=height, width=width)
+    return EasyDict(image=out["image"], so_img_list=out["so_images"])

@@ -1,0 +1,105 @@
+"""models/models.py of the reference: process-global model handles (`sd_key`, `sd_version`,
+`model_dict`), prompt encoding and the loader.  `model_dict.unet` is the HIP engine wrapped in the
+reference's UNet2DConditionModel call surface."""
+import torch
+
+from lgd_amd import weights as _weights
+from lgd_amd.sampler import LMDSampler
+from lgd_amd.scheduler import DDIMScheduler
+from lgd_amd.unet import UNetEngine
+from utils import torch_device  # noqa: F401
+
+from .unet_2d_condition import UNet2DConditionModel
+
+# set by generate.py (generate.py:104-123)
+sd_key = ""
+sd_version = ""
+model_dict = None
+
+
+class _EasyDict(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def build_model_dict(cfg, state_dict, vae=None, tokenizer=None, text_encoder=None, device="cuda",
+                     dtype=torch.float16):
+    """model_dict contract of models/models.py:55: vae, tokenizer, text_encoder, unet, scheduler, dtype."""
+    eng = UNetEngine(cfg, device, state_dict)
+    unet = UNet2DConditionModel(eng)
+    sched = DDIMScheduler(prediction_type=cfg.prediction_type)
+    md = _EasyDict(vae=vae, tokenizer=tokenizer, text_encoder=text_encoder, unet=unet, scheduler=sched, dtype=dtype)
+    md["sampler"] = LMDSampler(eng, sched, vae=vae)
+    return md
+
+
+def load_synthetic(name="sd14_gligen", seed=0, device="cuda", with_vae=True):
+    """Seeded random weights of the exact architecture (no checkpoints in the sandbox)."""
+    from lgd_amd.vae import make_hip_vae
+    cfg = _weights.CONFIGS[name]
+    return build_model_dict(cfg, _weights.synth_state_dict(cfg, seed), vae=make_hip_vae(device) if with_vae else None,
+                            device=device)
+
+
+def load_sd(key="runwayml/stable-diffusion-v1-5", use_fp16=False, load_inverse_scheduler=False,
+            use_dpm_multistep_scheduler=False, scheduler_cls=None):
+    """models/models.py:16-62.  Needs the Hugging Face checkpoint (diffusers + network/cache); the UNet
+    state dict is repacked into the HIP engine's arenas, CLIP / VAE stay Hugging Face modules."""
+    try:
+        from diffusers import AutoencoderKL, UNet2DConditionModel as HFUNet
+        from transformers import CLIPTextModel, CLIPTokenizer
+    except ImportError as e:
+        raise RuntimeError("load_sd needs `diffusers` and HF checkpoints; use load_synthetic() offline") from e
+    if use_dpm_multistep_scheduler or scheduler_cls is not None:
+        raise RuntimeError("only the DDIM scheduler is implemented on the HIP path")
+    hf = HFUNet.from_pretrained(key, subfolder="unet")
+    c = hf.config
+    heads = c.attention_head_dim if isinstance(c.attention_head_dim, (list, tuple)) else (c.attention_head_dim,) * 4
+    cfg = _weights.UNetConfig(name=key, block_out_channels=tuple(c.block_out_channels), cross_attention_dim=c.cross_attention_dim,
+                              attention_head_dim=tuple(heads), use_linear_projection=getattr(c, "use_linear_projection", False),
+                              use_gated_attention="gligen" in key, sample_size=c.sample_size)
+    vae = AutoencoderKL.from_pretrained(key, subfolder="vae").to(torch_device)
+    tok = CLIPTokenizer.from_pretrained(key, subfolder="tokenizer")
+    te = CLIPTextModel.from_pretrained(key, subfolder="text_encoder").to(torch_device)
+
+    class _HFVae:
+        def decode(self, z):
+            return vae.decode(z.to(vae.dtype)).sample
+    return build_model_dict(cfg, {k: v.float() for k, v in hf.state_dict().items()}, vae=_HFVae(), tokenizer=tok,
+                            text_encoder=te)
+
+
+def encode_prompts(tokenizer, text_encoder, prompts, negative_prompt="", return_full_only=False,
+                   one_uncond_input_only=False):
+    """models/models.py:63-89."""
+    if negative_prompt == "":
+        print("Note that negative_prompt is an empty string")
+    text_input = tokenizer(prompts, padding="max_length", max_length=tokenizer.model_max_length, truncation=True,
+                           return_tensors="pt")
+    max_length = text_input.input_ids.shape[-1]
+    n_unc = 1 if one_uncond_input_only else len(prompts)
+    uncond_input = tokenizer([negative_prompt] * n_unc, padding="max_length", max_length=max_length, return_tensors="pt")
+    with torch.no_grad():
+        uncond_embeddings = text_encoder(uncond_input.input_ids.to(torch_device))[0]
+        cond_embeddings = text_encoder(text_input.input_ids.to(torch_device))[0]
+    if one_uncond_input_only:
+        return uncond_embeddings, cond_embeddings
+    text_embeddings = torch.cat([uncond_embeddings, cond_embeddings])
+    if return_full_only:
+        return text_embeddings
+    return text_embeddings, uncond_embeddings, cond_embeddings
+
+
+def process_input_embeddings(input_embeddings):
+    """models/models.py:91-109: 2-tuple (uncond, cond) or 3-tuple (text, uncond, cond)."""
+    assert isinstance(input_embeddings, (tuple, list))
+    if len(input_embeddings) == 3:
+        _, unc, cond = input_embeddings
+        assert unc.shape[0] == cond.shape[0], f"{unc.shape[0]} != {cond.shape[0]}"
+        return input_embeddings
+    if len(input_embeddings) == 2:
+        unc, cond = input_embeddings
+        if unc.shape[0] == 1:
+            unc = unc.expand(cond.shape)
+        return torch.cat((unc, cond), dim=0), unc, cond
+    raise ValueError(f"input_embeddings length: {len(input_embeddings)}")

@@ -1,0 +1,144 @@
+"""models/unet_2d_condition.py of the reference: the call surface of UNet2DConditionModel
+(unet_2d_condition.py:704-980) over the HIP engine.
+
+    unet(sample, t, encoder_hidden_states=..., cross_attention_kwargs={save_attn_to_dict, save_keys,
+         return_cond_ca_only, return_token_ca_only, gligen{boxes, positive_embeddings, masks}},
+         return_cross_attention_probs=False) -> object with `.sample`
+
+Under `torch.enable_grad()` with `sample.requires_grad` the saved maps are attached to the autograd
+graph (attention_processor.py:479-480): `torch.autograd.grad(loss(maps), sample)` runs the engine's
+explicit backward plan.  In that mode the forward stops after the last requested map (the noise
+prediction is not needed by the guidance loss — TODO of pipelines.py:46) and `.sample` is None.
+The sampler loops of models/pipelines.py do not go through this wrapper (they replay captured graphs);
+it exists for API compatibility and tests."""
+import torch
+
+from lgd_amd import weights as _weights
+
+from .attention_processor import Attention, AttnProcessor
+
+
+class _Out:
+    def __init__(self, sample):
+        self.sample = sample
+        self.cross_attention_probs_down, self.cross_attention_probs_mid, self.cross_attention_probs_up = [], [], []
+
+
+class GatedSelfAttentionDense:
+    """Handle with the `enabled` switch pipelines.gligen_enable_fuser flips (pipelines.py:280-283)."""
+
+    def __init__(self):
+        self.enabled = True
+
+
+class _MapsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sample, plan, keys, grad_scale):
+        plan.forward(sample.detach().float())
+        ctx.plan, ctx.keys, ctx.grad_scale = plan, keys, grad_scale
+        return tuple(plan.maps[k].clone() for k in keys)
+
+    @staticmethod
+    def backward(ctx, *gmaps):
+        plan = ctx.plan
+        for k, g in zip(ctx.keys, gmaps):
+            plan.gmaps[k].copy_(g * ctx.grad_scale)
+        return plan.backward(ctx.grad_scale).clone(), None, None, None
+
+
+class UNet2DConditionModel:
+    def __init__(self, engine):
+        self.engine = engine
+        cfg = engine.cfg
+
+        class _Cfg(dict):
+            __getattr__ = dict.__getitem__
+        self.config = _Cfg(in_channels=cfg.in_channels, out_channels=cfg.out_channels, sample_size=cfg.sample_size,
+                           cross_attention_dim=cfg.cross_attention_dim, center_input_sample=False,
+                           class_embed_type=None, addition_embed_type=None, encoder_hid_dim_type=None)
+        self._fusers = [GatedSelfAttentionDense() for b in engine.blocks for _ in b.attns] if cfg.use_gated_attention else []
+        self._attn = {}
+        for b in engine.blocks:
+            for a in b.attns:
+                t = f"{a.prefix}.transformer_blocks.0"
+                self._attn[f"{t}.attn1"] = Attention(engine, f"{t}.attn1", a.heads, cross=False)
+                self._attn[f"{t}.attn2"] = Attention(engine, f"{t}.attn2", a.heads, cross=True)
+                if cfg.use_gated_attention:
+                    self._attn[f"{t}.fuser.attn"] = Attention(engine, f"{t}.fuser.attn", a.heads, cross=False)
+
+    # ---- hook API (unet_2d_condition.py:575-633)
+    @property
+    def attn_processors(self):
+        return {f"{name}.processor": a.processor for name, a in self._attn.items()}
+
+    def set_attn_processor(self, processor):
+        count = len(self._attn)
+        if isinstance(processor, dict):
+            if len(processor) != count:
+                raise ValueError(f"A dict of processors was passed, but the number of processors {len(processor)} does "
+                                 f"not match the number of attention layers: {count}.")
+            for name, a in self._attn.items():
+                a.set_processor(processor[f"{name}.processor"])
+        else:
+            for a in self._attn.values():
+                a.set_processor(processor)
+
+    def set_default_attn_processor(self):
+        self.set_attn_processor(AttnProcessor())
+
+    def modules(self):
+        return iter(self._fusers)
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    # ---- forward
+    def __call__(self, sample, timestep, encoder_hidden_states, cross_attention_kwargs=None,
+                 return_cross_attention_probs=False, **unused):
+        if return_cross_attention_probs:
+            raise NotImplementedError("return_cross_attention_probs is deprecated in the reference "
+                                      "(pipelines.py:135); use save_attn_to_dict")
+        eng = self.engine
+        kw = dict(cross_attention_kwargs or {})
+        B, _, L, _ = sample.shape
+        save_dict = kw.get("save_attn_to_dict")
+        all_keys = _weights.attn_keys(eng.cfg)
+        keys = []
+        if save_dict is not None:
+            keys = [tuple(k) for k in (kw.get("save_keys") or all_keys)]
+        gl = kw.get("gligen")
+        fuser = gl is not None and all(f.enabled for f in self._fusers) and bool(self._fusers)
+        need_grad = torch.is_grad_enabled() and sample.requires_grad and bool(keys)
+        stop = None
+        if need_grad:
+            stop = max(keys, key=all_keys.index)
+        if B > eng.max_text_batch:
+            raise RuntimeError(f"engine built for text batch <= {eng.max_text_batch}, got {B}")
+        plan = eng.plan(B, L, grad=need_grad, fuser=fuser, stop_key=stop, save_keys=keys)
+        eng.prepare_timesteps([int(timestep)])
+        eng.set_step(0)
+        eng.prepare_text(encoder_hidden_states)
+        if gl is not None and eng.cfg.use_gated_attention:
+            eng.prepare_gligen(boxes=gl["boxes"], masks=gl["masks"], positive_embeddings=gl["positive_embeddings"])
+        if need_grad:
+            maps = _MapsFn.apply(sample, plan, keys, 1024.0)
+            eps = None
+        else:
+            eps = plan.forward(sample.float()).clone()
+            maps = [plan.maps[k].clone() for k in keys]
+        tok, cond_only = kw.get("return_token_ca_only"), kw.get("return_cond_ca_only", False)
+        for k, m in zip(keys, maps):
+            if tok is not None:
+                m = m[:, :, :, tok:tok + 1] if isinstance(tok, int) else m[:, :, :, tok]
+            if cond_only:
+                assert B % 2 == 0, f"Samples are not in pairs: {B} samples"
+                m = m[B // 2:]
+            if kw.get("offload_cross_attn_to_cpu", False):
+                m = m.cpu()
+            save_dict[k] = m
+        return _Out(eps)
+
+    forward = __call__

@@ -10,16 +10,9 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import ops
+from .hostprep import scale_proportion
 
 F32 = torch.float32
-
-
-def scale_proportion(obj_box, H, W):
-    """utils/utils.py:57-70 (non-legacy branch)."""
-    x_min, y_min = round(obj_box[0] * W), round(obj_box[1] * H)
-    box_w, box_h = round((obj_box[2] - obj_box[0]) * W), round((obj_box[3] - obj_box[1]) * H)
-    x_max, y_max = x_min + box_w, y_min + box_h
-    return max(x_min, 0), max(y_min, 0), min(x_max, W), min(y_max, H)
 
 
 def box_mask(obj_boxes, H, W) -> torch.Tensor:

@@ -14,7 +14,6 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .energy import scale_proportion
 from .sampler import DEFAULT_GUIDANCE_ATTN_KEYS, LMDSampler, prepare_gligen_condition
 from .weights import UNetConfig
 
@@ -75,59 +74,11 @@ class CachedLayout:
             bg_seed=index, fg_seed_start=index + 123456789)                      # generate.py:226-229,317-344
 
 
-# -------------------------------------------------------------------------------------------------
-# host-side latent preparation (utils/latents.py) — tiny tensors, same arithmetic as the reference
-# -------------------------------------------------------------------------------------------------
-def proportion_to_mask(box, H, W) -> torch.Tensor:
-    x0, y0, x1, y1 = scale_proportion(box, H, W)                                 # utils/utils.py:46-55
-    m = torch.zeros(H, W)
-    m[y0:y1, x0:x1] = 1.
-    return m
+from .hostprep import compose as compose_latents, input_latents_list as _input_latents_list, proportion_to_mask
 
 
 def get_input_latents_list(bg_seed, fg_seed_start, so_boxes, fg_blending_ratio, in_channels=4, H=64, W=64):
-    """utils/latents.py:120-161: CPU-generator seeded noise, foreground blended inside each box."""
-    rnd = lambda seed: torch.randn((1, in_channels, H, W), generator=torch.manual_seed(seed), dtype=F32)
-    bg = rnd(bg_seed)
-    out = []
-    for idx, box in enumerate(so_boxes):
-        m = proportion_to_mask(box, H, W)
-        fg_seed = fg_seed_start + idx
-        if fg_seed == bg_seed:
-            fg_seed += 12345
-        fg = rnd(fg_seed)
-        out.append(bg * (1. - m) + (bg * np.sqrt(1. - fg_blending_ratio) + fg * np.sqrt(fg_blending_ratio)) * m)
-    return out, bg
-
-
-def binary_mask_to_box_mask(mask: torch.Tensor) -> torch.Tensor:
-    """utils/utils.py:72-100."""
-    loc = torch.where(mask)
-    h, w = mask.shape
-    ymin, ymax = max(int(loc[0].min()) - 1, 0), min(int(loc[0].max()) + 1, h)
-    xmin, xmax = max(int(loc[1].min()) - 1, 0), min(int(loc[1].max()) + 1, w)
-    m = torch.zeros(h, w)
-    m[ymin:ymax + 1, xmin:xmax + 1] = 1.
-    return m
-
-
-def compose_latents(latents_all_list, mask_list, steps, latents_bg):
-    """utils/latents.py:38-83 (compose_box_to_bg=True, no fast schedule), on whatever device the
-    histories live (the reference does it on CPU after offloading every step)."""
-    dev = latents_bg.device
-    composed = torch.zeros((steps + 1, *latents_bg.shape), device=dev, dtype=F32)
-    composed[0] = latents_bg
-    fg_idx = torch.zeros(latents_bg.shape[-2:], dtype=torch.long)
-    order = np.argsort(-np.array([float(m.sum()) for m in mask_list])) if mask_list else []
-    for i in order:
-        bm = binary_mask_to_box_mask(mask_list[i]).to(dev)[None, None, None]
-        composed[0] = composed[0] * (1. - bm) + latents_all_list[i][0] * bm
-    for i in order:
-        m = mask_list[i]
-        fg_idx = fg_idx * (~m) + (i + 1) * m
-        me = m.to(dev)[None, None, None].float()
-        composed = composed * (1. - me) + latents_all_list[i] * me
-    return composed, fg_idx
+    return _input_latents_list(bg_seed, fg_seed_start, so_boxes, fg_blending_ratio, in_channels, H, W)
 
 
 # -------------------------------------------------------------------------------------------------

@@ -1,0 +1,181 @@
+"""The drop-in boundary (llm-groundeddiffusion_amd/dropin): the reference's plugin / hook surfaces on
+the HIP engine.  Uses a fake whitespace tokenizer + deterministic text encoder (no CLIP in the sandbox)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+KEYS = [("mid", 0, 0, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 1, 2, 0)]
+BBOXES = [[74 / 512, 177 / 512, (74 + 183) / 512, (177 + 235) / 512],
+          [314 / 512, 193 / 512, (314 + 189) / 512, (193 + 216) / 512]]
+OBJ_POS = [[1, 2, 3], [5, 6, 7]]
+
+
+def relerr(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+class _Tok(dict):
+    def __getattr__(self, k):
+        return self[k]
+
+    def to(self, *_a, **_k):
+        return self
+
+
+class FakeTokenizer:
+    model_max_length = 77
+    eos_token = "<eos>"
+
+    def __init__(self):
+        self.vocab, self.rev = {"<bos>": 0, "<eos>": 1}, {0: "<bos>", 1: "<eos>"}
+
+    def _id(self, w):
+        if w not in self.vocab:
+            self.vocab[w] = len(self.vocab)
+            self.rev[self.vocab[w]] = w
+        return self.vocab[w]
+
+    def _convert_id_to_token(self, i):
+        return self.rev[int(i)]
+
+    def __call__(self, texts, padding="do_not_pad", max_length=77, truncation=False, return_tensors="pt"):
+        rows = [[0] + [self._id(w) for w in t.replace(",", " ,").split()][:75] + [1] for t in texts]
+        if padding == "max_length":
+            rows = [r + [1] * (max_length - len(r)) for r in rows]
+        elif padding is True:
+            m = max(len(r) for r in rows)
+            rows = [r + [1] * (m - len(r)) for r in rows]
+        if return_tensors == "np":
+            return _Tok(input_ids=[np.array(r) for r in rows])
+        return _Tok(input_ids=torch.tensor(rows))
+
+
+class FakeTextEncoder:
+    def __init__(self, cx):
+        self.cx = cx
+
+    def _emb(self, ids, dim):
+        g = torch.Generator().manual_seed(1234)
+        table = torch.randn(4096, dim, generator=g)
+        return table[ids.cpu() % 4096]
+
+    def __call__(self, input_ids=None, **kw):
+        class O(tuple):
+            pass
+        h = self._emb(input_ids, self.cx).to("cuda")
+        o = O((h,))
+        o.pooler_output = self._emb(input_ids, 768).mean(dim=1).to("cuda")
+        return o
+
+
+@pytest.fixture(scope="module")
+def dropin(dev):
+    sys.path.insert(0, os.path.join(ROOT, "llm-groundeddiffusion_amd", "dropin"))
+    import lgd_amd  # noqa: F401
+    from lgd_amd import weights
+    import models
+    cfg = weights.CONFIGS["tiny_gligen"]
+    from lgd_amd.vae import HipVAEDecoder, VAEDecoder
+    torch.manual_seed(5)
+    vae = HipVAEDecoder(VAEDecoder(ch=(128, 64, 64, 64), layers=1).float().eval(), dev)
+    models.model_dict = models.build_model_dict(cfg, weights.synth_state_dict(cfg, 0), vae=vae,
+                                                tokenizer=FakeTokenizer(), text_encoder=FakeTextEncoder(cfg.cross_attention_dim))
+    models.sd_key, models.sd_version = "tiny_gligen", "sdv1.4"
+    return models
+
+
+def test_plugin_run_contract(dropin):
+    """generate.py:131-153,327-345,381: `version` attribute, run(spec, bg_seed, fg_seed_start, **kw) -> .image"""
+    import generation.lmd_plus as g
+    assert g.version == "lmd_plus"
+    g.height = g.width = 256
+    spec = dict(prompt="A realistic image of a white deer and a gray bear in an empty factory scene",
+                gen_boxes=[("a white deer", [37, 88, 91, 117]), ("a gray bear", [157, 96, 94, 108])],
+                bg_prompt="A realistic image of an empty factory scene", extra_neg_prompt="")
+    out = g.run(spec, bg_seed=3, fg_seed_start=3 + 123456789, num_inference_steps=6, overall_max_index_step=4,
+                overall_loss_threshold=0.0)
+    assert out.image.dtype == np.uint8 and out.image.shape == (256, 256, 3) and len(out.so_img_list) == 2
+    import generation.lmd as gl
+    import generation.backward_guidance as gb
+    assert gl.version == "lmd" and gb.version == "backward_guidance"
+    gl.height = gl.width = 256
+    out = gl.run(spec, bg_seed=3, fg_seed_start=99, num_inference_steps=12, max_index_step=3, overall_max_index_step=3)
+    assert out.image.shape == (256, 256, 3)
+
+
+def test_phrase_indices_and_energy_hook(dropin, dev):
+    from utils import guidance
+    tok = dropin.model_dict.tokenizer
+    pos, widx, prompt = guidance.get_phrase_indices(tok, "a scene with a white deer and a gray bear",
+                                                    ["a white deer", "a brown fox"], words=["deer", "fox"],
+                                                    return_word_token_indices=True, add_suffix_if_not_found=True)
+    assert pos[0] == [4, 5, 6] and widx[0] == 6 and prompt.endswith("| a brown fox") and widx[1] == pos[1][-1]
+    g = np.load(os.path.join(GOLD, "energy.npz"))
+    ks = lambda k: "_".join(str(x) for x in k)
+    maps = {k: torch.from_numpy(g["map_" + ks(k)]).to(dev).requires_grad_(True) for k in KEYS}
+    loss = guidance.compute_ca_lossv3(saved_attn=maps, bboxes=BBOXES, object_positions=OBJ_POS, guidance_attn_keys=KEYS,
+                                      fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0,
+                                      use_ratio_based_loss=False)
+    grads = torch.autograd.grad(loss, [maps[k] for k in KEYS])
+    assert relerr(loss, g["loss_noref"]) < 1e-5
+    for k, gr in zip(KEYS, grads):
+        assert relerr(gr, g["grad_noref_" + ks(k)]) < 1e-4
+
+
+def test_unet_wrapper_and_attn_processor_hook(dropin, dev):
+    md = dropin.model_dict
+    g = np.load(os.path.join(GOLD, "unet_fwd_tiny_gligen.npz"))
+    saved = {}
+    kw = dict(save_attn_to_dict=saved, save_keys=KEYS, return_cond_ca_only=True, return_token_ca_only=3,
+              gligen=dict(boxes=torch.from_numpy(g["gl_boxes"]), positive_embeddings=torch.from_numpy(g["gl_emb"]),
+                          masks=torch.from_numpy(g["gl_masks"])))
+    from models import pipelines
+    pipelines.gligen_enable_fuser(md.unet, True)
+    out = md.unet(torch.from_numpy(g["x"]).to(dev), torch.tensor(int(g["t"])),
+                  encoder_hidden_states=torch.from_numpy(g["ehs"]).to(dev), cross_attention_kwargs=kw)
+    assert relerr(out.sample, g["eps"]) < 2e-2
+    m = saved[("up", 1, 1, 0)]
+    ref = torch.from_numpy(g["map_up_1_1_0"])[1:, :, :, 3:4]
+    assert tuple(m.shape) == tuple(ref.shape) and relerr(m, ref) < 3e-2
+    assert len(md.unet.attn_processors) == 48          # 16 x (attn1, attn2, fuser.attn) with GLIGEN
+    # layer-level hook: AttnProcessor.__call__ on one cross-attention layer vs torch
+    name = "mid_block.attentions.0.transformer_blocks.0.attn2"
+    attn = md.unet._attn[name]
+    from lgd_amd import weights
+    sd = weights.synth_state_dict(weights.CONFIGS["tiny_gligen"], 0)
+    x = torch.randn(2, 16, 256, device=dev) * 0.5
+    ctx = torch.from_numpy(g["ehs"]).to(dev)
+    d = {}
+    y, p = attn(x, encoder_hidden_states=ctx, return_attntion_probs=True, attn_key=["mid", 0, 0, 0], save_attn_to_dict=d)
+    q = (x @ sd[f"{name}.to_q.weight"].to(dev).t()).reshape(2, 16, 8, 32).permute(0, 2, 1, 3)
+    k = (ctx @ sd[f"{name}.to_k.weight"].to(dev).t()).reshape(2, 77, 8, 32).permute(0, 2, 1, 3)
+    v = (ctx @ sd[f"{name}.to_v.weight"].to(dev).t()).reshape(2, 77, 8, 32).permute(0, 2, 1, 3)
+    pr = (q @ k.transpose(-1, -2) * 32 ** -0.5).softmax(-1)
+    o = (pr @ v).permute(0, 2, 1, 3).reshape(2, 16, 256) @ sd[f"{name}.to_out.0.weight"].to(dev).t() + sd[f"{name}.to_out.0.bias"].to(dev)
+    assert relerr(p, pr) < 2e-2 and relerr(y, o) < 2e-2 and ("mid", 0, 0, 0) in d
+
+
+def test_pipelines_generate_partial_frozen_signature(dropin, dev):
+    """models.pipelines.generate_partial_frozen with the reference's positional signature."""
+    import lgd_amd  # noqa: F401
+    from lgd_amd import weights
+    import models
+    from models import pipelines
+    cfg = weights.CONFIGS["tiny"]
+    md = models.build_model_dict(cfg, weights.synth_state_dict(cfg, 0))
+    g = np.load(os.path.join(GOLD, "loops_tiny.npz"))
+    ehs = torch.from_numpy(g["ehs"])
+    sg = dict(loss_scale=5, loss_threshold=0.0, max_iter=[2, 1], max_index_step=2, use_ratio_based_loss=False,
+              guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0, verbose=False)
+    lat, images = pipelines.generate_partial_frozen(md, torch.from_numpy(g["lat_all_in"]), torch.from_numpy(g["frozen_mask"]),
+                                                    (ehs, ehs[:1], ehs[1:]), 4, 2, bboxes=BBOXES, phrases=["a", "b"],
+                                                    object_positions=OBJ_POS, semantic_guidance_kwargs=sg)
+    assert images is None and relerr(lat, g["partial_frozen_out"]) < 5e-2
