@@ -1,0 +1,71 @@
+"""CPU suite: the N>1 path (one process per GPU in production) with world_size-2 gloo processes:
+rank 0 packs the weights, the two arenas are broadcast, layouts are sharded round-robin with their global
+index preserved (seeds derive from it), and the timing reduction is a max over ranks."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import lgd_amd  # noqa: F401
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from lgd_amd import dist as ldist, weights
+    from lgd_amd.weightstore import WeightStore
+    from lgd_amd.pipeline import CachedLayout
+    ldist.init(backend="gloo")
+    cfg = weights.CONFIGS["tiny_gligen"]
+    ws = WeightStore(cfg, "cpu")
+    if rank == 0:
+        ws.load_state_dict(weights.synth_state_dict(cfg, 0))
+    secs = ldist.broadcast_weights(ws, src=0, chunk_bytes=8 << 20)
+    layouts = [[("a cat", [10 * i, 20, 100, 120]), ("a dog", [300, 40 + i, 90, 100])] for i in range(7)]
+    mine = ldist.shard(layouts)
+    lays = [CachedLayout.synthetic(cfg, gb, index=i) for i, gb in mine]
+    t = ldist.max_over_ranks(1.0 + rank)
+    total = ldist.sum_over_ranks(float(len(mine)))
+    torch.save(dict(sum16=float(ws.arena16.float().abs().sum()), sum32=float(ws.arena32.abs().sum()),
+                    gate=ws.scalars.get("mid_block.attentions.0.transformer_blocks.0.fuser.alpha_attn"),
+                    idx=[i for i, _ in mine], seeds=[(l.bg_seed, l.fg_seed_start) for l in lays],
+                    noise0=lays[0].overall_cond[0, 0, :4].tolist(), t=t, total=total, secs=secs),
+               os.path.join(out_dir, f"r{rank}.pt"))
+    ldist.barrier()
+    dist.destroy_process_group()
+
+
+def test_weight_broadcast_and_layout_sharding_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world))
+    # identical replicas after the broadcast (rank 1 never saw a state dict)
+    assert r0["sum16"] == r1["sum16"] > 0 and r0["sum32"] == r1["sum32"] > 0
+    assert abs(r0["gate"] - 0.7615941762924194) < 1e-6 and r0["gate"] == r1["gate"]
+    # disjoint, complete, index-preserving partition; seeds follow the GLOBAL index (generate.py:226-229)
+    assert r0["idx"] == [0, 2, 4, 6] and r1["idx"] == [1, 3, 5]
+    assert r1["seeds"][0] == (1, 1 + 123456789)
+    assert r0["t"] == r1["t"] == 2.0 and r0["total"] == r1["total"] == 7.0
+
+
+def test_per_item_results_do_not_depend_on_partition():
+    """A layout's synthetic text side and seeds depend only on its global index, so the 1-rank and
+    2-rank runs produce the same per-prompt inputs (byte-identical)."""
+    from lgd_amd import dist as ldist, weights
+    from lgd_amd.pipeline import CachedLayout
+    cfg = weights.CONFIGS["tiny"]
+    layouts = [[("a cat", [10 * i, 20, 100, 120])] for i in range(5)]
+    single = {i: CachedLayout.synthetic(cfg, gb, index=i) for i, gb in ldist.shard(layouts, 0, 1)}
+    for r in range(2):
+        for i, gb in ldist.shard(layouts, r, 2):
+            lay = CachedLayout.synthetic(cfg, gb, index=i)
+            assert torch.equal(lay.overall_cond, single[i].overall_cond) and lay.bg_seed == single[i].bg_seed
