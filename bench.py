@@ -107,7 +107,7 @@ def main():
 
     import lgd_amd  # noqa: F401
     from lgd_amd import dist as ldist, ops, weights
-    from lgd_amd.pipeline import CachedLayout, lmd_plus_generate
+    from lgd_amd.pipeline import CachedLayout, lmd_plus_generate_batch
     from lgd_amd.sampler import LMDSampler
     from lgd_amd.scheduler import DDIMScheduler
     from lgd_amd.unet import UNetEngine
@@ -129,11 +129,8 @@ def main():
     T = args.num_inference_steps
 
     def one_step():
-        it = 0
-        for lay in lays:
-            out = lmd_plus_generate(sm, lay, num_inference_steps=T, decode=not args.no_decode)
-            it += out["guidance_iters"]
-        return it
+        outs = lmd_plus_generate_batch(sm, lays, num_inference_steps=T, decode=not args.no_decode)
+        return sum(o["guidance_iters"] for o in outs)
 
     for _ in range(args.warmup):
         one_step()
@@ -156,11 +153,17 @@ def main():
     # launched eagerly on the same stream with HIP events around every GEMM/attention launch, and the
     # per-pass times are weighted by how often the timed region ran each pass.
     n_box = 2
-    weights_of = {"main_fuser_on": (n_box + 1) * int(0.4 * T), "main_fuser_off": (n_box + 1) * (T - int(0.4 * T)),
-                  "guide_fuser_on": it_per_image * 55.0 / 65.0, "guide_fuser_off": it_per_image * 10.0 / 65.0}
+    nl = args.layouts
+    n_on = int(0.4 * T)
+    # launches of each pass per timed step: stage A = one batched call over nl*n_box boxes, stage B = one
+    # batched call over nl layouts + its guidance iterations (the batch iterates until its slowest image exits)
+    per_step = {("main", True, nl * n_box): n_on, ("main", False, nl * n_box): T - n_on,
+                ("main", True, nl): n_on, ("main", False, nl): T - n_on,
+                ("guide", True, nl): it_per_image * 55.0 / 65.0, ("guide", False, nl): it_per_image * 10.0 / 65.0}
     agg = {}
     reps = 3
-    for name, fn in sm.profile_passes(64, T, cfg.use_gated_attention):
+    for kind, fz, nb_, fn in sm.profile_passes(64, T, cfg.use_gated_attention, main_batches=sorted({nl * n_box, nl}),
+                                               guide_batches=(nl,)):
         fn()
         torch.cuda.synchronize()
         prof = ops.LaunchProfiler()
@@ -168,9 +171,9 @@ def main():
         for _ in range(reps):
             fn()
         ops.PROFILER = None
+        w = per_step.get((kind, fz, nb_), 0.0) / reps / nl          # per image
         for k, v in prof.summary().items():
             a = agg.setdefault(k, dict(ms=0.0, flops=0.0, n=0.0, raw_ms=0.0, raw_n=0))
-            w = weights_of.get(name, 0.0) / reps
             a["ms"] += v["ms"] * w
             a["flops"] += v["flops"] * w
             a["n"] += v["n"] * w

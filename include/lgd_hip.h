@@ -188,9 +188,11 @@ int lgd_upsample2x_bwd_f16(const void* gy, void* gx, int B, int H, int W, int C,
 int lgd_cfg_ddim_step_f32(const float* eps, const float* x, float* x_out, const float* coef_table,
                           const int32_t* dyn, const float* frozen_ref, const float* mask, float* hist,
                           int B, int C, int HW, void* stream);
-/* guidance latent update (pipelines.py:60-69): x -= coef_table[*step_idx][col] * g */
+/* guidance latent update (pipelines.py:60-69): x -= active[i/per_sample] * coef_table[*step_idx][col] * g.
+ * active (device fp32 per image, or NULL = all on) emulates the per-image `while` exit of
+ * pipelines.py:30 when several layouts are guided in one batch. */
 int lgd_axpy_f32(const float* g, float* x, const float* coef_table, const int32_t* step_idx, int col,
-                 int64_t n, void* stream);
+                 const float* active, int64_t per_sample, int64_t n, void* stream);
 /* copy row `*idx` (device int32) of a [T][n] fp32 table into out[n] — per-step time-embedding
  * bias of every resnet without changing any kernel argument (graph-replay friendly). */
 int lgd_select_row_f32(const float* table, const int32_t* idx, float* out, int n, void* stream);
@@ -200,9 +202,10 @@ int lgd_select_row_f32(const float* table, const int32_t* idx, float* out, int n
  * all (key, object, token, head) items: utils/guidance.py:91-148 (max-based fg/bg top-k box loss),
  * :150-242 (reference-attention L1 transfer), :244-286 (compute_ca_lossv3), times loss_scale
  * (pipelines.py:48).
- *   items: int32 [n_items][8] = {map_id, kind(0 topk, 1 ref), token, mask_id, k_fg, k_bg, ref_id, 0}
+ *   items: int32 [n_items][8] = {map_id, kind(0 topk, 1 ref), token, mask_id, k_fg, k_bg, ref_id, image}
  *   coefs: fp32  [n_items][4] = {fg_coef, bg_coef, ref_coef, 0} (all normalisations folded in)
- *   maps:  device array of n_maps pointers to fp32 [H][HW][T]; gmaps likewise (pre-zeroed) or NULL
+ *   maps:  device array of n_maps pointers to fp32 [n_samples][H][HW][T]; gmaps likewise (pre-zeroed)
+ *          or NULL; loss: fp32 [n_samples] (one value per image of the batch)
  *   map_hw: int32[n_maps]; masks: fp32 [n_masks][max_hw] (1 inside the box); refs: fp32
  *   [T][n_refs][H][max_hw] reference maps R_b (guidance.py:201); the slice of step dyn[0] (device
  *   int32) is used: refs + dyn[0]*refs_step_stride
@@ -212,8 +215,8 @@ int lgd_select_row_f32(const float* table, const int32_t* idx, float* out, int n
  * ------------------------------------------------------------------------------------------- */
 int lgd_ca_energy_f32(const float* const* maps, float* const* gmaps, const int32_t* map_hw,
                       const int32_t* items, const float* coefs, const float* masks, const float* refs,
-                      int64_t refs_step_stride, const int32_t* dyn, int n_items, int H, int T,
-                      int max_hw, float grad_scale, float* partial, float* loss, void* stream);
+                      int64_t refs_step_stride, const int32_t* dyn, int n_items, int n_samples, int H,
+                      int T, int max_hw, float grad_scale, float* partial, float* loss, void* stream);
 
 #ifdef __cplusplus
 }

@@ -68,9 +68,9 @@ SIGNATURES = {
     "lgd_scale_f16": [_P, _P, _F, _L, _P],
     "lgd_upsample2x_bwd_f16": [_P, _P, _I, _I, _I, _I, _P],
     "lgd_cfg_ddim_step_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "lgd_axpy_f32": [_P, _P, _P, _P, _I, _L, _P],
+    "lgd_axpy_f32": [_P, _P, _P, _P, _I, _P, _L, _L, _P],
     "lgd_select_row_f32": [_P, _P, _P, _I, _P],
-    "lgd_ca_energy_f32": [_P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _P, _P, _P],
+    "lgd_ca_energy_f32": [_P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P],
 }
 
 _lib = None

@@ -30,11 +30,13 @@ __global__ __launch_bounds__(256) void ca_energy_kernel(
   const int h = blockIdx.x, item = blockIdx.y;
   const int32_t* it = items + item * 8;
   const int map_id = it[0], kind = it[1], tok = it[2], mask_id = it[3];
-  const int k_fg = it[4], k_bg = it[5], ref_id = it[6];
+  const int k_fg = it[4], k_bg = it[5], ref_id = it[6], smp = it[7];
   const float c_fg = coefs[item * 4 + 0], c_bg = coefs[item * 4 + 1], c_ref = coefs[item * 4 + 2];
   const int HW = map_hw[map_id];
-  const float* A = maps[map_id] + (long)h * HW * T + tok;
-  float* G = gmaps ? gmaps[map_id] + (long)h * HW * T + tok : nullptr;
+  // maps are [n_samples][H][HW][T]; item `smp` selects the image of the batch
+  const long img = ((long)smp * H + h) * HW * T + tok;
+  const float* A = maps[map_id] + img;
+  float* G = gmaps ? gmaps[map_id] + img : nullptr;
   const float* M = masks + (long)mask_id * max_hw;
   const int tid = threadIdx.x;
 
@@ -102,13 +104,17 @@ __global__ __launch_bounds__(256) void ca_energy_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void energy_sum_kernel(const float* __restrict__ partial, int n,
-                                                          float* __restrict__ loss) {
+// loss[b] = sum of the partial terms of the items that belong to image b (grid = n_samples)
+__global__ __launch_bounds__(256) void energy_sum_kernel(const float* __restrict__ partial,
+                                                          const int32_t* __restrict__ items, int n_items,
+                                                          int H, float* __restrict__ loss) {
   __shared__ float s_red[4];
+  const int b = blockIdx.x;
   float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  for (int i = threadIdx.x; i < n_items * H; i += 256)
+    if (items[(i / H) * 8 + 7] == b) s += partial[i];
   s = block_sum_256(s, s_red);
-  if (threadIdx.x == 0) loss[0] = s;
+  if (threadIdx.x == 0) loss[b] = s;
 }
 
 }  // namespace
@@ -116,15 +122,17 @@ __global__ __launch_bounds__(256) void energy_sum_kernel(const float* __restrict
 extern "C" int lgd_ca_energy_f32(const float* const* maps, float* const* gmaps,
                                  const int32_t* map_hw, const int32_t* items, const float* coefs,
                                  const float* masks, const float* refs, int64_t refs_step_stride,
-                                 const int32_t* dyn, int n_items, int H, int T, int max_hw,
-                                 float grad_scale, float* partial, float* loss, void* stream) {
+                                 const int32_t* dyn, int n_items, int n_samples, int H, int T,
+                                 int max_hw, float grad_scale, float* partial, float* loss,
+                                 void* stream) {
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  if (n_items < 0 || H < 1 || max_hw > E_MAXHW) return LGD_ERR_ARG;
+  if (n_items < 0 || n_samples < 1 || H < 1 || max_hw > E_MAXHW) return LGD_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (n_items > 0)
     hipLaunchKernelGGL(ca_energy_kernel, dim3(H, n_items), dim3(256), 0, st, maps, gmaps, map_hw,
                        items, coefs, masks, refs, (long)refs_step_stride, dyn, H, T, max_hw,
                        grad_scale, partial);
-  hipLaunchKernelGGL(energy_sum_kernel, dim3(1), dim3(256), 0, st, partial, n_items * H, loss);
+  hipLaunchKernelGGL(energy_sum_kernel, dim3(n_samples), dim3(256), 0, st, partial, items, n_items, H,
+                     loss);
   return lgd_check_launch();
 }

@@ -275,9 +275,13 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(
 __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ g, float* __restrict__ x,
                                                     const float* __restrict__ coef_table,
                                                     const int32_t* __restrict__ step_idx, int col,
+                                                    const float* __restrict__ active, long per_sample,
                                                     long n) {
   const float s = coef_table[(*step_idx) * 4 + col];
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) x[i] -= s * g[i];
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    const float a = active ? active[i / per_sample] : 1.f;   // per-image on/off (batched guidance)
+    x[i] -= a * s * g[i];
+  }
 }
 
 __global__ __launch_bounds__(256) void select_row_kernel(const float* __restrict__ table,
@@ -396,10 +400,12 @@ extern "C" int lgd_cfg_ddim_step_f32(const float* eps, const float* x, float* x_
 }
 
 extern "C" int lgd_axpy_f32(const float* g, float* x, const float* coef_table,
-                            const int32_t* step_idx, int col, int64_t n, void* stream) {
+                            const int32_t* step_idx, int col, const float* active, int64_t per_sample,
+                            int64_t n, void* stream) {
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(n)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), g, x, coef_table, step_idx, col, (long)n);
+                     reinterpret_cast<hipStream_t>(stream), g, x, coef_table, step_idx, col, active,
+                     (long)(per_sample > 0 ? per_sample : n), (long)n);
   return lgd_check_launch();
 }
 

@@ -39,6 +39,7 @@ class EnergyTables:
         self.heads, self.T = heads, text_len
         self.n_obj = len(bboxes)
         self.max_hw = max([map_hw[k] for k in self.keys] + [1])
+        self._map_hw = dict(map_hw)
         n_keys = len(self.keys)
         items, coefs, masks = [], [], []
         self.ref_slots: List[Tuple[int, int, int]] = []     # (obj, box, key index) per ref_id
@@ -82,16 +83,57 @@ class EnergyTables:
                             items.append([ki, 1, int(p), mid, 1, 1, rid, 0])
                             coefs.append([0.0, 0.0, loss_scale * ref_ca_loss_weight /
                                           (heads * len(obj_boxes) * len(toks) * denom), 0.0])
+        self._host = (items, coefs, masks)
+        self.n_samples = 1
+        self._refs_host = None
+        self._finalize()
+
+    def _finalize(self):
+        items, coefs, masks = self._host
+        device, heads = self.device, self.heads
         self.n_items = len(items)
         self.items = torch.tensor(items if items else [[0] * 8], dtype=torch.int32, device=device)
         self.coefs = torch.tensor(coefs if coefs else [[0.0] * 4], dtype=F32, device=device)
         self.masks = (torch.stack(masks) if masks else torch.zeros(1, self.max_hw)).to(device, F32).contiguous()
-        self.map_hw = torch.tensor([map_hw[k] for k in self.keys] or [1], dtype=torch.int32, device=device)
+        self.map_hw = torch.tensor([self._map_hw[k] for k in self.keys] or [1], dtype=torch.int32, device=device)
         self.partial = torch.zeros(max(self.n_items * heads, 1), dtype=F32, device=device)
-        self.loss = torch.zeros(1, dtype=F32, device=device)
+        self.loss = torch.zeros(self.n_samples, dtype=F32, device=device)
         self.n_refs = len(self.ref_slots)
         self.refs = None        # fp32 [T][n_refs][heads][max_hw], filled by set_refs
         self._ptrs = None
+
+    @classmethod
+    def merged(cls, tables: "List[Optional[EnergyTables]]") -> "EnergyTables":
+        """One table for a batch of images: image b's items carry sample index b (items[7]) and the
+        kernel returns one loss per image.  `None` entries are images without guidance."""
+        first = next(t for t in tables if t is not None)
+        m = cls.__new__(cls)
+        m.device, m.keys, m.heads, m.T, m.max_hw, m._map_hw = (first.device, first.keys, first.heads, first.T,
+                                                                first.max_hw, first._map_hw)
+        items, coefs, masks, m.ref_slots, refs = [], [], [], [], []
+        for b, t in enumerate(tables):
+            if t is None:
+                continue
+            assert t.keys == m.keys and t.max_hw == m.max_hw
+            it, co, ma = t._host
+            for row in it:
+                r = list(row)
+                r[3] += len(masks)
+                r[6] += len(m.ref_slots) if r[1] == 1 else 0
+                r[7] = b
+                items.append(r)
+            coefs += co
+            masks += ma
+            m.ref_slots += t.ref_slots
+            if t.refs is not None:
+                refs.append(t.refs)
+        m.n_obj = sum(t.n_obj for t in tables if t is not None)
+        m._host = (items, coefs, masks)
+        m.n_samples = len(tables)
+        m._finalize()
+        if refs:
+            m.set_refs(torch.cat(refs, dim=1))
+        return m
 
     def bind(self, maps: Dict[Tuple, torch.Tensor], gmaps: Optional[Dict[Tuple, torch.Tensor]]):
         """Device pointer tables to the (static) map / map-gradient buffers of a guidance plan."""
@@ -117,5 +159,5 @@ class EnergyTables:
         stride = self.refs[0].numel() if self.refs is not None else 0
         ops.ca_energy(mp, gp if with_grad else None, self.map_hw, self.items, self.coefs, self.masks,
                       self.refs, stride, dyn, self.n_items, self.heads, self.T, self.max_hw, self.partial,
-                      self.loss, grad_scale=grad_scale)
+                      self.loss, grad_scale=grad_scale, n_samples=self.n_samples)
         return self.loss

@@ -412,8 +412,10 @@ def cfg_ddim_step(eps, x, x_out, coef_table, dyn, *, frozen_ref=None, mask=None,
     return x_out
 
 
-def axpy(g, x, coef_table, step_idx, col):
-    _call("lgd_axpy_f32", _p(g), _p(x), _p(coef_table), _p(step_idx), int(col), x.numel(), _stream())
+def axpy(g, x, coef_table, step_idx, col, active=None):
+    per = x.numel() // x.shape[0] if active is not None else 0
+    _call("lgd_axpy_f32", _p(g), _p(x), _p(coef_table), _p(step_idx), int(col), _p(active), per, x.numel(),
+          _stream())
 
 
 def select_row(table, idx, out):
@@ -421,7 +423,7 @@ def select_row(table, idx, out):
 
 
 def ca_energy(map_ptrs, gmap_ptrs, map_hw, items, coefs, masks, refs, refs_step_stride, dyn, n_items,
-              H, T, max_hw, partial, loss, grad_scale=1.0):
+              H, T, max_hw, partial, loss, grad_scale=1.0, n_samples=1):
     _call("lgd_ca_energy_f32", _p(map_ptrs), _p(gmap_ptrs), _p(map_hw), _p(items), _p(coefs),
-          _p(masks), _p(refs), int(refs_step_stride), _p(dyn), n_items, H, T, max_hw, float(grad_scale),
-          _p(partial), _p(loss), _stream())
+          _p(masks), _p(refs), int(refs_step_stride), _p(dyn), n_items, n_samples, H, T, max_hw,
+          float(grad_scale), _p(partial), _p(loss), _stream())

@@ -14,7 +14,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .sampler import DEFAULT_GUIDANCE_ATTN_KEYS, LMDSampler, prepare_gligen_condition
+from .sampler import DEFAULT_GUIDANCE_ATTN_KEYS, Job, LMDSampler, prepare_gligen_condition
 from .weights import UNetConfig
 
 F32 = torch.float32
@@ -94,61 +94,82 @@ def _ref_maps(sampler: LMDSampler, saved_list, keys, L, T):
     return out
 
 
-def lmd_plus_generate(sampler: LMDSampler, lay: CachedLayout, *, num_inference_steps=50,
-                      frozen_step_ratio=0.5, guidance_scale=7.5, so_gligen_scheduled_sampling_beta=0.4,
-                      overall_gligen_scheduled_sampling_beta=0.4, overall_loss_scale=5,
-                      overall_loss_threshold=5.0, overall_max_iter=None, overall_max_index_step=30,
-                      overall_fg_top_p=0.2, overall_bg_top_p=0.2, overall_fg_weight=1.0,
-                      overall_bg_weight=4.0, ref_ca_loss_weight=2.0, fg_blending_ratio=0.1,
-                      use_ref_ca=True, height=512, width=512, decode=True, guidance_attn_keys=None):
-    """LMD+ for one layout (generation/lmd_plus.py:193-520 with its default arguments; per-box
-    guidance is off there: max_index_step=0, :203)."""
+def lmd_plus_generate(sampler: LMDSampler, lay: CachedLayout, **kw):
+    """LMD+ for one layout (generation/lmd_plus.py:193-520 with its default arguments)."""
+    return lmd_plus_generate_batch(sampler, [lay], **kw)[0]
+
+
+def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, num_inference_steps=50,
+                            frozen_step_ratio=0.5, guidance_scale=7.5, so_gligen_scheduled_sampling_beta=0.4,
+                            overall_gligen_scheduled_sampling_beta=0.4, overall_loss_scale=5,
+                            overall_loss_threshold=5.0, overall_max_iter=None, overall_max_index_step=30,
+                            overall_fg_top_p=0.2, overall_bg_top_p=0.2, overall_fg_weight=1.0,
+                            overall_bg_weight=4.0, ref_ca_loss_weight=2.0, fg_blending_ratio=0.1,
+                            use_ref_ca=True, height=512, width=512, decode=True, guidance_attn_keys=None):
+    """LMD+ (generation/lmd_plus.py:193-520, default arguments; per-box guidance is off there:
+    max_index_step=0, :203) for a batch of independent layouts: the per-box generations of ALL layouts run
+    as one batched denoising call (B = 2 x total boxes), then the overall generations of all layouts as
+    another (B = 2 x layouts; guidance pass B = layouts with a per-image loop exit).  Results per layout
+    are independent of how layouts are batched (images only share kernel launches)."""
     L = height // 8
     T = num_inference_steps
     frozen_steps = int(T * min(max(frozen_step_ratio, 0.0), 1.0))
     keys = [tuple(k) for k in (guidance_attn_keys or DEFAULT_GUIDANCE_ATTN_KEYS)]
     dev = sampler.dev
     C = sampler.eng.cfg.in_channels
-    input_latents, latents_bg = get_input_latents_list(lay.bg_seed, lay.fg_seed_start, lay.boxes,
-                                                       fg_blending_ratio, C, L, L)
-    # ---- stage A: one GLIGEN generation per box (lmd_plus.py:44-145,162-188)
-    latents_all_list, mask_list, saved_list, so_images = [], [], [], []
+    prep = [get_input_latents_list(lay.bg_seed, lay.fg_seed_start, lay.boxes, fg_blending_ratio, C, L, L)
+            for lay in lays]
+    # ---- stage A: one GLIGEN generation per box (lmd_plus.py:44-145,162-188), all boxes batched
+    jobs, owner = [], []
     if use_ref_ca or frozen_steps > 0:
-        for i, box in enumerate(lay.boxes):
-            text = torch.cat([lay.so_uncond, lay.so_cond[i:i + 1]])
-            gl = prepare_gligen_condition([list(box)], lay.phrase_embeddings[i:i + 1], dev)
-            r = sampler.denoise(input_latents[i], text, T, guidance_scale=guidance_scale, gligen=gl,
-                                gligen_scheduled_sampling_beta=so_gligen_scheduled_sampling_beta,
-                                saved_cross_attn_keys=[OBJ_ATTN_KEY, *keys] if use_ref_ca else [OBJ_ATTN_KEY],
-                                return_cond_ca_only=True, return_token_ca_only=lay.so_word_token_index[i])
-            if decode:
-                so_images.append(sampler.decode(r["latents"]))       # feeds SAM in the reference
-            latents_all_list.append(r["latents_all"])
-            saved_list.append(r["saved"])
-            mask_list.append(proportion_to_mask(box, L, L).bool())  # SAM stand-in (SURVEY.md §8d)
-    # ---- composition (lmd_plus.py:398-416)
-    composed, fg_idx = compose_latents(latents_all_list, mask_list, T, latents_bg.to(dev))
-    # ---- stage B: overall generation with attention guidance (lmd_plus.py:440-511)
-    overall_bboxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
-    flat = [i for grp in lay.overall_groups for i in grp]
-    guid = None
-    if overall_bboxes:
-        guid = dict(bboxes=overall_bboxes, object_positions=lay.overall_object_positions,
-                    loss_scale=overall_loss_scale, loss_threshold=overall_loss_threshold,
-                    max_iter=overall_max_iter or DEFAULT_MAX_ITER, max_index_step=overall_max_index_step,
-                    fg_top_p=overall_fg_top_p, bg_top_p=overall_bg_top_p, fg_weight=overall_fg_weight,
-                    bg_weight=overall_bg_weight, ref_ca_word_token_only=True, ref_ca_last_token_only=True,
-                    word_token_indices=lay.overall_word_token_indices, ref_ca_loss_weight=ref_ca_loss_weight,
-                    guidance_attn_keys=keys,
-                    ref_maps=_ref_maps(sampler, [saved_list[i] for i in flat], keys, L, T) if use_ref_ca else None)
-    gl = prepare_gligen_condition([list(lay.boxes[i]) for i in flat], lay.phrase_embeddings[flat], dev)
-    text = torch.cat([lay.overall_uncond, lay.overall_cond])
-    r = sampler.denoise(composed, text, T, guidance_scale=guidance_scale, gligen=gl,
-                        gligen_scheduled_sampling_beta=overall_gligen_scheduled_sampling_beta, guidance=guid,
-                        frozen_steps=frozen_steps, frozen_mask=(fg_idx != 0), save_all_latents=False)
-    image = sampler.decode(r["latents"])[0] if decode else None
-    return dict(image=image, latents=r["latents"], so_images=so_images, guidance_iters=r["guidance_iters"],
-                composed=composed, fg_idx=fg_idx)
+        for li, lay in enumerate(lays):
+            for i, box in enumerate(lay.boxes):
+                jobs.append(Job(prep[li][0][i], torch.cat([lay.so_uncond, lay.so_cond[i:i + 1]]),
+                                gligen=prepare_gligen_condition([list(box)], lay.phrase_embeddings[i:i + 1], dev),
+                                token=lay.so_word_token_index[i]))
+                owner.append((li, i))
+    res_a = sampler.denoise_batch(jobs, T, guidance_scale=guidance_scale, use_gligen=True,
+                                  gligen_scheduled_sampling_beta=so_gligen_scheduled_sampling_beta,
+                                  saved_cross_attn_keys=[OBJ_ATTN_KEY, *keys] if use_ref_ca else [OBJ_ATTN_KEY],
+                                  return_cond_ca_only=True) if jobs else []
+    per_lay = [dict(latents_all=[], masks=[], saved=[], so_images=[]) for _ in lays]
+    if decode and res_a:
+        imgs = sampler.decode(torch.cat([r["latents"] for r in res_a]))      # feeds SAM in the reference
+    for n, ((li, i), r) in enumerate(zip(owner, res_a)):
+        d = per_lay[li]
+        d["latents_all"].append(r["latents_all"])
+        d["saved"].append(r["saved"])
+        d["masks"].append(proportion_to_mask(lays[li].boxes[i], L, L).bool())   # SAM stand-in (SURVEY.md §8d)
+        if decode:
+            d["so_images"].append(imgs[n:n + 1])
+    # ---- composition (lmd_plus.py:398-416) and stage B: overall generation with attention guidance
+    jobs_b, comps = [], []
+    for li, lay in enumerate(lays):
+        d = per_lay[li]
+        composed, fg_idx = compose_latents(d["latents_all"], d["masks"], T, prep[li][1].to(dev))
+        comps.append((composed, fg_idx))
+        overall_bboxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
+        flat = [i for grp in lay.overall_groups for i in grp]
+        guid = None
+        if overall_bboxes:
+            guid = dict(bboxes=overall_bboxes, object_positions=lay.overall_object_positions,
+                        loss_scale=overall_loss_scale, loss_threshold=overall_loss_threshold,
+                        max_iter=overall_max_iter or DEFAULT_MAX_ITER, max_index_step=overall_max_index_step,
+                        fg_top_p=overall_fg_top_p, bg_top_p=overall_bg_top_p, fg_weight=overall_fg_weight,
+                        bg_weight=overall_bg_weight, ref_ca_word_token_only=True, ref_ca_last_token_only=True,
+                        word_token_indices=lay.overall_word_token_indices, ref_ca_loss_weight=ref_ca_loss_weight,
+                        guidance_attn_keys=keys,
+                        ref_maps=_ref_maps(sampler, [d["saved"][i] for i in flat], keys, L, T) if use_ref_ca else None)
+        gl = prepare_gligen_condition([list(lay.boxes[i]) for i in flat], lay.phrase_embeddings[flat], dev)
+        jobs_b.append(Job(composed, torch.cat([lay.overall_uncond, lay.overall_cond]), gligen=gl, guidance=guid,
+                          frozen_mask=(fg_idx != 0)))
+    res_b = sampler.denoise_batch(jobs_b, T, guidance_scale=guidance_scale, use_gligen=True,
+                                  gligen_scheduled_sampling_beta=overall_gligen_scheduled_sampling_beta,
+                                  frozen_steps=frozen_steps, save_all_latents=False)
+    images = sampler.decode(torch.cat([r["latents"] for r in res_b])) if decode else [None] * len(lays)
+    return [dict(image=images[li], latents=res_b[li]["latents"], so_images=per_lay[li]["so_images"],
+                 guidance_iters=res_b[li]["guidance_iters"], composed=comps[li][0], fg_idx=comps[li][1])
+            for li in range(len(lays))]
 
 
 def lmd_generate(sampler: LMDSampler, lay: CachedLayout, *, num_inference_steps=50, frozen_step_ratio=0.4,

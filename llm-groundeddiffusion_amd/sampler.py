@@ -45,21 +45,14 @@ def prepare_gligen_condition(bboxes, phrase_embeddings, device, positive_len=768
 
 
 class GuidanceState:
-    """Everything the guidance inner loop needs for one layout."""
+    """Everything the guidance inner loop needs for one image (layout)."""
 
     def __init__(self, energy: EnergyTables, loss_scale, loss_threshold, max_iter, max_index_step):
         self.energy = energy
         self.loss_scale, self.loss_threshold = float(loss_scale), float(loss_threshold)
         self.max_iter, self.max_index_step = max_iter, int(max_index_step)
-        self.loss = 10000.0             # pipelines.py:161,375,552
-        self.loss_dev = None            # device scalar of the last launched energy, read lazily
+        self.loss = 10000.0             # carried across steps; pipelines.py:161,375,552
         self.iterations = 0
-
-    def current_loss(self) -> float:
-        if self.loss_dev is not None:
-            self.loss = float(self.loss_dev.item())     # host sync, as pipelines.py:30
-            self.loss_dev = None
-        return self.loss
 
     def iters_at(self, index):
         m = self.max_iter
@@ -91,16 +84,25 @@ class HipGraph:
 
 
 class _State:
-    """Persistent device buffers of one (latent shape, step count): fixed addresses for the graphs."""
+    """Persistent device buffers of one (batch, latent shape, step count): fixed addresses for the graphs."""
 
-    def __init__(self, dev, C, L, T):
-        self.lat = torch.zeros((1, C, L, L), device=dev, dtype=F32)
-        self.hist = torch.zeros((T + 1, 1, C, L, L), device=dev, dtype=F32)
-        self.frozen_ref = torch.zeros((T + 1, 1, C, L, L), device=dev, dtype=F32)
-        self.mask = torch.zeros((1, L * L), device=dev, dtype=F32)
+    def __init__(self, dev, nb, C, L, T):
+        self.lat = torch.zeros((nb, C, L, L), device=dev, dtype=F32)
+        self.hist = torch.zeros((T + 1, nb, C, L, L), device=dev, dtype=F32)
+        self.frozen_ref = torch.zeros((T + 1, nb, C, L, L), device=dev, dtype=F32)
+        self.mask = torch.zeros((nb, L * L), device=dev, dtype=F32)
+        self.active = torch.zeros(nb, device=dev, dtype=F32)      # per-image guidance on/off
         self.ctab = torch.zeros((T, 4), device=dev, dtype=F32)
         self.gtab = torch.zeros((T, 4), device=dev, dtype=F32)
         self.graphs = {}
+
+
+class Job:
+    """One image of a batched denoising call."""
+
+    def __init__(self, latents, text, gligen=None, guidance=None, frozen_mask=None, token=None):
+        self.latents, self.text, self.gligen = latents, text, gligen
+        self.guidance, self.frozen_mask, self.token = guidance, frozen_mask, token
 
 
 class LMDSampler:
@@ -151,10 +153,10 @@ class LMDSampler:
         return GuidanceState(en, loss_scale, loss_threshold, max_iter, max_index_step)
 
     # ------------------------------------------------------------------------------------------
-    def _state(self, C, L, T) -> _State:
-        key = (C, L, T)
+    def _state(self, nb, C, L, T) -> _State:
+        key = (nb, C, L, T)
         if key not in self._states:
-            self._states[key] = _State(self.dev, C, L, T)
+            self._states[key] = _State(self.dev, nb, C, L, T)
         return self._states[key]
 
     def _runner(self, st: _State, name, fn):
@@ -165,113 +167,131 @@ class LMDSampler:
             st.graphs[name] = HipGraph(fn)
         return st.graphs[name]
 
-    def backward_guidance(self, gs: GuidanceState, plan_g, index: int, st: _State, fwd_run, bwd_run,
-                          trace: Optional[list] = None):
-        """latent_backward_guidance (pipelines.py:16-82) on the persistent latent buffer st.lat."""
-        if gs is None or index >= gs.max_index_step:
-            return
-        en = gs.energy
-        max_it = gs.iters_at(index)
+    def _guide_runners(self, st: _State, nb: int, L: int, fuser: bool, gkeys):
+        """(plan, forward runner, backward+update runner) of the guidance pass for a batch of nb images:
+        B=nb grad plan on the conditional text (second half of the text batch) and the zero-masked GLIGEN
+        half (pipelines.py:381-384)."""
+        eng = self.eng
+        pg = eng.plan(nb, L, grad=True, fuser=fuser, stop_key=gkeys[-1], save_keys=gkeys,
+                      text_batch_offset=nb, obj_batch_offset=0)
+
+        def g_fwd():
+            pg.forward(st.lat)
+
+        def g_bwd():
+            grad = pg.backward(self.grad_scale)
+            ops.axpy(grad, st.lat, st.gtab, eng.dyn, 0, active=st.active)       # pipelines.py:62-69
+        name = ("guide", fuser, tuple(gkeys))
+        return pg, self._runner(st, name + ("fwd",), g_fwd), self._runner(st, name + ("bwd",), g_bwd)
+
+    def backward_guidance(self, states: List[Optional[GuidanceState]], energy: EnergyTables, plan_g, index: int,
+                          st: _State, fwd_run, bwd_run, trace: Optional[list] = None):
+        """latent_backward_guidance (pipelines.py:16-82) for a batch of images on st.lat.  Each image keeps
+        its own `while loss/scale > thr and it < max_iter` exit: an image that left the loop is masked out of
+        the latent update (st.active) and its carried loss is not refreshed."""
+        nb = len(states)
+        energy.bind(plan_g.maps, plan_g.gmaps)
         it = 0
-        en.bind(plan_g.maps, plan_g.gmaps)
-        while it < max_it and gs.current_loss() / gs.loss_scale > gs.loss_threshold:
+        while True:
+            act = [gs is not None and index < gs.max_index_step and it < gs.iters_at(index)
+                   and gs.loss / gs.loss_scale > gs.loss_threshold for gs in states]
+            if not any(act):
+                break
+            st.active.copy_(torch.tensor([1.0 if a else 0.0 for a in act]))
             fwd_run()                                               # grad-plan forward from st.lat
-            gs.loss_dev = en.run(self.eng.dyn, grad_scale=self.grad_scale)
-            bwd_run()                                               # backward + latent update
+            loss_dev = energy.run(self.eng.dyn, grad_scale=self.grad_scale)
+            bwd_run()                                               # backward + masked latent update
+            losses = loss_dev.tolist()                              # host sync, as pipelines.py:30
+            for j, gs in enumerate(states):
+                if act[j]:
+                    gs.loss = losses[j]
+                    gs.iterations += 1
+                    self.stats["guidance_iters"] += 1
             if trace is not None:
-                trace.append(dict(index=index, it=it, loss=float(gs.loss_dev.item()),
+                trace.append(dict(index=index, it=it, loss=losses[0], losses=losses,
                                   grad=plan_g.g_latents.clone()))
             it += 1
-            gs.iterations += 1
-            self.stats["guidance_iters"] += 1
-
-    # ------------------------------------------------------------------------------------------
-    def profile_passes(self, L: int, T: int, gligen: bool, guidance_keys=None):
-        """Eager (non-graph) launch sequences of the plans the sampler replays, for per-kernel HIP-event
-        timing by bench.py: [(name, callable)].  Uses whatever run constants are currently loaded."""
-        eng = self.eng
-        st = self._state(eng.cfg.in_channels, L, T)
-        keys = [tuple(k) for k in (guidance_keys or DEFAULT_GUIDANCE_ATTN_KEYS)]
-        plan_keys = sorted({OBJ_KEY_DEFAULT, *DEFAULT_GUIDANCE_ATTN_KEYS})
-        out = []
-        for f in ([True, False] if gligen else [False]):
-            plan = eng.plan(2, L, fuser=f, save_keys=plan_keys)
-            out.append((f"main_fuser_{'on' if f else 'off'}", plan.forward))
-            pg = eng.plan(1, L, grad=True, fuser=f, stop_key=keys[-1], save_keys=keys, text_batch_offset=1)
-
-            def guide(pg=pg):
-                pg.forward(st.lat)
-                pg.backward(self.grad_scale)
-            out.append((f"guide_fuser_{'on' if f else 'off'}", guide))
-        return out
 
     # ------------------------------------------------------------------------------------------
     def guidance_only(self, latents: torch.Tensor, cond_embeddings: torch.Tensor, num_inference_steps: int,
                       index: int, guidance: dict, *, gligen=None, fuser: bool = False,
                       trace: Optional[list] = None):
         """One latent_backward_guidance call (pipelines.py:16-82) at step `index` of a T-step schedule.
-        Returns (latents, loss) like the reference."""
+        Returns (latents, loss, state) like the reference."""
         eng, sch, dev = self.eng, self.scheduler, self.dev
         _, C, L, _ = latents.shape
         T = num_inference_steps
-        st = self._state(C, L, T)
+        st = self._state(1, C, L, T)
         sch.set_timesteps(T)
         st.gtab.copy_(sch.guidance_step_table(dev))
         g = dict(guidance)
         gkeys = [tuple(k) for k in (g.get("guidance_attn_keys") or DEFAULT_GUIDANCE_ATTN_KEYS)]
         gs = g.pop("state", None) or self.make_guidance(L, g.pop("bboxes"), g.pop("object_positions"), **g)
-        pg = eng.plan(1, L, grad=True, fuser=fuser, stop_key=gkeys[-1], save_keys=gkeys,
-                      text_batch_offset=1, obj_batch_offset=0)
         eng.prepare_timesteps([int(t) for t in sch.timesteps])
         cond = cond_embeddings.to(dev)
         eng.prepare_text(torch.cat([torch.zeros_like(cond), cond]))
+        eng.set_step(index)
+        pg, gf, gb = self._guide_runners(st, 1, L, fuser, gkeys)
         if gligen is not None:
             eng.prepare_gligen(boxes=gligen[0], positive_embeddings=gligen[1], masks=gligen[2])
-        eng.set_step(index)
-
-        def g_fwd():
-            pg.forward(st.lat)
-
-        def g_bwd():
-            ops.axpy(pg.backward(self.grad_scale), st.lat, st.gtab, eng.dyn, 0)
-        name = ("guide", fuser, tuple(gkeys))
-        gf, gb = self._runner(st, name + ("fwd",), g_fwd), self._runner(st, name + ("bwd",), g_bwd)
         st.lat.copy_(latents.to(dev, F32))
         if gs is not None:
-            self.backward_guidance(gs, pg, index, st, gf, gb, trace)
-        return st.lat.clone(), (gs.current_loss() if gs is not None else None), gs
+            self.backward_guidance([gs], gs.energy, pg, index, st, gf, gb, trace)
+        return st.lat.clone(), (gs.loss if gs is not None else None), gs
 
     # ------------------------------------------------------------------------------------------
-    def denoise(self, latents: torch.Tensor, text_embeddings: torch.Tensor, num_inference_steps: int, *,
-                guidance_scale: float = 7.5,
-                gligen: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None,
-                gligen_scheduled_sampling_beta: float = 0.3,
-                guidance: Optional[dict] = None,
-                frozen_steps: int = 0, frozen_mask: Optional[torch.Tensor] = None,
-                saved_cross_attn_keys: Sequence[Tuple] = (), return_cond_ca_only: bool = False,
-                return_token_ca_only: Optional[int] = None, save_all_latents: bool = True,
-                trace: Optional[list] = None):
-        """Generic 50-step loop.
+    def profile_passes(self, L: int, T: int, gligen: bool, main_batches=(1,), guide_batches=(1,), guidance_keys=None):
+        """Eager (non-graph) launch sequences of the plans the sampler replays, for per-kernel HIP-event
+        timing by bench.py: [(kind, fuser, images, callable)].  Uses whatever run constants are loaded."""
+        eng = self.eng
+        keys = [tuple(k) for k in (guidance_keys or DEFAULT_GUIDANCE_ATTN_KEYS)]
+        plan_keys = sorted({OBJ_KEY_DEFAULT, *DEFAULT_GUIDANCE_ATTN_KEYS})
+        out = []
+        for f in ([True, False] if gligen else [False]):
+            for nb in main_batches:
+                out.append(("main", f, nb, eng.plan(2 * nb, L, fuser=f, save_keys=plan_keys).forward))
+            for nb in guide_batches:
+                st = self._state(nb, eng.cfg.in_channels, L, T)
+                pg = eng.plan(nb, L, grad=True, fuser=f, stop_key=keys[-1], save_keys=keys, text_batch_offset=nb)
 
-        latents: (1,C,L,L) start latents or (T+1,1,C,L,L) history whose [0] is the start and whose
+                def guide(pg=pg, st=st):
+                    pg.forward(st.lat)
+                    pg.backward(self.grad_scale)
+                out.append(("guide", f, nb, guide))
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def denoise(self, latents, text_embeddings, num_inference_steps, *, gligen=None, guidance=None,
+                frozen_mask=None, return_token_ca_only=None, **shared):
+        """Single-image form of denoise_batch (same arguments as before)."""
+        job = Job(latents, text_embeddings, gligen, guidance, frozen_mask, return_token_ca_only)
+        return self.denoise_batch([job], num_inference_steps, use_gligen=gligen is not None, **shared)[0]
+
+    def denoise_batch(self, jobs: List[Job], num_inference_steps: int, *, guidance_scale: float = 7.5,
+                      use_gligen: bool = False, gligen_scheduled_sampling_beta: float = 0.3,
+                      frozen_steps: int = 0, saved_cross_attn_keys: Sequence[Tuple] = (),
+                      return_cond_ca_only: bool = False, save_all_latents: bool = True,
+                      trace: Optional[list] = None):
+        """Generic 50-step loop over a batch of independent images (one UNet call serves all of them:
+        B = 2*len(jobs) for the CFG pass, len(jobs) for the guidance pass).
+
+        job.latents: (1,C,L,L) start latents or (T+1,1,C,L,L) history whose [0] is the start and whose
           [i+1] feeds the frozen-mask blend (pipelines.py:340-345, 445-446, 585-586).
-        text_embeddings: (2,77,Cx) = [uncond; cond].
-        gligen: (boxes (2,30,4), embeddings (2,30,768), masks (2,30)) or None.
-        guidance: dict(bboxes, object_positions, **semantic_guidance_kwargs, [ref_maps]) or None.
-        Returns dict(latents, latents_all (T+1,1,C,L,L) device, saved {key: fp32 [T,Bp,H,HW,Tp]},
+        job.text: (2,77,Cx) = [uncond; cond];  job.gligen: (boxes (2,30,4), embeddings (2,30,768), masks (2,30));
+        job.guidance: dict(bboxes, object_positions, **semantic_guidance_kwargs, [ref_maps]) or None;
+        job.token: return_token_ca_only.
+        Returns per job dict(latents (1,C,L,L), latents_all (T+1,1,C,L,L), saved {key: [T,Bp,H,HW,Tp]},
         guidance_iters).
         """
         eng, sch, dev = self.eng, self.scheduler, self.dev
-        latents_all_input = latents if latents.dim() == 5 else None
-        lat0 = latents[0] if latents_all_input is not None else latents
-        B1, C, L, _ = lat0.shape
-        assert B1 == 1
+        nb = len(jobs)
+        starts = [j.latents[0] if j.latents.dim() == 5 else j.latents for j in jobs]
+        _, C, L, _ = starts[0].shape
         T = num_inference_steps
-        st = self._state(C, L, T)
+        st = self._state(nb, C, L, T)
         sch.set_timesteps(T)
         st.ctab.copy_(sch.coef_table(guidance_scale, dev))
         st.gtab.copy_(sch.guidance_step_table(dev))
-        use_gligen = gligen is not None
         n_ground = int(gligen_scheduled_sampling_beta * T) if use_gligen else 0
         save_keys = [tuple(k) for k in saved_cross_attn_keys]
         # a superset of keys is always captured by the main plans so that one graph serves every caller
@@ -279,78 +299,83 @@ class LMDSampler:
 
         def fuser_at(index):
             return bool(use_gligen and index < n_ground)                     # pipelines.py:408-414
-        gs = None
+        gstates: List[Optional[GuidanceState]] = []
         gkeys = None
-        if guidance is not None:
-            g = dict(guidance)
+        for j in jobs:
+            if j.guidance is None:
+                gstates.append(None)
+                continue
+            g = dict(j.guidance)
             gkeys = [tuple(k) for k in (g.get("guidance_attn_keys") or DEFAULT_GUIDANCE_ATTN_KEYS)]
-            gs = self.make_guidance(L, g.pop("bboxes"), g.pop("object_positions"), **g)
-
-        # ---- plans + launch sequences (built/captured once per shape, cached)
-        main_run, guide_run, plans_main, plans_guide = {}, {}, {}, {}
-        for f in {fuser_at(i) for i in range(T)}:
-            plan = plans_main[f] = eng.plan(2, L, fuser=f, save_keys=plan_keys)
-
-            def main_fn(plan=plan):
-                plan.latents_in.copy_(st.lat.expand(2, C, L, L))             # torch.cat([latents]*2)
-                plan.forward()
-                ops.cfg_ddim_step(plan.eps_out, st.lat, st.lat, st.ctab, eng.dyn, frozen_ref=st.frozen_ref,
-                                  mask=st.mask, hist=st.hist)
-            main_run[f] = (main_fn, ("main", f, tuple(plan_keys)))
-        if gs is not None:
-            for f in {fuser_at(i) for i in range(min(gs.max_index_step, T))}:
-                pg = plans_guide[f] = eng.plan(1, L, grad=True, fuser=f, stop_key=gkeys[-1], save_keys=gkeys,
-                                               text_batch_offset=1, obj_batch_offset=0)
-
-                def g_fwd(pg=pg):
-                    pg.forward(st.lat)
-
-                def g_bwd(pg=pg):
-                    grad = pg.backward(self.grad_scale)
-                    ops.axpy(grad, st.lat, st.gtab, eng.dyn, 0)              # pipelines.py:62-69
-                guide_run[f] = (g_fwd, g_bwd, ("guide", f, tuple(gkeys)))
+            gstates.append(self.make_guidance(L, g.pop("bboxes"), g.pop("object_positions"), **g))
+        guided = any(gs is not None for gs in gstates)
+        energy = None
+        if guided:
+            energy = gstates[[gs is not None for gs in gstates].index(True)].energy if nb == 1 else \
+                EnergyTables.merged([gs.energy if gs is not None else None for gs in gstates])
+        max_guided = max([gs.max_index_step for gs in gstates if gs is not None] + [0])
 
         # ---- per-run constants (before graph capture so that warm-up launches see valid inputs)
         eng.prepare_timesteps([int(t) for t in sch.timesteps])
-        eng.prepare_text(text_embeddings)
-        if use_gligen:
-            eng.prepare_gligen(boxes=gligen[0], positive_embeddings=gligen[1], masks=gligen[2])
+        eng.prepare_text(torch.cat([j.text[0:1] for j in jobs] + [j.text[1:2] for j in jobs]))
         eng.set_step(0)
         eng.dyn[1:2].fill_(0)
-        runners_main = {f: self._runner(st, name, fn) for f, (fn, name) in main_run.items()}
-        runners_guide = {f: (self._runner(st, name + ("fwd",), gf), self._runner(st, name + ("bwd",), gb))
-                         for f, (gf, gb, name) in guide_run.items()}
+
+        # ---- plans + launch sequences (built/captured once per shape, cached)
+        runners_main, plans_main, runners_guide = {}, {}, {}
+        for f in {fuser_at(i) for i in range(T)}:
+            plan = plans_main[f] = eng.plan(2 * nb, L, fuser=f, save_keys=plan_keys)
+
+            def main_fn(plan=plan):
+                plan.latents_in[:nb].copy_(st.lat)                           # torch.cat([latents]*2)
+                plan.latents_in[nb:].copy_(st.lat)
+                plan.forward()
+                ops.cfg_ddim_step(plan.eps_out, st.lat, st.lat, st.ctab, eng.dyn, frozen_ref=st.frozen_ref,
+                                  mask=st.mask, hist=st.hist)
+            runners_main[f] = (main_fn, ("main", f, tuple(plan_keys)))
+        if guided:
+            for f in {fuser_at(i) for i in range(min(max_guided, T))}:
+                runners_guide[f] = self._guide_runners(st, nb, L, f, gkeys)
+        if use_gligen:                                                        # after the plans exist
+            eng.prepare_gligen(boxes=torch.cat([j.gligen[0][0:1] for j in jobs] + [j.gligen[0][1:2] for j in jobs]),
+                               positive_embeddings=torch.cat([j.gligen[1][0:1] for j in jobs] +
+                                                             [j.gligen[1][1:2] for j in jobs]),
+                               masks=torch.cat([j.gligen[2][0:1] for j in jobs] + [j.gligen[2][1:2] for j in jobs]))
+        runners_main = {f: self._runner(st, name, fn) for f, (fn, name) in runners_main.items()}
 
         # ---- state of this call
-        st.lat.copy_(lat0.to(dev, F32))
+        st.lat.copy_(torch.cat([s.to(dev, F32) for s in starts]))
         st.hist[0].copy_(st.lat)
-        if frozen_mask is not None and frozen_steps > 0 and latents_all_input is not None:
-            st.frozen_ref.copy_(latents_all_input.to(dev, F32))
-            st.mask.copy_(frozen_mask.to(dev, F32).clamp(0., 1.).reshape(1, L * L))
+        st.mask.zero_()
+        if frozen_steps > 0:
+            for b, j in enumerate(jobs):
+                if j.frozen_mask is not None and j.latents.dim() == 5:
+                    st.frozen_ref[:, b].copy_(j.latents[:, 0].to(dev, F32))
+                    st.mask[b].copy_(j.frozen_mask.to(dev, F32).clamp(0., 1.).reshape(L * L))
             eng.dyn[1:2].fill_(int(frozen_steps))
-        saved = {}
         hw = self.map_hw(L)
-        tok = return_token_ca_only
-        for k in save_keys:
-            Tp = 1 if tok is not None else eng.text_len
-            Bp = 1 if return_cond_ca_only else 2
-            saved[k] = torch.zeros((T, Bp, self.heads_of(k), hw[k], Tp), device=dev, dtype=F32)
+        Bp = 1 if return_cond_ca_only else 2
+        saved = [{k: torch.zeros((T, Bp, self.heads_of(k), hw[k], 1 if j.token is not None else eng.text_len),
+                                 device=dev, dtype=F32) for k in save_keys} for j in jobs]
 
         for index in range(T):
             eng.set_step(index)
             fuser_on = fuser_at(index)
-            if gs is not None and index < gs.max_index_step:
-                gf, gb = runners_guide[fuser_on]
-                self.backward_guidance(gs, plans_guide[fuser_on], index, st, gf, gb, trace)
+            if guided and index < max_guided:
+                pg, gf, gb = runners_guide[fuser_on]
+                self.backward_guidance(gstates, energy, pg, index, st, gf, gb, trace)
             runners_main[fuser_on]()
             self.stats["unet_main"] += 1
             if save_keys:
                 maps = plans_main[fuser_on].maps
-                for k in save_keys:                                   # attention_processor.py:466-476
-                    m = maps[k][1:] if return_cond_ca_only else maps[k]
-                    saved[k][index].copy_(m[..., int(tok):int(tok) + 1] if tok is not None else m)
-        return dict(latents=st.lat.clone(), latents_all=st.hist.clone() if save_all_latents else None,
-                    saved=saved, guidance_iters=gs.iterations if gs is not None else 0)
+                for b, j in enumerate(jobs):                              # attention_processor.py:466-476
+                    for k in save_keys:
+                        m = maps[k][nb + b:nb + b + 1] if return_cond_ca_only else maps[k][[b, nb + b]]
+                        saved[b][k][index].copy_(m[..., int(j.token):int(j.token) + 1] if j.token is not None else m)
+        hist = st.hist.clone() if save_all_latents else None
+        return [dict(latents=st.lat[b:b + 1].clone(), latents_all=hist[:, b:b + 1] if hist is not None else None,
+                     saved=saved[b], guidance_iters=gstates[b].iterations if gstates[b] is not None else 0)
+                for b in range(nb)]
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -500,7 +500,7 @@ class Plan:
 
 class UNetEngine:
     def __init__(self, cfg: UNetConfig, device="cuda", state_dict: Optional[Dict[str, torch.Tensor]] = None,
-                 text_len: int = 77, max_text_batch: int = 2):
+                 text_len: int = 77, max_text_batch: int = 16):
         self.cfg = cfg
         self.device = torch.device(device)
         self.blocks = unet_blocks(cfg)
@@ -596,6 +596,8 @@ class UNetEngine:
         objs = ops.linear(h, w.h["position_net.linears.4.w"], w.f["position_net.linears.4.b"])  # [Bt*30, Cx]
         self._objs = objs
         for (prefix, B, toff), cat in self._fuser_cat.items():
+            if B not in (Bt, Bt // 2) or toff + B > Bt:
+                continue                   # concat buffer of a plan with another batch size
             f = f"{prefix}.transformer_blocks.0.fuser"
             C = cat.shape[1]
             S = cat.shape[0] // B - N_OBJ_TOKENS
