@@ -33,7 +33,9 @@ def rec(d):
 ops.gemm_launch = rec
 sm = LMDSampler(eng, use_graphs=False)
 eng.prepare_timesteps([500]); eng.set_step(0)
-for name, fn in sm.profile_passes(L, 50, cfg.use_gated_attention):
+batches = [int(x) for x in os.environ.get("LGD_TUNE_BATCHES", "1,4,8").split(",")]
+for kind, fz, nb, fn in sm.profile_passes(L, 50, cfg.use_gated_attention, main_batches=batches,
+                                          guide_batches=[b for b in batches if b <= 4]):
     fn()
 torch.cuda.synchronize()
 ops.gemm_launch = orig
@@ -68,9 +70,11 @@ def bench(sh, tile, splits, reps=12):
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3   # us
 
-table = {}
+table = json.load(open(out_path)) if os.path.exists(out_path) else {}
 tot_old = tot_new = 0.0
 for key, sh in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"] * kv[1]["N"] * kv[1]["K"]):
+    if key in table:
+        continue
     M, N, K = sh["M"], sh["N"], sh["K"]
     geglu = bool(sh["epi"] & 1)
     cands = []
