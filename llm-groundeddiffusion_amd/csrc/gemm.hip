@@ -86,6 +86,57 @@ __device__ __forceinline__ void epilogue_store4(const LgdGemmDesc& d, long c_off
   }
 }
 
+// Epilogue shared by both main-loop variants: lane owns pixel m = .. + (lane&15) and the 4
+// consecutive channels n = .. + (lane>>4)*4 + r of every 16x16 accumulator tile.
+template <int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& ga, f32x4 (&acc)[NI][MI], int m0, int n0,
+                                              int wm, int wn, int lane, int batch, int split,
+                                              long c_off, long r_off) {
+  const LgdGemmDesc& d = ga.d;
+  const int m_l = lane & 15;
+  const int n_l = (lane >> 4) * 4;
+  if (d.splits > 1) {
+    float* ws = ga.d.ws + ((long)batch * d.splits + split) * (long)d.M * d.N;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      int m = m0 + wm * 16 * MI + mi * 16 + m_l;
+      if (m >= d.M) continue;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        int n = n0 + wn * 16 * NI + ni * 16 + n_l;
+        if (n >= d.N) continue;
+        f32x4 v = acc[ni][mi];
+        *reinterpret_cast<float4*>(ws + (long)m * d.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    return;
+  }
+  const bool geglu = d.epi & LGD_EPI_GEGLU;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    int m = m0 + wm * 16 * MI + mi * 16 + m_l;
+    if (m >= d.M) continue;
+    if (geglu) {
+      if constexpr (NI % 2 == 0) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ni += 2) {
+          int n_in = n0 + wn * 16 * NI + ni * 16 + n_l;
+          if (n_in >= d.N) continue;
+          int n_out = (n0 + wn * 16 * NI + ni * 16) / 2 + n_l;
+          epilogue_store4<true>(d, c_off, r_off, m, n_in, n_out, acc[ni][mi], acc[ni + 1][mi]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        int n = n0 + wn * 16 * NI + ni * 16 + n_l;
+        if (n >= d.N) continue;
+        epilogue_store4<false>(d, c_off, r_off, m, n, n, acc[ni][mi], acc[ni][mi]);
+      }
+    }
+  }
+}
+
 template <int MI, int NI>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs ga) {
   constexpr int BM = 32 * MI;
@@ -256,49 +307,204 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs ga) {
     }
   }
 
-  // ---- epilogue: lane owns pixel m = .. + (lane&15), channels n = .. + (lane>>4)*4 + r
-  const int m_l = lane & 15;
-  const int n_l = (lane >> 4) * 4;
-  if (d.splits > 1) {
-    float* ws = ga.d.ws + ((long)batch * d.splits + split) * (long)d.M * d.N;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      int m = m0 + wm * 16 * MI + mi * 16 + m_l;
-      if (m >= d.M) continue;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        int n = n0 + wn * 16 * NI + ni * 16 + n_l;
-        if (n >= d.N) continue;
-        f32x4 v = acc[ni][mi];
-        *reinterpret_cast<float4*>(ws + (long)m * d.N + n) = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-    return;
+  gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off);
+}
+
+// 128 B of zeros: the source of every conv-padding / out-of-range segment of the LDS-DMA variant
+// (an LDS-DMA lane cannot be predicated into writing zeros, so it is pointed here instead).
+__device__ __attribute__((aligned(128))) unsigned int g_zero_line[32];
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+// Main-loop variant 2: operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4), no staging
+// VGPRs and no ds_write pass; two LDS stages, one barrier per K tile.
+//   * a wave-instruction moves 64 x 16 B = 8 tile rows of 128 B; the DMA's LDS image is lane-linear,
+//     so LDS rows are unpadded [row][64 halfs] and the bank spread comes from an XOR swizzle applied on
+//     the SOURCE side: the lane that fills physical 16-B slot p of row r fetches logical segment
+//     p ^ ((r>>1)&7).  The 8 lanes of a row still cover one full 128-B line, so HBM/L2 traffic is
+//     unchanged; the fragment reads (16 rows x 4 segments per ds_read_b128) hit 16 distinct slots of
+//     the 256-B bank row in each of the 4 hardware lane groups -> conflict-free.
+//   * requires every K tile to be full (K % 64 == 0) — true for every UNet contraction; the entry
+//     point routes other shapes to the register-staged variant.
+template <int MI, int NI>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs ga) {
+  constexpr int BM = 32 * MI;
+  constexpr int BN = 32 * NI;
+  constexpr int A_IT = BM / 32;
+  constexpr int B_IT = BN / 32;
+  constexpr int STAGE = (BM + BN) * BK;  // halfs per stage
+
+  __shared__ __attribute__((aligned(1024))) half_t smem[2 * STAGE];
+
+  const LgdGemmDesc& d = ga.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+
+  // ---- block coordinates. Workgroups are dealt round-robin to the 8 XCDs; remap so that each XCD
+  // walks a contiguous range of tiles (n fastest): the tiles that share A rows share one L2.
+  const int n_tiles_n = (d.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const bool geglu = d.epi & LGD_EPI_GEGLU;
+  const int tile_m = bid / n_tiles_n;
+  const int tile_n = bid - tile_m * n_tiles_n;
+  const int zz = blockIdx.z;
+  const int batch = zz / d.splits;
+  const int split = zz - batch * d.splits;
+  const int b_o = batch / d.nb_i, b_i = batch - b_o * d.nb_i;
+  const long a_off = b_o * d.a_bs_o + b_i * d.a_bs_i;
+  const long w_off = b_o * d.w_bs_o + b_i * d.w_bs_i;
+  const long c_off = b_o * d.c_bs_o + b_i * d.c_bs_i;
+  const long r_off = b_o * d.r_bs_o + b_i * d.r_bs_i;
+
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int k_beg = split * ga.k_per_split;
+  int k_end = k_beg + ga.k_per_split;
+  if (k_end > d.K) k_end = d.K;
+  const int nk = (k_end - k_beg) / BK;
+
+  const half_t* A0 = reinterpret_cast<const half_t*>(d.a0) + a_off;
+  const half_t* A1 = d.a1 ? reinterpret_cast<const half_t*>(d.a1) + a_off : nullptr;
+  const half_t* W = reinterpret_cast<const half_t*>(d.w) + w_off;
+  const half_t* zero = reinterpret_cast<const half_t*>(g_zero_line);
+
+  // ---- per-thread staging coordinates
+  const int rrow = tid >> 3;                       // row within a 32-row pass
+  const int kseg = (tid & 7) ^ ((rrow >> 1) & 7);  // logical 8-half segment this lane fetches
+  const int cin = ga.cin;
+  const bool conv = d.taps == 9;
+
+  int a_iy0[A_IT], a_ix0[A_IT];
+  long a_row[A_IT];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    int m = m0 + wm * 16 * MI + mi * 16 + m_l;
-    if (m >= d.M) continue;
-    if (geglu) {
-      if constexpr (NI % 2 == 0) {
-#pragma unroll
-        for (int ni = 0; ni < NI; ni += 2) {
-          int n_in = n0 + wn * 16 * NI + ni * 16 + n_l;
-          if (n_in >= d.N) continue;
-          int n_out = (n0 + wn * 16 * NI + ni * 16) / 2 + n_l;
-          epilogue_store4<true>(d, c_off, r_off, m, n_in, n_out, acc[ni][mi], acc[ni + 1][mi]);
-        }
-      }
+  for (int i = 0; i < A_IT; ++i) {
+    int m = m0 + rrow + 32 * i;
+    if (m >= d.M) m = d.M - 1;  // rows past M are computed on valid data and never stored
+    if (conv) {
+      int hw = d.hout * d.wout;
+      int b = m / hw;
+      int rem = m - b * hw;
+      int oy = rem / d.wout;
+      int ox = rem - oy * d.wout;
+      a_iy0[i] = oy * d.stride - 1;
+      a_ix0[i] = ox * d.stride - 1;
+      a_row[i] = (long)b * d.hin * d.win;
     } else {
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        int n = n0 + wn * 16 * NI + ni * 16 + n_l;
-        if (n >= d.N) continue;
-        epilogue_store4<false>(d, c_off, r_off, m, n, n, acc[ni][mi], acc[ni][mi]);
-      }
+      a_iy0[i] = 0; a_ix0[i] = 0;
+      a_row[i] = m;
     }
   }
+  const half_t* w_row[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    int n = n0 + rrow + 32 * i;
+    if (n >= d.N) n = d.N - 1;
+    w_row[i] = W + (long)n * d.ldw + k_beg + kseg * 8;
+  }
+  const int k_first = k_beg + kseg * 8;
+  int tap = conv ? k_first / cin : 0;
+  int ch = k_first - tap * cin;
+
+  // Source pointers are re-derived only when the K walk enters a new tap or crosses from the first
+  // to the second (concatenated) source; inside a run they just advance by one K tile.
+  const half_t* a_ptr[A_IT];
+  bool a_ok[A_IT];
+  bool rederive = true;
+  auto issue_tile = [&](int stage) {
+    half_t* As = smem + stage * STAGE;
+    half_t* Bs = As + BM * BK;
+    if (rederive) {
+      int ky = 0, kx = 0;
+      if (conv) { ky = tap / 3; kx = tap - ky * 3; }
+      const bool src1 = ch >= d.c0;
+      const half_t* src = src1 ? A1 : A0;
+      const long ld = src1 ? d.lda1 : d.lda0;
+      const int cc = src1 ? ch - d.c0 : ch;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        bool ok = true;
+        long row = a_row[i];
+        if (conv) {
+          int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+          if (d.ups) {
+            ok = iy >= 0 && ix >= 0 && iy < 2 * d.hin && ix < 2 * d.win;
+            if (d.ups == 2) ok = ok && !((iy | ix) & 1);
+            iy >>= 1; ix >>= 1;
+          } else {
+            ok = iy >= 0 && ix >= 0 && iy < d.hin && ix < d.win;
+          }
+          row += (long)iy * d.win + ix;
+        }
+        a_ok[i] = ok;
+        a_ptr[i] = src + row * ld + cc;
+      }
+      rederive = false;
+    }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const half_t* p = a_ok[i] ? a_ptr[i] : zero;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)(As + (32 * i + 8 * wid) * BK), 16, 0, 0);
+      a_ptr[i] += BK;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)w_row[i], (lds_ptr_t)(Bs + (32 * i + 8 * wid) * BK), 16, 0, 0);
+      w_row[i] += BK;
+    }
+    const int ch_prev = ch;
+    ch += BK;
+    if (ch_prev < d.c0 && ch >= d.c0) rederive = true;
+    if (ch >= cin) {
+      rederive = true;
+      do { ch -= cin; ++tap; } while (ch >= cin);
+    }
+  };
+
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fg = lane >> 4;
+  const int fsw = (frow >> 1) & 7;
+
+  if (nk > 0) issue_tile(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed (this wave's DMAs: vmcnt; the other waves': barrier), and every wave has
+    // finished reading the other stage (it was consumed in iteration kt-1).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) issue_tile((kt + 1) & 1);
+    const half_t* As = smem + (kt & 1) * STAGE;
+    const half_t* Bs = As + BM * BK;
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      const int slot = ((kk * 4 + fg) ^ fsw) * 8;
+      half8_t af[MI], bf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        af[mi] = *reinterpret_cast<const half8_t*>(As + (wm * 16 * MI + mi * 16 + frow) * BK + slot);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        bf[ni] = *reinterpret_cast<const half8_t*>(Bs + (wn * 16 * NI + ni * 16 + frow) * BK + slot);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    }
+  }
+
+  gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off);
 }
 
 // Sums the split-K partials and applies the epilogue. One thread per 4 output channels.
@@ -333,12 +539,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs ga) {
 }
 
 template <int MI, int NI>
-int launch_gemm(const GemmArgs& ga, hipStream_t st) {
+int launch_gemm(const GemmArgs& ga, hipStream_t st, bool dma) {
   constexpr int BM = 32 * MI, BN = 32 * NI;
   const LgdGemmDesc& d = ga.d;
   long tiles = (long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
   dim3 grid((unsigned)tiles, 1, (unsigned)(d.nb_o * d.nb_i * d.splits));
-  hipLaunchKernelGGL((gemm_kernel<MI, NI>), grid, dim3(256), 0, st, ga);
+  if (dma) hipLaunchKernelGGL((gemm_dma_kernel<MI, NI>), grid, dim3(256), 0, st, ga);
+  else hipLaunchKernelGGL((gemm_kernel<MI, NI>), grid, dim3(256), 0, st, ga);
   return lgd_check_launch();
 }
 
@@ -387,13 +594,19 @@ extern "C" int lgd_gemm_f16(const LgdGemmDesc* desc, void* stream) {
     else if (wgs(128, 64) >= 256) tile = 2;
     else tile = 4;
   }
+  // tile codes 1..5 = register-staged main loop, 17..21 (16 + code) = LDS-DMA main loop
+  bool dma = tile > 16;
+  if (dma) tile -= 16;
+  if (dma && (d.K % BK)) dma = false;
   int rc;
   switch (tile) {
-    case 1: rc = launch_gemm<4, 4>(ga, st); break;
-    case 2: rc = launch_gemm<4, 2>(ga, st); break;
-    case 3: rc = launch_gemm<2, 4>(ga, st); break;
-    case 4: rc = launch_gemm<2, 2>(ga, st); break;
-    case 5: rc = launch_gemm<1, 4>(ga, st); break;
+    case 1: rc = launch_gemm<4, 4>(ga, st, dma); break;
+    case 2: rc = launch_gemm<4, 2>(ga, st, dma); break;
+    case 3: rc = launch_gemm<2, 4>(ga, st, dma); break;
+    case 4: rc = launch_gemm<2, 2>(ga, st, dma); break;
+    case 5: rc = launch_gemm<1, 4>(ga, st, dma); break;
+    case 6: rc = geglu ? LGD_ERR_ARG : launch_gemm<4, 5>(ga, st, dma); break;  // 128x160: N = 320 k exactly
+    case 7: rc = geglu ? LGD_ERR_ARG : launch_gemm<2, 5>(ga, st, dma); break;  // 64x160
     default: return LGD_ERR_ARG;
   }
   if (rc) return rc;

@@ -41,6 +41,10 @@ def pack_geglu(w, b):  # [2n,K] -> 16-row value/gate interleave
     (8192, 320, 320, 0, 1), (4100, 640, 640, 1, 1), (512, 1280, 1280, 2, 1), (128, 1280, 5120, 4, 4),
     (77, 320, 768, 5, 1), (154, 1280, 768, 0, 1), (30, 640, 768, 5, 3), (2048, 640, 2560, 3, 2),
     (64, 64, 32, 4, 1), (100, 100, 72, 2, 1),
+    # LDS-DMA main loop (tile code 16 + t); K % 64 != 0 falls back to the register-staged loop
+    (8192, 320, 320, 17, 1), (4100, 640, 640, 18, 1), (512, 1280, 1280, 19, 1), (128, 1280, 5120, 20, 4),
+    (77, 320, 768, 21, 1), (30, 640, 768, 21, 3), (2048, 640, 2560, 19, 2), (100, 100, 72, 18, 1),
+    (1000, 200, 64, 17, 1),
 ])
 def test_gemm_plain(dev, M, N, K, tile, splits):
     x = rnd(M, K, dev=dev, seed=1).half()
@@ -62,27 +66,29 @@ def test_gemm_out_f32_bias2(dev):
     assert y.dtype == F32 and relerr(y, ref) < 1e-3
 
 
-@pytest.mark.parametrize("M,dim,splits", [(4096, 320, 1), (300, 640, 1), (128, 1280, 2)])
-def test_gemm_geglu(dev, M, dim, splits):
+@pytest.mark.parametrize("M,dim,splits,tile", [(4096, 320, 1, 0), (300, 640, 1, 0), (128, 1280, 2, 0),
+                                               (4096, 320, 1, 17), (300, 640, 1, 19), (128, 1280, 2, 20)])
+def test_gemm_geglu(dev, M, dim, splits, tile):
     inner = 4 * dim
     x = rnd(M, dim, dev=dev, seed=1).half()
     w = rnd(2 * inner, dim, dev=dev, seed=2, scale=dim ** -0.5).half()
     b = rnd(2 * inner, dev=dev, seed=3)
     wp, bp = pack_geglu(w, b)
-    y = ops.linear(x, wp, bp, geglu=True, splits=splits)
+    y = ops.linear(x, wp, bp, geglu=True, splits=splits, tile=tile)
     h = x.float() @ w.float().t() + b
     v, g = h.chunk(2, dim=-1)
     ref = v * F.gelu(g)
     assert y.shape == (M, inner) and relerr(y, ref) < 3e-3
 
 
+@pytest.mark.parametrize("dma", [0, 16])
 @pytest.mark.parametrize("B,H,C0,C1,Cout,stride,ups,splits", [
     (2, 16, 64, 0, 64, 1, False, 1), (2, 32, 320, 0, 320, 1, False, 1),
     (1, 16, 128, 64, 128, 1, False, 1), (2, 8, 1280, 1280, 1280, 1, False, 8),
     (2, 16, 320, 0, 320, 2, False, 1), (1, 8, 640, 0, 640, 1, True, 1),
     (1, 10, 64, 0, 128, 1, False, 1), (1, 16, 64, 0, 64, 1, 2, 1),
 ])
-def test_conv3x3(dev, B, H, C0, C1, Cout, stride, ups, splits):
+def test_conv3x3(dev, B, H, C0, C1, Cout, stride, ups, splits, dma):
     C = C0 + C1
     x = rnd(B, C, H, H, dev=dev, seed=1).half()
     w = rnd(Cout, C, 3, 3, dev=dev, seed=2, scale=(9 * C) ** -0.5).half()
@@ -101,7 +107,7 @@ def test_conv3x3(dev, B, H, C0, C1, Cout, stride, ups, splits):
     Ho = ref.shape[-1]
     res = rnd(B * Ho * Ho, Cout, dev=dev, seed=7).half()
     y = ops.conv3x3(x0, pack_conv_w(w), B, H, H, x1=x1, bias=b, res=res, stride=stride,
-                    ups=int(ups), splits=splits)
+                    ups=int(ups), splits=splits, tile=(dma + 3 if dma else 0))
     ref = ref.permute(0, 2, 3, 1).reshape(-1, Cout) + res.float()
     assert relerr(y, ref) < 3e-3
 
