@@ -57,12 +57,25 @@ __device__ __forceinline__ float silu_grad_f(float x) {
   float s = 1.f / (1.f + __expf(-x));
   return s * (1.f + x * (1.f - s));
 }
-// exact (erf) GELU, as torch.nn.functional.gelu default
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the fp16 resolution of every
+// consumer): ~14 VALU ops instead of the device library's branchy erff — the GEGLU epilogue of the
+// K = 320 feed-forward GEMM evaluates it once per output element and was VALU-bound on it.
+__device__ __forceinline__ float erf_f(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.f - p * t * __expf(-ax * ax);
+  return copysignf(e, x);
+}
+// exact-form (erf) GELU, as torch.nn.functional.gelu default
 __device__ __forceinline__ float gelu_f(float x) {
-  return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+  return 0.5f * x * (1.f + erf_f(x * 0.70710678118654752f));
 }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  float cdf = 0.5f * (1.f + erf_f(x * 0.70710678118654752f));
   float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }

@@ -40,22 +40,11 @@ __device__ __forceinline__ float4 ld_bias4(const float* p, int n) {
 // For GEGLU `v` holds the value accumulators and `g` the gate accumulators of the same columns.
 template <bool GEGLU>
 __device__ __forceinline__ void epilogue_store4(const LgdGemmDesc& d, long c_off, long r_off, int m,
-                                                int n_in, int n_out, f32x4 v, f32x4 g) {
-  // n_in: column index in the (packed) weight/bias space for the value block;
-  // n_out: output column.
-  if (d.bias) {
-    float4 b = ld_bias4(d.bias, n_in);
-    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    if (GEGLU) {
-      float4 bg = ld_bias4(d.bias, n_in + 16);
-      g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
-    }
-  }
-  if (d.bias2) {
-    float4 b = ld_bias4(d.bias2, n_in);
-    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-  }
+                                                int n_out, f32x4 v, f32x4 g, float4 bv, float4 bg) {
+  // bv / bg: summed biases of the value / gate columns (zeros when absent); n_out: output column.
+  v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
   if (GEGLU) {
+    g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = v[r] * gelu_f(g[r]);
   }
@@ -86,6 +75,17 @@ __device__ __forceinline__ void epilogue_store4(const LgdGemmDesc& d, long c_off
   }
 }
 
+// Sum of the (optional) two bias vectors at columns n..n+3.
+__device__ __forceinline__ float4 ld_bias_sum4(const LgdGemmDesc& d, int n) {
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (d.bias) b = ld_bias4(d.bias, n);
+  if (d.bias2) {
+    float4 b2 = ld_bias4(d.bias2, n);
+    b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+  }
+  return b;
+}
+
 // Epilogue shared by both main-loop variants: lane owns pixel m = .. + (lane&15) and the 4
 // consecutive channels n = .. + (lane>>4)*4 + r of every 16x16 accumulator tile.
 template <int MI, int NI>
@@ -112,26 +112,33 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& ga, f32x4 (&acc)[N
     return;
   }
   const bool geglu = d.epi & LGD_EPI_GEGLU;
+  if (geglu) {
+    if constexpr (NI % 2 == 0) {
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    int m = m0 + wm * 16 * MI + mi * 16 + m_l;
-    if (m >= d.M) continue;
-    if (geglu) {
-      if constexpr (NI % 2 == 0) {
+      for (int ni = 0; ni < NI; ni += 2) {
+        const int n_in = n0 + wn * 16 * NI + ni * 16 + n_l;
+        if (n_in >= d.N) continue;
+        const int n_out = (n0 + wn * 16 * NI + ni * 16) / 2 + n_l;
+        const float4 bv = ld_bias_sum4(d, n_in);
+        float4 bg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d.bias) bg = ld_bias4(d.bias, n_in + 16);
 #pragma unroll
-        for (int ni = 0; ni < NI; ni += 2) {
-          int n_in = n0 + wn * 16 * NI + ni * 16 + n_l;
-          if (n_in >= d.N) continue;
-          int n_out = (n0 + wn * 16 * NI + ni * 16) / 2 + n_l;
-          epilogue_store4<true>(d, c_off, r_off, m, n_in, n_out, acc[ni][mi], acc[ni + 1][mi]);
+        for (int mi = 0; mi < MI; ++mi) {
+          const int m = m0 + wm * 16 * MI + mi * 16 + m_l;
+          if (m < d.M) epilogue_store4<true>(d, c_off, r_off, m, n_out, acc[ni][mi], acc[ni + 1][mi], bv, bg);
         }
       }
-    } else {
+    }
+  } else {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        int n = n0 + wn * 16 * NI + ni * 16 + n_l;
-        if (n >= d.N) continue;
-        epilogue_store4<false>(d, c_off, r_off, m, n, n, acc[ni][mi], acc[ni][mi]);
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wn * 16 * NI + ni * 16 + n_l;
+      if (n >= d.N) continue;
+      const float4 bv = ld_bias_sum4(d, n);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * 16 * MI + mi * 16 + m_l;
+        if (m < d.M) epilogue_store4<false>(d, c_off, r_off, m, n, acc[ni][mi], acc[ni][mi], bv, bv);
       }
     }
   }
@@ -533,8 +540,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs ga) {
         g[0] += u.x; g[1] += u.y; g[2] += u.z; g[3] += u.w;
       }
     }
-    if (geglu) epilogue_store4<true>(d, c_off, r_off, m, n_in, gcol, v, g);
-    else epilogue_store4<false>(d, c_off, r_off, m, n_in, gcol, v, g);
+    const float4 bv = ld_bias_sum4(d, n_in);
+    if (geglu) {
+      float4 bg = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (d.bias) bg = ld_bias4(d.bias, n_in + 16);
+      epilogue_store4<true>(d, c_off, r_off, m, gcol, v, g, bv, bg);
+    } else {
+      epilogue_store4<false>(d, c_off, r_off, m, gcol, v, g, bv, bv);
+    }
   }
 }
 
@@ -589,12 +602,14 @@ extern "C" int lgd_gemm_f16(const LgdGemmDesc* desc, void* stream) {
     auto wgs = [&](int bm, int bn) {
       return batches * ((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn);
     };
-    if (d.M <= 32) tile = 5;
-    else if (wgs(128, 128) >= 384 && d.N % 128 == 0) tile = 1;
-    else if (wgs(128, 64) >= 256) tile = 2;
-    else tile = 4;
+    if (d.M <= 32) tile = 21;
+    else if (!geglu && d.N % 160 == 0 && wgs(128, 160) >= 384) tile = 22;
+    else if (!geglu && d.N % 160 == 0 && wgs(64, 160) >= 256) tile = 23;
+    else if (wgs(128, 128) >= 384 && d.N % 128 == 0) tile = 17;
+    else if (wgs(64, 128) >= 256 && d.N % 128 == 0) tile = 19;
+    else tile = 20;
   }
-  // tile codes 1..5 = register-staged main loop, 17..21 (16 + code) = LDS-DMA main loop
+  // tile codes 1..7 = register-staged main loop, 17..23 (16 + code) = LDS-DMA main loop
   bool dma = tile > 16;
   if (dma) tile -= 16;
   if (dma && (d.K % BK)) dma = false;

@@ -80,7 +80,7 @@ def gemm_desc(a0, w, c, M, N, K, *, a1=None, lda0=None, lda1=0, c0=None, c1=0, t
     if splits is None:
         splits = ent["splits"] if ent else choose_splits(M, N, K, nb_o * nb_i)
     if not tile:
-        tile = ent["tile"] if (ent and ent["splits"] == splits) else choose_tile(M, N, nb_o * nb_i * max(splits, 1))
+        tile = ent["tile"] if (ent and ent["splits"] == splits) else choose_tile(M, N, nb_o * nb_i * max(splits, 1), bool(epi & EPI_GEGLU), K)
     if splits > 1 and ws is None:
         global WORKSPACE
         need = splits * M * N * nb_o * nb_i
@@ -94,21 +94,29 @@ def gemm_desc(a0, w, c, M, N, K, *, a1=None, lda0=None, lda1=0, c0=None, c1=0, t
     return d
 
 
-TILE_NAMES = {1: "gemm_kernel<4,4> 128x128", 2: "gemm_kernel<4,2> 128x64", 3: "gemm_kernel<2,4> 64x128",
-              4: "gemm_kernel<2,2> 64x64", 5: "gemm_kernel<1,4> 32x128"}
+_TILE_DIMS = {1: (4, 4), 2: (4, 2), 3: (2, 4), 4: (2, 2), 5: (1, 4), 6: (4, 5), 7: (2, 5)}
+TILE_NAMES = {t: f"gemm_kernel<{mi},{ni}> {32 * mi}x{32 * ni}" for t, (mi, ni) in _TILE_DIMS.items()}
+TILE_NAMES.update({16 + t: f"gemm_dma_kernel<{mi},{ni}> {32 * mi}x{32 * ni}" for t, (mi, ni) in _TILE_DIMS.items()})
 
 
-def choose_tile(M, N, batches=1):
-    """Tile heuristic (same rule as the library's auto mode, done here so the choice is known to the
-    profiler): the largest tile that still yields enough workgroups for 256 CUs."""
+def choose_tile(M, N, batches=1, geglu=False, K=64):
+    """Tile heuristic for shapes the tuning table does not list (same rule as the library's auto mode,
+    done here so the choice is known to the profiler): the largest tile that still yields enough
+    workgroups for 256 CUs; 160-wide tiles when they divide N (every UNet width is 320 k).  Codes
+    17..23 select the LDS-DMA main loop (the library falls back to register staging if K % 64)."""
     wgs = lambda bm, bn: batches * ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
     if M <= 32:
-        return 5
+        return 21
+    if not geglu and N % 160 == 0:
+        if wgs(128, 160) >= 384:
+            return 22
+        if wgs(64, 160) >= 256:
+            return 23
     if wgs(128, 128) >= 384 and N % 128 == 0:
-        return 1
-    if wgs(128, 64) >= 256:
-        return 2
-    return 4
+        return 17
+    if wgs(64, 128) >= 256 and N % 128 == 0:
+        return 19
+    return 20
 
 
 def shape_key(d) -> str:

@@ -41,7 +41,7 @@ torch.cuda.synchronize()
 ops.gemm_launch = orig
 print(f"{len(shapes)} distinct GEMM shapes")
 
-def bench(sh, tile, splits, reps=12):
+def bench(sh, tile, splits, reps=8):
     M, N, K = sh["M"], sh["N"], sh["K"]
     c0, c1, taps = sh["c0"], sh["c1"], sh["taps"]
     rows_in = M if taps == 1 else max(1, (M // max(sh["hout"] * sh["wout"], 1))) * sh["hin"] * sh["win"]
@@ -70,7 +70,7 @@ def bench(sh, tile, splits, reps=12):
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3   # us
 
-table = json.load(open(out_path)) if os.path.exists(out_path) else {}
+table = json.load(open(out_path)) if (os.path.exists(out_path) and not os.environ.get("LGD_TUNE_FRESH")) else {}
 tot_old = tot_new = 0.0
 for key, sh in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"] * kv[1]["N"] * kv[1]["K"]):
     if key in table:
@@ -78,8 +78,11 @@ for key, sh in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"
     M, N, K = sh["M"], sh["N"], sh["K"]
     geglu = bool(sh["epi"] & 1)
     cands = []
-    for tile in (1, 2, 3, 4, 5):
-        bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (32, 128)}[tile]
+    for tile in (17, 18, 19, 20, 21, 22, 23):   # LDS-DMA main loop (falls back to register staging if K % 64)
+        if geglu and tile in (22, 23):
+            continue
+        bm, bn = {17: (128, 128), 18: (128, 64), 19: (64, 128), 20: (64, 64), 21: (32, 128), 22: (128, 160),
+                  23: (64, 160)}[tile]
         wgs = -(-M // bm) * -(-N // bn)
         for sp in (1, 2, 3, 4, 6, 8, 12, 16):
             if sp > 1 and (K // 64 < 4 * sp or wgs * sp > 2048 or sp * M * N > (1 << 26)):
@@ -88,9 +91,8 @@ for key, sh in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"
                 continue   # hopelessly under-filled, a larger split exists
             cands.append((tile, sp))
     best = None
-    d_tile = ops.choose_tile(M, N, 1)
     from lgd_amd.unet import choose_splits
-    base = bench(sh, ops.choose_tile(M, N, choose_splits(M, N, K)), choose_splits(M, N, K))
+    base = bench(sh, ops.choose_tile(M, N, choose_splits(M, N, K), geglu, K), choose_splits(M, N, K)) or 0.0
     for tile, sp in cands:
         t = bench(sh, tile, sp)
         if t is not None and (best is None or t < best[0]):
