@@ -35,7 +35,9 @@ struct AttnArgs {
   float scale_log2;  // scale * log2(e)
 };
 
-template <int DP, bool SAVE_P>
+// ONES (only without SAVE_P, needs d < DP): row d of the transposed V tile is set to 1, so the PV
+// MFMA also produces the softmax row sum (in accumulator row d) and the VALU never adds it up.
+template <int DP, bool SAVE_P, bool ONES>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   constexpr int K_LD = DP + 8;
   constexpr int NDC = DP / 32;  // 32-wide chunks of the head dim (QK^T contraction)
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           half2_t pr = {e0[e], e1[e]};
+          if (ONES && seg * 8 + e == d) pr = (half2_t){(half_t)1.f, (half_t)1.f};
           *reinterpret_cast<half2_t*>(Vt + (seg * 8 + e) * VT_LD + pair * 2) = pr;
         }
       }
@@ -233,37 +236,70 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     }
     l_run = 1.f;  // already normalised
   } else {
+    // Softmax work per score is what bounds this kernel at head dims 40/80 (one MFMA pass covers 32
+    // of the contraction, the exp is quarter rate), so the VALU side is pared down to:
+    //   max3 chain, one fma (scale and reference shift), v_exp_f32, packed fp16 convert.
+    //  * the running reference m_ref is only raised when some row's tile max exceeds it by more
+    //    than 2^8 (wave-uniform vote): P stays <= 256 (exact in the fp32 accumulators, fine as an
+    //    fp16 MFMA operand) and the accumulator rescale all but disappears after the first tiles;
+    //  * the row sum comes out of the PV MFMA (ONES), and the tail mask is a uniform branch.
+    float m_ref = NEG_BIG;
+    const float sc = a.scale_log2;
     load_tile(0);
     store_tile();
     __syncthreads();
     for (int t = 0; t < n_tiles; ++t) {
       if (t + 1 < n_tiles) load_tile((t + 1) * KV_T);
+      const int kv0 = t * KV_T;
       f32x4 s[4];
-      compute_s(t * KV_T, s);
-      float mx = NEG_BIG;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4; ++kt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+        for (int dc = 0; dc < NDC; ++dc) {
+          half8_t kf =
+              *reinterpret_cast<const half8_t*>(Ks + (kt * 16 + c16) * K_LD + dc * 32 + g * 8);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[dc], acc, 0, 0, 0);
+        }
+        s[kt] = acc;
+      }
+      if (kv0 + KV_T > a.Sk) {  // ragged last tile
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kv0 + kt * 16 + g * 4 + r >= a.Sk) s[kt][r] = NEG_BIG;
+      }
+      float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
+      mx = fmaxf(fmaxf(mx, s[0][3]), s[1][0]);
+      mx = fmaxf(fmaxf(mx, s[1][1]), s[1][2]);
+      mx = fmaxf(fmaxf(mx, s[1][3]), s[2][0]);
+      mx = fmaxf(fmaxf(mx, s[2][1]), s[2][2]);
+      mx = fmaxf(fmaxf(mx, s[2][3]), s[3][0]);
+      mx = fmaxf(fmaxf(mx, s[3][1]), s[3][2]);
+      mx = fmaxf(mx, s[3][3]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = exp2f(m_run - m_new);
-      float sum = 0.f;
+      const float mxs = mx * sc;
+      if (__builtin_amdgcn_ballot_w64(mxs > m_ref + 8.f) != 0) {
+        const float m_new = fmaxf(m_ref, mxs);
+        const float alpha = __builtin_amdgcn_exp2f(m_ref - m_new);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+        if (!ONES) l_run *= alpha;
+        m_ref = m_new;
+      }
+      const float nm = -m_ref;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float p = exp2f(s[kt][r] - m_new);
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc, nm));
           s[kt][r] = p;
-          sum += p;
+          if (!ONES) l_run += p;
         }
-      l_run = l_run * alpha + sum;
-      m_run = m_new;
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
       pv(s);
       __syncthreads();
       if (t + 1 < n_tiles) {
@@ -271,8 +307,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         __syncthreads();
       }
     }
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
+    m_run = m_ref;
+    if (ONES) {
+      // row sum of query c16 sits in accumulator row d: tile d/16, lane group (d%16)/4, register 0
+      const int dt_l = d >> 4, g_l = (d & 15) >> 2;
+      float lv = 0.f;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+        if (dt == dt_l) lv = oacc[dt][0];
+      l_run = __shfl(lv, g_l * 16 + c16, 64);
+    } else {
+      l_run += __shfl_xor(l_run, 16, 64);
+      l_run += __shfl_xor(l_run, 32, 64);
+    }
   }
 
   // ---- epilogue: lane owns query q0+c16, dv = dt*16 + g*4 + r
@@ -295,15 +342,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   }
 }
 
+template <int DP, bool SAVE_P>
+void launch_attn_dp(const AttnArgs& a, dim3 grid, hipStream_t st) {
+  if constexpr (SAVE_P) {
+    hipLaunchKernelGGL((attn_fwd_kernel<DP, true, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (a.d < DP) hipLaunchKernelGGL((attn_fwd_kernel<DP, false, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<DP, false, false>), grid, dim3(256), 0, st, a);
+  }
+}
+
 template <bool SAVE_P>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
   dim3 grid((a.Sq + 63) / 64, a.H, a.B);
   const int d = a.d;
-  if (d <= 32) hipLaunchKernelGGL((attn_fwd_kernel<32, SAVE_P>), grid, dim3(256), 0, st, a);
-  else if (d <= 64) hipLaunchKernelGGL((attn_fwd_kernel<64, SAVE_P>), grid, dim3(256), 0, st, a);
-  else if (d <= 96) hipLaunchKernelGGL((attn_fwd_kernel<96, SAVE_P>), grid, dim3(256), 0, st, a);
-  else if (d <= 128) hipLaunchKernelGGL((attn_fwd_kernel<128, SAVE_P>), grid, dim3(256), 0, st, a);
-  else if (d <= 160) hipLaunchKernelGGL((attn_fwd_kernel<160, SAVE_P>), grid, dim3(256), 0, st, a);
+  if (d <= 32) launch_attn_dp<32, SAVE_P>(a, grid, st);
+  else if (d <= 64) launch_attn_dp<64, SAVE_P>(a, grid, st);
+  else if (d <= 96) launch_attn_dp<96, SAVE_P>(a, grid, st);
+  else if (d <= 128) launch_attn_dp<128, SAVE_P>(a, grid, st);
+  else if (d <= 160) launch_attn_dp<160, SAVE_P>(a, grid, st);
   else return LGD_ERR_UNSUPPORTED;
   return lgd_check_launch();
 }
