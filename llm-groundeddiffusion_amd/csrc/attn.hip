@@ -342,25 +342,299 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Self-attention forward (no map capture): the kernel the UNet spends most of its attention time
+// in (S = 4096, d = 40 at the 64x64 level).  Same transposed-product layout as attn_fwd_kernel, but
+//   * each wave owns QT x 16 queries, so every K / V^T fragment read from LDS feeds QT MFMAs and
+//     the tile staging cost is split over QT x 64 queries per workgroup;
+//   * two LDS stages, one barrier per key tile; staging pointers and predicates are hoisted, the
+//     head-dim padding (columns d..DP of K, rows d..DP of V^T) is written once, not per tile;
+//   * softmax pared down to max3 / fma / v_exp_f32 / packed convert: the reference exponent m_ref
+//     is only raised when a row's tile max exceeds it by more than 2^8 (wave-uniform vote), the
+//     row sum is produced by the PV MFMA from a row of ones at V^T row d (ONES, needs d < DP).
+template <int DP, bool ONES, int QT>
+__global__ __launch_bounds__(256) void attn_self_kernel(const AttnArgs a) {
+  constexpr int K_LD = DP + 8;
+  constexpr int NDC = DP / 32;
+  constexpr int NDT = DP / 16;
+  constexpr int KSEG = DP / 8;
+  constexpr int K_IT = (KV_T * KSEG + 255) / 256;
+  constexpr int V_ITEMS = (KV_T / 2) * KSEG;
+  constexpr int V_IT = (V_ITEMS + 255) / 256;
+  constexpr int STAGE = KV_T * K_LD + DP * VT_LD;
+
+  __shared__ __attribute__((aligned(16))) half_t smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (64 * QT) + wid * (16 * QT);
+  const int d = a.d;
+  const half_t* Qb = a.q + (long)b * a.q_bs + (long)h * d;
+  const half_t* Kb = a.k + (long)b * a.k_bs + (long)h * d;
+  const half_t* Vb = a.v + (long)b * a.v_bs + (long)h * d;
+
+  // ---- one-time LDS fill: zeros everywhere (padding columns / rows must not hold NaN bit
+  // patterns), ones at V^T row d of both stages.
+  for (int i = tid; i < 2 * STAGE / 8; i += 256)
+    reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  if (ONES && tid < 2 * VT_LD) {
+    const int st = tid / VT_LD, col = tid - st * VT_LD;
+    smem[st * STAGE + KV_T * K_LD + d * VT_LD + col] = (half_t)1.f;
+  }
+
+  // ---- Q fragments
+  half8_t qf[QT][NDC];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qrow = q0 + qt * 16 + c16;
+#pragma unroll
+    for (int dc = 0; dc < NDC; ++dc) {
+      const int dd = dc * 32 + g * 8;
+      if (qrow < a.Sq && dd < d)
+        qf[qt][dc] = *reinterpret_cast<const half8_t*>(Qb + (long)qrow * a.ldq + dd);
+      else
+        qf[qt][dc] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+
+  // ---- hoisted staging coordinates
+  const half_t* kp[K_IT];
+  int k_row[K_IT], k_dst[K_IT];
+  bool k_use[K_IT];
+#pragma unroll
+  for (int i = 0; i < K_IT; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx / KSEG, seg = idx - row * KSEG;
+    k_use[i] = (idx < KV_T * KSEG) && (seg * 8 < d);
+    k_row[i] = row;
+    k_dst[i] = row * K_LD + seg * 8;
+    kp[i] = Kb + (long)row * a.ldk + seg * 8;
+  }
+  const half_t* vp[V_IT];
+  int v_row[V_IT], v_dst[V_IT];
+  bool v_use[V_IT];
+#pragma unroll
+  for (int i = 0; i < V_IT; ++i) {
+    const int idx = tid + i * 256;
+    const int pair = idx & 31, seg = idx >> 5;
+    v_use[i] = (idx < V_ITEMS) && (seg * 8 < d);
+    v_row[i] = pair * 2;
+    v_dst[i] = KV_T * K_LD + (seg * 8) * VT_LD + pair * 2;
+    vp[i] = Vb + (long)(pair * 2) * a.ldv + seg * 8;
+  }
+
+  uint4 k_reg[K_IT], v_reg[V_IT][2];
+  auto load_tile = [&](int kv0) {
+    const bool full = kv0 + KV_T <= a.Sk;
+#pragma unroll
+    for (int i = 0; i < K_IT; ++i) {
+      const bool ok = k_use[i] && (full || kv0 + k_row[i] < a.Sk);
+      k_reg[i] = ok ? *reinterpret_cast<const uint4*>(kp[i]) : make_uint4(0, 0, 0, 0);
+      kp[i] += (long)KV_T * a.ldk;
+    }
+#pragma unroll
+    for (int i = 0; i < V_IT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const bool ok = v_use[i] && (full || kv0 + v_row[i] + r < a.Sk);
+        v_reg[i][r] = ok ? *reinterpret_cast<const uint4*>(vp[i] + (long)r * a.ldv)
+                         : make_uint4(0, 0, 0, 0);
+      }
+      vp[i] += (long)KV_T * a.ldv;
+    }
+  };
+  auto store_tile = [&](int stage) {
+    half_t* base = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < K_IT; ++i)
+      if (k_use[i]) *reinterpret_cast<uint4*>(base + k_dst[i]) = k_reg[i];
+#pragma unroll
+    for (int i = 0; i < V_IT; ++i)
+      if (v_use[i]) {
+        const half_t* e0 = reinterpret_cast<const half_t*>(&v_reg[i][0]);
+        const half_t* e1 = reinterpret_cast<const half_t*>(&v_reg[i][1]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          half2_t pr = {e0[e], e1[e]};
+          *reinterpret_cast<half2_t*>(base + v_dst[i] + e * VT_LD) = pr;
+        }
+      }
+  };
+
+  f32x4 oacc[QT][NDT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) oacc[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_ref[QT], l_run[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) { m_ref[qt] = NEG_BIG; l_run[qt] = 0.f; }
+  const float sc = a.scale_log2;
+  const int n_tiles = (a.Sk + KV_T - 1) / KV_T;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < n_tiles; ++t) {
+    if (t + 1 < n_tiles) load_tile((t + 1) * KV_T);
+    const half_t* Ks = smem + (t & 1) * STAGE;
+    const half_t* Vt = Ks + KV_T * K_LD;
+    const int kv0 = t * KV_T;
+    // ---- S^T = K Q^T (raw, unscaled)
+    f32x4 s[QT][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      half8_t kf[NDC];
+#pragma unroll
+      for (int dc = 0; dc < NDC; ++dc)
+        kf[dc] = *reinterpret_cast<const half8_t*>(Ks + (kt * 16 + c16) * K_LD + dc * 32 + g * 8);
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dc = 0; dc < NDC; ++dc)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[dc], qf[qt][dc], acc, 0, 0, 0);
+        s[qt][kt] = acc;
+      }
+    }
+    if (kv0 + KV_T > a.Sk) {  // ragged last tile
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kv0 + kt * 16 + g * 4 + r >= a.Sk) s[qt][kt][r] = NEG_BIG;
+    }
+    // ---- tile max per query, reference update vote
+    float mxs[QT];
+    bool raise = false;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float mx = fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), s[qt][0][2]);
+      mx = fmaxf(fmaxf(mx, s[qt][0][3]), s[qt][1][0]);
+      mx = fmaxf(fmaxf(mx, s[qt][1][1]), s[qt][1][2]);
+      mx = fmaxf(fmaxf(mx, s[qt][1][3]), s[qt][2][0]);
+      mx = fmaxf(fmaxf(mx, s[qt][2][1]), s[qt][2][2]);
+      mx = fmaxf(fmaxf(mx, s[qt][2][3]), s[qt][3][0]);
+      mx = fmaxf(fmaxf(mx, s[qt][3][1]), s[qt][3][2]);
+      mx = fmaxf(mx, s[qt][3][3]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mxs[qt] = mx * sc;
+      raise = raise || (mxs[qt] > m_ref[qt] + 8.f);
+    }
+    if (__builtin_amdgcn_ballot_w64(raise) != 0) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const float m_new = fmaxf(m_ref[qt], mxs[qt]);
+        const float alpha = __builtin_amdgcn_exp2f(m_ref[qt] - m_new);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oacc[qt][dt][r] *= alpha;
+        if (!ONES) l_run[qt] *= alpha;
+        m_ref[qt] = m_new;
+      }
+    }
+    // ---- P = exp2(s * scale - m_ref), packed to the fp16 B operand of the PV product
+    half8_t pf[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const float nm = -m_ref[qt];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[qt][kt][r], sc, nm));
+          if (!ONES) l_run[qt] += p;
+          pf[qt][kt >> 1][(kt & 1) * 4 + r] = (half_t)p;
+        }
+    }
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const half_t* vrow = Vt + (dt * 16 + c16) * VT_LD + c * 32 + g * 4;
+        half4_t lo = *reinterpret_cast<const half4_t*>(vrow);
+        half4_t hi = *reinterpret_cast<const half4_t*>(vrow + 16);
+        half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+          oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][c], oacc[qt][dt], 0, 0, 0);
+      }
+    // ---- next tile into the other stage (its last readers finished before the previous barrier)
+    if (t + 1 < n_tiles) store_tile((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns query q0 + qt*16 + c16, dv = dt*16 + g*4 + r
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float l;
+    if (ONES) {
+      const int dt_l = d >> 4, g_l = (d & 15) >> 2;
+      float lv = 0.f;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+        if (dt == dt_l) lv = oacc[qt][dt][0];
+      l = __shfl(lv, g_l * 16 + c16, 64);
+    } else {
+      l = l_run[qt];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
+    const int qrow = q0 + qt * 16 + c16;
+    if (qrow < a.Sq) {
+      const float inv = 1.f / l;
+      half_t* orow = a.o + (long)b * a.o_bs + (long)qrow * a.ldo + (long)h * d;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const int dv = dt * 16 + g * 4;
+        if (dv < d) {
+          half4_t o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (half_t)(oacc[qt][dt][r] * inv);
+          *reinterpret_cast<half4_t*>(orow + dv) = o;
+        }
+      }
+      if (a.lse && g == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow] = m_ref[qt] + log2f(l);
+    }
+  }
+}
+
 template <int DP, bool SAVE_P>
-void launch_attn_dp(const AttnArgs& a, dim3 grid, hipStream_t st) {
+void launch_attn_dp(const AttnArgs& a, hipStream_t st) {
   if constexpr (SAVE_P) {
+    dim3 grid((a.Sq + 63) / 64, a.H, a.B);
     hipLaunchKernelGGL((attn_fwd_kernel<DP, true, false>), grid, dim3(256), 0, st, a);
   } else {
-    if (a.d < DP) hipLaunchKernelGGL((attn_fwd_kernel<DP, false, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<DP, false, false>), grid, dim3(256), 0, st, a);
+    // two query tiles per wave once there are enough 128-query blocks to fill the chip
+    const bool qt2 = (long)((a.Sq + 127) / 128) * a.H * a.B >= 1024 && DP <= 96;
+    dim3 grid(qt2 ? (a.Sq + 127) / 128 : (a.Sq + 63) / 64, a.H, a.B);
+    if constexpr (DP <= 96) {
+      if (qt2) {
+        if (a.d < DP) hipLaunchKernelGGL((attn_self_kernel<DP, true, 2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_self_kernel<DP, false, 2>), grid, dim3(256), 0, st, a);
+        return;
+      }
+    }
+    if (a.d < DP) hipLaunchKernelGGL((attn_self_kernel<DP, true, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_self_kernel<DP, false, 1>), grid, dim3(256), 0, st, a);
   }
 }
 
 template <bool SAVE_P>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
-  dim3 grid((a.Sq + 63) / 64, a.H, a.B);
   const int d = a.d;
-  if (d <= 32) launch_attn_dp<32, SAVE_P>(a, grid, st);
-  else if (d <= 64) launch_attn_dp<64, SAVE_P>(a, grid, st);
-  else if (d <= 96) launch_attn_dp<96, SAVE_P>(a, grid, st);
-  else if (d <= 128) launch_attn_dp<128, SAVE_P>(a, grid, st);
-  else if (d <= 160) launch_attn_dp<160, SAVE_P>(a, grid, st);
+  if (d <= 32) launch_attn_dp<32, SAVE_P>(a, st);
+  else if (d <= 64) launch_attn_dp<64, SAVE_P>(a, st);
+  else if (d <= 96) launch_attn_dp<96, SAVE_P>(a, st);
+  else if (d <= 128) launch_attn_dp<128, SAVE_P>(a, st);
+  else if (d <= 160) launch_attn_dp<160, SAVE_P>(a, st);
   else return LGD_ERR_UNSUPPORTED;
   return lgd_check_launch();
 }
