@@ -16,6 +16,10 @@ STAMP = OUT + ".stamp"
 SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "attn_bwd.hip", "misc.hip", "energy.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-Wno-unused-value"]
+# Per-file extras.  The attention kernels run softmax VALU work on MFMA results every key tile: keep
+# the accumulators in VGPRs (not AGPRs) so that no v_accvgpr_read/write traffic is generated.
+EXTRA_FLAGS = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "attn_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _digest():
@@ -26,6 +30,7 @@ def _digest():
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -40,7 +45,7 @@ def build(force=False, verbose=True):
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for s in SOURCES:
         o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", os.path.join(CSRC, s), "-o", o]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(o)
     for s, p in procs:
