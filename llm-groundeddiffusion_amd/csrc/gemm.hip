@@ -40,8 +40,11 @@ __device__ __forceinline__ float4 ld_bias4(const float* p, int n) {
 // For GEGLU `v` holds the value accumulators and `g` the gate accumulators of the same columns.
 template <bool GEGLU>
 __device__ __forceinline__ void epilogue_store4(const LgdGemmDesc& d, long c_off, long r_off, int m,
-                                                int n_out, f32x4 v, f32x4 g, float4 bv, float4 bg) {
-  // bv / bg: summed biases of the value / gate columns (zeros when absent); n_out: output column.
+                                                int n_out, f32x4 v, f32x4 g, float4 bv, float4 bg,
+                                                bool res_ready = false,
+                                                half4_t res_pre = (half4_t){0, 0, 0, 0}) {
+  // bv / bg: summed biases of the value / gate columns (zeros when absent); n_out: output column;
+  // res_pre: the fp16 residual of these 4 outputs when the caller already fetched it (res_ready).
   v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
   if (GEGLU) {
     g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
@@ -51,7 +54,10 @@ __device__ __forceinline__ void epilogue_store4(const LgdGemmDesc& d, long c_off
   const float alpha = d.alpha;
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] *= alpha;
-  if (d.res) {
+  if (res_ready) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += (float)res_pre[r];
+  } else if (d.res) {
     if (d.epi & LGD_EPI_RES_F32) {
       const float* rp = reinterpret_cast<const float*>(d.res) + r_off + (long)m * d.ldr + n_out;
       float4 rv = *reinterpret_cast<const float4*>(rp);
@@ -129,17 +135,38 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& ga, f32x4 (&acc)[N
         }
       }
     }
-  } else {
+    return;
+  }
+  // fp16 residual (every resnet conv2 / attention out-projection / feed-forward down-projection):
+  // all MI x NI fetches are issued before the first one is consumed, so the epilogue pays one
+  // memory round trip, not MI x NI of them.  Out-of-range lanes fetch a clamped, valid address.
+  const bool res16 = d.res && !(d.epi & LGD_EPI_RES_F32);
+  half4_t rpre[NI][MI];
+  if (res16) {
+    const half_t* rb = reinterpret_cast<const half_t*>(d.res) + r_off;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const int n = n0 + wn * 16 * NI + ni * 16 + n_l;
-      if (n >= d.N) continue;
-      const float4 bv = ld_bias_sum4(d, n);
+      int n = n0 + wn * 16 * NI + ni * 16 + n_l;
+      if (n >= d.N) n = 0;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * 16 * MI + mi * 16 + m_l;
-        if (m < d.M) epilogue_store4<false>(d, c_off, r_off, m, n, acc[ni][mi], acc[ni][mi], bv, bv);
+        int m = m0 + wm * 16 * MI + mi * 16 + m_l;
+        if (m >= d.M) m = d.M - 1;
+        rpre[ni][mi] = *reinterpret_cast<const half4_t*>(rb + (long)m * d.ldr + n);
       }
+    }
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * 16 * NI + ni * 16 + n_l;
+    if (n >= d.N) continue;
+    const float4 bv = ld_bias_sum4(d, n);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + wm * 16 * MI + mi * 16 + m_l;
+      if (m < d.M)
+        epilogue_store4<false>(d, c_off, r_off, m, n, acc[ni][mi], acc[ni][mi], bv, bv, res16,
+                               res16 ? rpre[ni][mi] : (half4_t){0, 0, 0, 0});
     }
   }
 }

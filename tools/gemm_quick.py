@@ -20,10 +20,11 @@ for (M, N, K, taps, c0, c1, h, geglu) in SHAPES:
     n_out = N // 2 if geglu else N
     c = torch.empty(M, n_out, device=dev, dtype=torch.float16)
     bias = torch.zeros(N, device=dev)
+    res = torch.zeros(M, n_out, device=dev, dtype=torch.float16) if (os.environ.get("RES") and not geglu) else None
     best = None
     for tile in tiles:
         d = ops.gemm_desc(a0, w, c, M, N, K, c0=c0, c1=c1, lda0=c0, taps=taps, hin=h, win=h, hout=h, wout=h,
-                          bias=bias, epi=geglu, ldc=n_out, tile=tile, splits=None if tile == 0 else 1)
+                          bias=bias, res=res, ldr=n_out, epi=geglu, ldc=n_out, tile=tile, splits=None if tile == 0 else 1)
         try:
             ops.gemm_launch(d); torch.cuda.synchronize()
         except RuntimeError:
