@@ -17,6 +17,8 @@ constexpr int GN_MAXC = 2560;
 // quantities a, b) in LDS at [pixel lane][channel]; thread g < G then adds the channels of group g
 // over all pixel lanes in a fixed order.  (No float atomics: results are bit-reproducible.)
 constexpr int GN_PASS_C = 2048;   // channels covered by one pass of 256 8-channel vectors
+constexpr int GN_UNROLL = 4;      // pixels a thread has in flight per loop trip (apply passes)
+constexpr int GN_UNROLL_S = 8;    // same, forward statistics pass (one tensor, no stores)
 
 __device__ __forceinline__ void gn_group_reduce(float* s_a, float* s_b, const float (&a)[8],
                                                 const float (&b)[8], bool active, int slot, int c_lo,
@@ -76,14 +78,23 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
       const half_t* src = second ? x1 : x0;
       const int cc = second ? c - c0 : c;
       const int ld = second ? c1 : c0;
-      for (int p = p_beg + plane; p < p_end; p += pl) {
-        half8_t h = *reinterpret_cast<const half8_t*>(src + ((long)b * HW + p) * ld + cc);
+      // GN_UNROLL_S independent 16-byte loads in flight per thread (zeros past the chunk end)
+      for (int p = p_beg + plane; p < p_end; p += GN_UNROLL_S * pl) {
+        half8_t h[GN_UNROLL_S];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float f = (float)h[e];
-          s[e] += f;
-          q[e] += f * f;
+        for (int u = 0; u < GN_UNROLL_S; ++u) {
+          const int pp = p + u * pl;
+          h[u] = pp < p_end ? *reinterpret_cast<const half8_t*>(src + ((long)b * HW + pp) * ld + cc)
+                            : (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
         }
+#pragma unroll
+        for (int u = 0; u < GN_UNROLL_S; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float f = (float)h[u][e];
+            s[e] += f;
+            q[e] += f * f;
+          }
       }
     }
     gn_group_reduce(s_a, s_b, s, q, active, plane * c_n + (v * 8 - c_lo), c_lo, c_n, pl, cpg, G, acc_s, acc_q);
@@ -106,7 +117,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
                                                         const float* __restrict__ part, int nchunk,
                                                         float* stats, int napply) {
   __shared__ float s_mean[64], s_rstd[64];
-  __shared__ float s_a[GN_MAXC], s_b[GN_MAXC];
   const int C = c0 + c1;
   const int cpg = C / G;
   const int b = blockIdx.y;
@@ -142,35 +152,54 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    int g = c / cpg;
-    float a = s_rstd[g] * gamma[c];
-    s_a[c] = a;
-    s_b[c] = beta[c] - s_mean[g] * a;
-  }
-  __syncthreads();
+  // A thread owns a fixed 8-channel column (scale/shift in registers) and walks the block's pixels
+  // GN_UNROLL at a time: no per-element index division, no LDS traffic in the streaming loop.
   const int p_per = (HW + napply - 1) / napply;
   const int p_beg = blockIdx.x * p_per;
   int p_end = p_beg + p_per;
   if (p_end > HW) p_end = HW;
   const int nvec = C / 8;
-  const long total = (long)(p_end - p_beg) * nvec;
-  for (long idx = threadIdx.x; idx < total; idx += 256) {
-    int p = p_beg + (int)(idx / nvec);
-    int c = (int)(idx % nvec) * 8;
+  const int vs = nvec < 256 ? nvec : 256;
+  const int pl = 256 / vs;
+  const int plane = threadIdx.x / vs;
+  const int n_pass = (nvec + vs - 1) / vs;
+  for (int pass = 0; pass < n_pass; ++pass) {
+    const int v = threadIdx.x % vs + pass * vs;
+    if (v >= nvec || plane >= pl) continue;
+    const int c = v * 8;
+    float sa[8], sb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (c + e) / cpg;
+      sa[e] = s_rstd[g] * gamma[c + e];
+      sb[e] = beta[c + e] - s_mean[g] * sa[e];
+    }
     const bool second = c >= c0;
     const half_t* src = second ? x1 : x0;
     const int cc = second ? c - c0 : c;
     const int ld = second ? c1 : c0;
-    half8_t h = *reinterpret_cast<const half8_t*>(src + ((long)b * HW + p) * ld + cc);
-    half8_t o;
+    for (int p = p_beg + plane; p < p_end; p += GN_UNROLL * pl) {
+      half8_t h[GN_UNROLL];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float f = (float)h[e] * s_a[c + e] + s_b[c + e];
-      if (silu) f = silu_f(f);
-      o[e] = (half_t)f;
+      for (int u = 0; u < GN_UNROLL; ++u) {
+        const int pp = p + u * pl;
+        if (pp < p_end) h[u] = *reinterpret_cast<const half8_t*>(src + ((long)b * HW + pp) * ld + cc);
+      }
+#pragma unroll
+      for (int u = 0; u < GN_UNROLL; ++u) {
+        const int pp = p + u * pl;
+        if (pp < p_end) {
+          half8_t o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float f = (float)h[u][e] * sa[e] + sb[e];
+            if (silu) f = silu_f(f);
+            o[e] = (half_t)f;
+          }
+          *reinterpret_cast<half8_t*>(y + ((long)b * HW + pp) * C + c) = o;
+        }
+      }
     }
-    *reinterpret_cast<half8_t*>(y + ((long)b * HW + p) * C + c) = o;
   }
 }
 
@@ -221,18 +250,30 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(
         gm[e] = gamma[c + e];
         bt[e] = beta[c + e];
       }
-      for (int p = p_beg + plane; p < p_end; p += pl) {
-        half8_t hx = *reinterpret_cast<const half8_t*>(src + ((long)b * HW + p) * ld + cc);
-        half8_t hg = *reinterpret_cast<const half8_t*>(gy + ((long)b * HW + p) * C + c);
+      for (int p = p_beg + plane; p < p_end; p += GN_UNROLL * pl) {
+        half8_t hx[GN_UNROLL], hg[GN_UNROLL];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float xh = ((float)hx[e] - mean[e]) * rstd[e];
-          float dz = (float)hg[e];
-          if (silu) dz *= silu_grad_f(gm[e] * xh + bt[e]);
-          float dxh = dz * gm[e];
-          a1[e] += dxh;
-          a2[e] += dxh * xh;
+        for (int u = 0; u < GN_UNROLL; ++u) {
+          const int pp = p + u * pl;
+          if (pp < p_end) {
+            hx[u] = *reinterpret_cast<const half8_t*>(src + ((long)b * HW + pp) * ld + cc);
+            hg[u] = *reinterpret_cast<const half8_t*>(gy + ((long)b * HW + pp) * C + c);
+          } else {
+            hg[u] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};  // zero gradient: contributes nothing
+            hx[u] = hg[u];
+          }
         }
+#pragma unroll
+        for (int u = 0; u < GN_UNROLL; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float xh = ((float)hx[u][e] - mean[e]) * rstd[e];
+            float dz = (float)hg[u][e];
+            if (silu) dz *= silu_grad_f(gm[e] * xh + bt[e]);
+            float dxh = dz * gm[e];
+            a1[e] += dxh;
+            a2[e] += dxh * xh;
+          }
       }
     }
     gn_group_reduce(s_a, s_b, a1, a2, active, plane * c_n + (v * 8 - c_lo), c_lo, c_n, pl, cpg, G, acc_1, acc_2);
@@ -280,35 +321,61 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
   int p_end = p_beg + p_per;
   if (p_end > HW) p_end = HW;
   const int nvec = C / 8;
-  const long total = (long)(p_end - p_beg) * nvec;
-  for (long idx = threadIdx.x; idx < total; idx += 256) {
-    int p = p_beg + (int)(idx / nvec);
-    int c = (int)(idx % nvec) * 8;
+  const int vs = nvec < 256 ? nvec : 256;
+  const int pl = 256 / vs;
+  const int plane = threadIdx.x / vs;
+  const int n_pass = (nvec + vs - 1) / vs;
+  for (int pass = 0; pass < n_pass; ++pass) {
+    const int v = threadIdx.x % vs + pass * vs;
+    if (v >= nvec || plane >= pl) continue;
+    const int c = v * 8;
+    float mean[8], rstd[8], gm[8], bt[8], m1[8], m2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (c + e) / cpg;
+      mean[e] = stats[((long)b * G + g) * 2];
+      rstd[e] = stats[((long)b * G + g) * 2 + 1];
+      gm[e] = gamma[c + e];
+      bt[e] = beta[c + e];
+      m1[e] = s_m1[g];
+      m2[e] = s_m2[g];
+    }
     const bool second = c >= c0;
     const half_t* src = second ? x1 : x0;
     half_t* dst = second ? gx1 : gx0;
     const int cc = second ? c - c0 : c;
     const int ld = second ? c1 : c0;
-    const long off = ((long)b * HW + p) * ld + cc;
-    half8_t hx = *reinterpret_cast<const half8_t*>(src + off);
-    half8_t hg = *reinterpret_cast<const half8_t*>(gy + ((long)b * HW + p) * C + c);
-    half8_t o;
-    if (accumulate) o = *reinterpret_cast<const half8_t*>(dst + off);
+    for (int p = p_beg + plane; p < p_end; p += 2 * pl) {
+      half8_t hx[2], hg[2], ho[2];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int g = (c + e) / cpg;
-      float mean = stats[((long)b * G + g) * 2];
-      float rstd = stats[((long)b * G + g) * 2 + 1];
-      float gm = gamma[c + e];
-      float xh = ((float)hx[e] - mean) * rstd;
-      float dz = (float)hg[e];
-      if (silu) dz *= silu_grad_f(gm * xh + beta[c + e]);
-      float dxh = dz * gm;
-      float dx = rstd * (dxh - s_m1[g] - xh * s_m2[g]);
-      if (accumulate) dx += (float)o[e];
-      o[e] = (half_t)dx;
+      for (int u = 0; u < 2; ++u) {
+        const int pp = p + u * pl;
+        if (pp < p_end) {
+          const long off = ((long)b * HW + pp) * ld + cc;
+          hx[u] = *reinterpret_cast<const half8_t*>(src + off);
+          hg[u] = *reinterpret_cast<const half8_t*>(gy + ((long)b * HW + pp) * C + c);
+          if (accumulate) ho[u] = *reinterpret_cast<const half8_t*>(dst + off);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int pp = p + u * pl;
+        if (pp < p_end) {
+          half8_t o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float xh = ((float)hx[u][e] - mean[e]) * rstd[e];
+            float dz = (float)hg[u][e];
+            if (silu) dz *= silu_grad_f(gm[e] * xh + bt[e]);
+            float dxh = dz * gm[e];
+            float dx = rstd[e] * (dxh - m1[e] - xh * m2[e]);
+            if (accumulate) dx += (float)ho[u][e];
+            o[e] = (half_t)dx;
+          }
+          *reinterpret_cast<half8_t*>(dst + ((long)b * HW + pp) * ld + cc) = o;
+        }
+      }
     }
-    *reinterpret_cast<half8_t*>(dst + off) = o;
   }
 }
 
@@ -424,6 +491,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   }
 }
 
+// Workgroups per image of the apply passes: about 1024 workgroups in total, at least one full
+// GN_UNROLL trip of pixels per thread.
+int gn_apply_blocks(int B, int HW, int C) {
+  const int nvec = C / 8;
+  const int pl = nvec < 256 ? 256 / nvec : 1;
+  int px = GN_UNROLL * pl;
+  const int want = (int)(((long)HW * B + 1023) / 1024);
+  if (px < want) px = want;
+  int n = (HW + px - 1) / px;
+  return n < 1 ? 1 : n;
+}
+
 }  // namespace
 
 extern "C" int lgd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, int B, int HW,
@@ -436,9 +515,7 @@ extern "C" int lgd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1,
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, st, (const half_t*)x0,
                      (const half_t*)x1, c0, c1, HW, G, part, nchunk);
-  int napply = (int)(((long)HW * C / 8 + 2047) / 2048);  // ~8 vectors per thread
-  if (napply < 1) napply = 1;
-  if (napply > HW) napply = HW;
+  const int napply = gn_apply_blocks(B, HW, C);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(napply, B), dim3(256), 0, st, (const half_t*)x0,
                      (const half_t*)x1, c0, c1, HW, G, eps, gamma, beta, silu, (half_t*)y, part,
                      nchunk, stats, napply);
@@ -456,9 +533,7 @@ extern "C" int lgd_groupnorm_bwd_f16(const void* gy, const void* x0, const void*
   hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nchunk, B), dim3(256), 0, st, (const half_t*)gy,
                      (const half_t*)x0, (const half_t*)x1, c0, c1, HW, G, gamma, beta, silu, stats,
                      part, nchunk);
-  int napply = (int)(((long)HW * C / 8 + 2047) / 2048);
-  if (napply < 1) napply = 1;
-  if (napply > HW) napply = HW;
+  const int napply = gn_apply_blocks(B, HW, C);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(napply, B), dim3(256), 0, st, (const half_t*)gy,
                      (const half_t*)x0, (const half_t*)x1, c0, c1, HW, G, gamma, beta, silu, stats,
                      (half_t*)gx0, (half_t*)gx1, part, nchunk, accumulate, napply);

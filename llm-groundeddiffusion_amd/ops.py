@@ -250,8 +250,9 @@ def conv_out(x, w, bias, B, L, out=None, out_scale=1.0):
 # norms
 # ---------------------------------------------------------------------------------------------
 def gn_chunks(B, HW):
-    n = max(1, min(HW // 16, max(1, 512 // max(B, 1))))
-    return min(n, 256)
+    """Pixel chunks per image of the GroupNorm statistics pass (>= 8 pixels each, at most 64 so that the
+    partial table [B, nchunk, G, 2] every apply workgroup re-reduces stays at 16 KB per image)."""
+    return max(1, min(HW // 8, 1024 // max(B, 1), 64))
 
 
 def groupnorm(x, B, HW, G, eps, gamma, beta, silu, *, x1=None, out=None, part=None, stats=None):

@@ -10,7 +10,10 @@ SHAPES = [  # (M, N, K, taps, c0, c1, h, geglu)
     (4096, 1280, 11520, 9, 1280, 0, 16, 0), (1024, 1280, 11520, 9, 1280, 0, 8, 0), (65536, 2560, 320, 1, 320, 0, 0, 1),
     (16384, 5120, 640, 1, 640, 0, 0, 1), (65536, 320, 1280, 1, 1280, 0, 0, 0), (65536, 320, 320, 1, 320, 0, 0, 0),
     (65536, 960, 320, 1, 320, 0, 0, 0), (4096, 1280, 1280, 1, 1280, 0, 0, 0), (32768, 320, 5760, 9, 640, 0, 64, 0),
+    (1024, 1280, 1280, 1, 1280, 0, 0, 0), (256, 1280, 1280, 1, 1280, 0, 0, 0), (256, 1280, 11520, 9, 1280, 0, 8, 0),
+    (64, 1280, 11520, 9, 1280, 0, 8, 0), (16384, 640, 640, 1, 640, 0, 0, 0),
 ]
+if os.environ.get("SMALL"): SHAPES = [s for s in SHAPES if s[0] <= 4096 or s[2] <= 640]
 tiles = [int(x) for x in os.environ.get("TILES", "0").split(",")]
 tot = 0.0
 for (M, N, K, taps, c0, c1, h, geglu) in SHAPES:
@@ -24,7 +27,8 @@ for (M, N, K, taps, c0, c1, h, geglu) in SHAPES:
     best = None
     for tile in tiles:
         d = ops.gemm_desc(a0, w, c, M, N, K, c0=c0, c1=c1, lda0=c0, taps=taps, hin=h, win=h, hout=h, wout=h,
-                          bias=bias, res=res, ldr=n_out, epi=geglu, ldc=n_out, tile=tile, splits=None if tile == 0 else 1)
+                          bias=bias, res=res, ldr=n_out, epi=geglu, ldc=n_out, tile=tile,
+                          splits=None if tile == 0 else int(os.environ.get("SPLITS", "1")))
         try:
             ops.gemm_launch(d); torch.cuda.synchronize()
         except RuntimeError:
