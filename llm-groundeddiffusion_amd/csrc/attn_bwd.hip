@@ -405,6 +405,175 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const CrossBwdArgs 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cross-attention dQ on the matrix cores (Sk <= 96, i.e. the 77 text tokens).  grid =
+// (ceil(Sq/256), H, B); K, V (row-major) and K^T of the head are staged in LDS once per workgroup,
+// then every wave walks 16-query tiles.  All <= 96 keys of a query sit in registers at once (6
+// accumulator tiles, lane = query lane&15, keys kt*16 + (lane>>4)*4 + r), so the softmax is exact,
+// not online:
+//   S^T = K Q^T, dP^T = V gO^T (+ gP read from the fp32 map gradient), P = softmax(scale S),
+//   dS = P o (dP - sum_k P dP) * scale, dQ^T = K^T dS^T (permuted contraction order of tr_frag).
+// ---------------------------------------------------------------------------------------------
+constexpr int XM_KEYS = 96;
+constexpr int XM_LD = XM_KEYS + 8;  // halfs per row of the transposed K image
+
+template <int DP>
+__global__ __launch_bounds__(256) void cross_attn_bwd_mfma_kernel(const CrossBwdArgs a) {
+  constexpr int K_LD = DP + 8;
+  constexpr int NDC = DP / 32, NDT = DP / 16, KSEG = DP / 8;
+  constexpr int NKT = XM_KEYS / 16;
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  half_t* Ks = reinterpret_cast<half_t*>(dyn_smem);
+  half_t* Vs = Ks + XM_KEYS * K_LD;
+  half_t* Kt = Vs + XM_KEYS * K_LD;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int d = a.d, Sk = a.Sk;
+  const half_t* Kb = a.k + (long)b * a.k_bs + (long)h * d;
+  const half_t* Vb = a.v + (long)b * a.v_bs + (long)h * d;
+
+  // ---- stage K, V, K^T (zero padded to 96 keys x DP)
+  for (int idx = tid; idx < XM_KEYS * KSEG; idx += 256) {
+    const int row = idx / KSEG, seg = idx - row * KSEG;
+    const bool ok = row < Sk && seg * 8 < d;
+    const uint4 kk = ok ? *reinterpret_cast<const uint4*>(Kb + (long)row * a.ldk + seg * 8) : make_uint4(0, 0, 0, 0);
+    const uint4 vv = ok ? *reinterpret_cast<const uint4*>(Vb + (long)row * a.ldv + seg * 8) : make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(Ks + row * K_LD + seg * 8) = kk;
+    *reinterpret_cast<uint4*>(Vs + row * K_LD + seg * 8) = vv;
+    const half_t* e = reinterpret_cast<const half_t*>(&kk);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Kt[(seg * 8 + j) * XM_LD + row] = e[j];
+  }
+  __syncthreads();
+
+  const float sl2 = a.scale * 1.4426950408889634f;
+  const int q_blk = blockIdx.x * 256;
+  for (int it = 0; it < 4; ++it) {
+    const int qrow = q_blk + it * 64 + wid * 16 + c16;
+    if (q_blk + it * 64 + wid * 16 >= a.Sq) break;  // wave-uniform
+    const bool q_ok = qrow < a.Sq;
+    half8_t qf[NDC], gof[NDC];
+#pragma unroll
+    for (int dc = 0; dc < NDC; ++dc) {
+      const int dd = dc * 32 + g * 8;
+      qf[dc] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+      gof[dc] = qf[dc];
+      if (q_ok && dd < d) {
+        qf[dc] = *reinterpret_cast<const half8_t*>(a.q + (long)b * a.q_bs + (long)qrow * a.ldq + (long)h * d + dd);
+        if (a.go)
+          gof[dc] = *reinterpret_cast<const half8_t*>(a.go + (long)b * a.go_bs + (long)qrow * a.ldgo + (long)h * d + dd);
+      }
+    }
+    f32x4 sv[NKT], dp[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dc = 0; dc < NDC; ++dc) {
+        half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kt * 16 + c16) * K_LD + dc * 32 + g * 8);
+        half8_t vf = *reinterpret_cast<const half8_t*>(Vs + (kt * 16 + c16) * K_LD + dc * 32 + g * 8);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[dc], s, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, gof[dc], t, 0, 0, 0);
+      }
+      sv[kt] = s;
+      dp[kt] = t;
+    }
+    // ---- exact softmax over the (masked) keys of query c16
+    float mx = -1.0e30f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (kt * 16 + g * 4 + r >= Sk) sv[kt][r] = -1.0e30f;
+        mx = fmaxf(mx, sv[kt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float nm = -mx * sl2;
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(sv[kt][r], sl2, nm));
+        sv[kt][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    if (a.gp && q_ok) {
+      const float* gpr = a.gp + (((long)b * a.H + h) * a.Sq + qrow) * Sk;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + g * 4 + r;
+          if (key < Sk) dp[kt][r] += gpr[key];
+        }
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sv[kt][r] *= inv;
+        dot += sv[kt][r] * dp[kt][r];
+      }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+    // ---- dQ^T = K^T dS^T
+    f32x4 dq[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NKT / 2; ++c) {
+      half8_t dsf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dsf[r] = (half_t)(sv[2 * c][r] * (dp[2 * c][r] - dot) * a.scale);
+        dsf[4 + r] = (half_t)(sv[2 * c + 1][r] * (dp[2 * c + 1][r] - dot) * a.scale);
+      }
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const half_t* pk = Kt + (dt * 16 + c16) * XM_LD + c * 32 + g * 4;
+        half4_t lo = *reinterpret_cast<const half4_t*>(pk);
+        half4_t hi = *reinterpret_cast<const half4_t*>(pk + 16);
+        half8_t ktf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ktf, dsf, dq[dt], 0, 0, 0);
+      }
+    }
+    if (q_ok) {
+      half_t* out = a.gq + (long)b * a.gq_bs + (long)qrow * a.ldgq + (long)h * d;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const int dv = dt * 16 + g * 4;
+        if (dv < d) {
+          half4_t o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (half_t)dq[dt][r];
+          *reinterpret_cast<half4_t*>(out + dv) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int DP>
+int launch_cross_bwd_mfma(const CrossBwdArgs& a, hipStream_t st) {
+  const size_t smem = (size_t)(2 * XM_KEYS * (DP + 8) + DP * XM_LD) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn_bwd_mfma_kernel<DP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((cross_attn_bwd_mfma_kernel<DP>), dim3((a.Sq + 255) / 256, a.H, a.B), dim3(256), smem, st, a);
+  return lgd_check_launch();
+}
+
 template <int DP>
 int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
   constexpr int K_LD = DP + 8;
@@ -478,6 +647,14 @@ extern "C" int lgd_cross_attn_bwd_f16(const void* q, int64_t ldq, int64_t q_bs, 
   a.gp = gp;
   a.gq = (half_t*)gq; a.ldgq = ldgq; a.gq_bs = gq_bs;
   a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.d = d; a.scale = scale;
+  hipStream_t st_ = reinterpret_cast<hipStream_t>(stream);
+  if (Sk <= XM_KEYS && d <= 160 && (ldq % 8) == 0 && (ldgo % 8) == 0 && (ldgq % 4) == 0) {
+    if (d <= 32) return launch_cross_bwd_mfma<32>(a, st_);
+    if (d <= 64) return launch_cross_bwd_mfma<64>(a, st_);
+    if (d <= 96) return launch_cross_bwd_mfma<96>(a, st_);
+    if (d <= 128) return launch_cross_bwd_mfma<128>(a, st_);
+    return launch_cross_bwd_mfma<160>(a, st_);
+  }
   const int ld = d + 2;
   size_t smem = (size_t)(2 * Sk * ld + 2) * 2 + (size_t)4 * 2 * XB_MAXD * 4 + (size_t)4 * XB_MAXSK * 4;
   smem = (smem + 15) & ~(size_t)15;

@@ -265,7 +265,7 @@ def test_cross_attn_maps(dev, B, H, Sq, d, tok, cond_only):
 
 @pytest.mark.parametrize("B,H,Sq,d,with_go,with_gp", [
     (1, 8, 256, 160, True, True), (1, 8, 64, 160, False, True), (2, 8, 1024, 80, True, False),
-    (1, 8, 100, 8, True, True),
+    (1, 8, 100, 8, True, True), (2, 8, 4096, 40, True, False), (1, 8, 300, 40, True, True),
 ])
 def test_cross_attn_bwd(dev, B, H, Sq, d, with_go, with_gp):
     Sk, C = 77, H * d
