@@ -21,35 +21,57 @@ namespace {
 constexpr int T64 = 64;
 constexpr int TR_LD = T64 + 8;  // halfs per row of a transposed tile
 
-// Stage a tile of 64 rows x DP (zero padded beyond `nrows`/`d`) from global into LDS, row-major
-// (`rm`, leading dim DP+8) and/or transposed (`tr`, [DP][72]).  All 256 threads participate.
-template <int DP, bool RM, bool TR>
-__device__ __forceinline__ void stage_tile(const half_t* __restrict__ src, long ld, int row0,
-                                           int nrows, int d, half_t* rm, half_t* tr) {
-  constexpr int KSEG = DP / 8;
-  constexpr int ITEMS = (T64 / 2) * KSEG;
-  for (int idx = threadIdx.x; idx < ITEMS; idx += 256) {
-    const int pair = idx & 31, seg = idx >> 5;
-    uint4 v[2];
+// Tile staging, split into a global->register half and a register->LDS half so that the loads of
+// tile t+1 are in flight while tile t is multiplied.  A tile is 64 rows x DP; a thread owns
+// (row pair, 8-column segment) items, which lets the transposed image be written as 4-byte
+// (row pair) stores.  Rows past `nrows` and columns past `d` are zero.
+template <int DP>
+struct PairTile {
+  static constexpr int KSEG = DP / 8;
+  static constexpr int ITEMS = (T64 / 2) * KSEG;
+  static constexpr int IT = (ITEMS + 255) / 256;
+  uint4 v[IT][2];
+
+  __device__ __forceinline__ void load(const half_t* __restrict__ src, long ld, int row0, int nrows, int d) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      int row = pair * 2 + r;
-      bool ok = (row0 + row < nrows) && (seg * 8 < d);
-      v[r] = ok ? *reinterpret_cast<const uint4*>(src + (long)(row0 + row) * ld + seg * 8)
-                : make_uint4(0, 0, 0, 0);
-      if (RM) *reinterpret_cast<uint4*>(rm + row * (DP + 8) + seg * 8) = v[r];
-    }
-    if (TR) {
-      const half_t* e0 = reinterpret_cast<const half_t*>(&v[0]);
-      const half_t* e1 = reinterpret_cast<const half_t*>(&v[1]);
+    for (int i = 0; i < IT; ++i) {
+      const int idx = threadIdx.x + i * 256;
+      const int pair = idx & 31, seg = idx >> 5;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        half2_t pr = {e0[e], e1[e]};
-        *reinterpret_cast<half2_t*>(tr + (seg * 8 + e) * TR_LD + pair * 2) = pr;
+      for (int r = 0; r < 2; ++r) {
+        const int row = row0 + pair * 2 + r;
+        const bool ok = idx < ITEMS && row < nrows && seg * 8 < d;
+        v[i][r] = ok ? *reinterpret_cast<const uint4*>(src + (long)row * ld + seg * 8) : make_uint4(0, 0, 0, 0);
       }
     }
   }
-}
+  template <bool RM, bool TR>
+  __device__ __forceinline__ void store(half_t* rm, half_t* tr) const {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int idx = threadIdx.x + i * 256;
+      if (idx >= ITEMS) continue;
+      const int pair = idx & 31, seg = idx >> 5;
+      if (RM) {
+        *reinterpret_cast<uint4*>(rm + (pair * 2) * (DP + 8) + seg * 8) = v[i][0];
+        *reinterpret_cast<uint4*>(rm + (pair * 2 + 1) * (DP + 8) + seg * 8) = v[i][1];
+      }
+      if (TR) {
+        // (row 2p, row 2p+1) halves of column seg*8+e packed into one dword, by integer ops on the
+        // loaded words (no address-taken register arrays: those end up in scratch)
+        const uint32_t w0[4] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w};
+        const uint32_t w1[4] = {v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t even = (w0[j] & 0xffffu) | (w1[j] << 16);
+          const uint32_t odd = (w0[j] >> 16) | (w1[j] & 0xffff0000u);
+          *reinterpret_cast<uint32_t*>(tr + (seg * 8 + 2 * j) * TR_LD + pair * 2) = even;
+          *reinterpret_cast<uint32_t*>(tr + (seg * 8 + 2 * j + 1) * TR_LD + pair * 2) = odd;
+        }
+      }
+    }
+  }
+};
 
 struct AttnBwdArgs {
   const half_t* q; long ldq, q_bs;
@@ -75,7 +97,9 @@ __device__ __forceinline__ half8_t tr_frag(const half_t* tr, int row, int c, int
   return (half8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int DP>
+// dQ.  Each wave owns QT x 16 queries (K / V / K^T fragments read from LDS feed QT MFMAs each);
+// the next key tile is fetched into registers while the current one is multiplied.
+template <int DP, int QT>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
   constexpr int K_LD = DP + 8;
   constexpr int NDC = DP / 32, NDT = DP / 16;
@@ -88,96 +112,143 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
   const int g = lane >> 4, c16 = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
   const int d = a.d;
-  const int qrow = blockIdx.x * 64 + wid * 16 + c16;
-  const bool q_ok = qrow < a.Sq;
+  const int q0 = blockIdx.x * (64 * QT) + wid * (16 * QT);
   const half_t* Qb = a.q + (long)b * a.q_bs + (long)h * d;
   const half_t* Kb = a.k + (long)b * a.k_bs + (long)h * d;
   const half_t* Vb = a.v + (long)b * a.v_bs + (long)h * d;
   const half_t* Ob = a.o + (long)b * a.o_bs + (long)h * d;
   const half_t* GOb = a.go + (long)b * a.go_bs + (long)h * d;
 
-  half8_t qf[NDC], dof[NDC];
-  float delta = 0.f;
+  half8_t qf[QT][NDC], dof[QT][NDC];
+  float delta[QT], nlse[QT];
 #pragma unroll
-  for (int dc = 0; dc < NDC; ++dc) {
-    const int dd = dc * 32 + g * 8;
-    if (q_ok && dd < d) {
-      qf[dc] = *reinterpret_cast<const half8_t*>(Qb + (long)qrow * a.ldq + dd);
-      dof[dc] = *reinterpret_cast<const half8_t*>(GOb + (long)qrow * a.ldgo + dd);
-      half8_t of = *reinterpret_cast<const half8_t*>(Ob + (long)qrow * a.ldo + dd);
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qrow = q0 + qt * 16 + c16;
+    const bool q_ok = qrow < a.Sq;
+    float dl = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) delta += (float)dof[dc][e] * (float)of[e];
-    } else {
-      qf[dc] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
-      dof[dc] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    for (int dc = 0; dc < NDC; ++dc) {
+      const int dd = dc * 32 + g * 8;
+      if (q_ok && dd < d) {
+        qf[qt][dc] = *reinterpret_cast<const half8_t*>(Qb + (long)qrow * a.ldq + dd);
+        dof[qt][dc] = *reinterpret_cast<const half8_t*>(GOb + (long)qrow * a.ldgo + dd);
+        half8_t of = *reinterpret_cast<const half8_t*>(Ob + (long)qrow * a.ldo + dd);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)dof[qt][dc][e] * (float)of[e];
+      } else {
+        qf[qt][dc] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+        dof[qt][dc] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+      }
     }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    const long stat_idx = ((long)b * a.H + h) * a.Sq + qrow;
+    if (q_ok && g == 0) a.delta[stat_idx] = dl;
+    delta[qt] = dl;
+    nlse[qt] = q_ok ? -a.lse[stat_idx] : 0.f;
   }
-  delta += __shfl_xor(delta, 16, 64);
-  delta += __shfl_xor(delta, 32, 64);
-  const long stat_idx = ((long)b * a.H + h) * a.Sq + qrow;
-  if (q_ok && g == 0) a.delta[stat_idx] = delta;
-  const float lse = q_ok ? a.lse[stat_idx] : 0.f;
 
-  f32x4 dq[NDT];
+  f32x4 dq[QT][NDT];
 #pragma unroll
-  for (int dt = 0; dt < NDT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) dq[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  const float sl2 = a.scale_log2;
   const int n_tiles = (a.Sk + T64 - 1) / T64;
+  PairTile<DP> kreg, vreg;
+  kreg.load(Kb, a.ldk, 0, a.Sk, d);
+  vreg.load(Vb, a.ldv, 0, a.Sk, d);
+  kreg.template store<true, true>(Ks, Kt);
+  vreg.template store<true, false>(Vs, nullptr);
+  __syncthreads();
   for (int t = 0; t < n_tiles; ++t) {
     const int kv0 = t * T64;
-    __syncthreads();
-    stage_tile<DP, true, true>(Kb, a.ldk, kv0, a.Sk, d, Ks, Kt);
-    stage_tile<DP, true, false>(Vb, a.ldv, kv0, a.Sk, d, Vs, nullptr);
-    __syncthreads();
-    f32x4 ds[4];
+    if (t + 1 < n_tiles) {
+      kreg.load(Kb, a.ldk, kv0 + T64, a.Sk, d);
+      vreg.load(Vb, a.ldv, kv0 + T64, a.Sk, d);
+    }
+    f32x4 ds[QT][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      half8_t kf[NDC], vf[NDC];
 #pragma unroll
       for (int dc = 0; dc < NDC; ++dc) {
-        half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kt * 16 + c16) * K_LD + dc * 32 + g * 8);
-        half8_t vf = *reinterpret_cast<const half8_t*>(Vs + (kt * 16 + c16) * K_LD + dc * 32 + g * 8);
-        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[dc], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, dof[dc], dp, 0, 0, 0);
+        kf[dc] = *reinterpret_cast<const half8_t*>(Ks + (kt * 16 + c16) * K_LD + dc * 32 + g * 8);
+        vf[dc] = *reinterpret_cast<const half8_t*>(Vs + (kt * 16 + c16) * K_LD + dc * 32 + g * 8);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int key = kv0 + kt * 16 + g * 4 + r;
-        float p = (key < a.Sk && q_ok) ? exp2f(s[r] * a.scale_log2 - lse) : 0.f;
-        ds[kt][r] = p * (dp[r] - delta);
+      for (int qt = 0; qt < QT; ++qt) {
+        f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dc = 0; dc < NDC; ++dc) {
+          sv = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[dc], qf[qt][dc], sv, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dc], dof[qt][dc], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sv[r], sl2, nlse[qt]));
+          ds[qt][kt][r] = pv * (dp[r] - delta[qt]);
+        }
       }
+    }
+    if (kv0 + T64 > a.Sk) {  // ragged last tile: padded keys carry no gradient
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kv0 + kt * 16 + g * 4 + r >= a.Sk) ds[qt][kt][r] = 0.f;
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      half8_t dsf;
+      half8_t dsf[QT];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        dsf[r] = (half_t)ds[2 * c][r];
-        dsf[4 + r] = (half_t)ds[2 * c + 1][r];
-      }
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dsf[qt][r] = (half_t)ds[qt][2 * c][r];
+          dsf[qt][4 + r] = (half_t)ds[qt][2 * c + 1][r];
+        }
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
         half8_t ktf = tr_frag(Kt, dt * 16 + c16, c, g);
-        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ktf, dsf, dq[dt], 0, 0, 0);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+          dq[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ktf, dsf[qt], dq[qt][dt], 0, 0, 0);
       }
     }
+    __syncthreads();
+    if (t + 1 < n_tiles) {
+      kreg.template store<true, true>(Ks, Kt);
+      vreg.template store<true, false>(Vs, nullptr);
+      __syncthreads();
+    }
   }
-  if (q_ok) {
-    half_t* out = a.gq + (long)b * a.gq_bs + (long)qrow * a.ldgq + (long)h * d;
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-      const int dv = dt * 16 + g * 4;
-      if (dv < d) {
-        half4_t o;
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qrow = q0 + qt * 16 + c16;
+    if (qrow < a.Sq) {
+      half_t* out = a.gq + (long)b * a.gq_bs + (long)qrow * a.ldgq + (long)h * d;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (half_t)(dq[dt][r] * a.scale);
-        *reinterpret_cast<half4_t*>(out + dv) = o;
+      for (int dt = 0; dt < NDT; ++dt) {
+        const int dv = dt * 16 + g * 4;
+        if (dv < d) {
+          half4_t o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (half_t)(dq[qt][dt][r] * a.scale);
+          *reinterpret_cast<half4_t*>(out + dv) = o;
+        }
       }
     }
   }
 }
 
-template <int DP>
+// dK, dV.  Each wave owns KT x 16 keys; loops over query tiles (Q, dO row-major and transposed,
+// lse and delta in LDS), next tile prefetched into registers.  Padded query rows are all-zero in
+// Q and dO, so they contribute nothing whatever their recomputed probability is.
+template <int DP, int KT>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
   constexpr int K_LD = DP + 8;
   constexpr int NDC = DP / 32, NDT = DP / 16;
@@ -186,15 +257,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
   half_t* Gs = Qs + T64 * K_LD;          // dO row-major
   half_t* Qt = Gs + T64 * K_LD;          // Q transposed [d][q]
   half_t* Gt = Qt + DP * TR_LD;          // dO transposed [dv][q]
-  float* s_lse = reinterpret_cast<float*>(Gt + DP * TR_LD);
+  float* s_lse = reinterpret_cast<float*>(Gt + DP * TR_LD);  // -lse
   float* s_delta = s_lse + T64;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, c16 = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
   const int d = a.d;
-  const int krow = blockIdx.x * 64 + wid * 16 + c16;
-  const bool k_ok = krow < a.Sk;
+  const int k0 = blockIdx.x * (64 * KT) + wid * (16 * KT);
   const half_t* Qb = a.q + (long)b * a.q_bs + (long)h * d;
   const half_t* Kb = a.k + (long)b * a.k_bs + (long)h * d;
   const half_t* Vb = a.v + (long)b * a.v_bs + (long)h * d;
@@ -202,92 +272,135 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
   const float* lse_b = a.lse + ((long)b * a.H + h) * a.Sq;
   const float* delta_b = a.delta + ((long)b * a.H + h) * a.Sq;
 
-  // B operands: lane -> key c16, head-dim elements dc*32 + g*8..+8
-  half8_t kf[NDC], vf[NDC];
+  half8_t kf[KT][NDC], vf[KT][NDC];
 #pragma unroll
-  for (int dc = 0; dc < NDC; ++dc) {
-    const int dd = dc * 32 + g * 8;
-    if (k_ok && dd < d) {
-      kf[dc] = *reinterpret_cast<const half8_t*>(Kb + (long)krow * a.ldk + dd);
-      vf[dc] = *reinterpret_cast<const half8_t*>(Vb + (long)krow * a.ldv + dd);
-    } else {
-      kf[dc] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
-      vf[dc] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k2 = 0; k2 < KT; ++k2) {
+    const int krow = k0 + k2 * 16 + c16;
+#pragma unroll
+    for (int dc = 0; dc < NDC; ++dc) {
+      const int dd = dc * 32 + g * 8;
+      if (krow < a.Sk && dd < d) {
+        kf[k2][dc] = *reinterpret_cast<const half8_t*>(Kb + (long)krow * a.ldk + dd);
+        vf[k2][dc] = *reinterpret_cast<const half8_t*>(Vb + (long)krow * a.ldv + dd);
+      } else {
+        kf[k2][dc] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+        vf[k2][dc] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+      }
     }
   }
-  f32x4 dk[NDT], dv[NDT];
+  f32x4 dk[KT][NDT], dv[KT][NDT];
 #pragma unroll
-  for (int dt = 0; dt < NDT; ++dt) {
-    dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
+  for (int k2 = 0; k2 < KT; ++k2)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      dk[k2][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dv[k2][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
+  const float sl2 = a.scale_log2;
   const int n_tiles = (a.Sq + T64 - 1) / T64;
-  for (int t = 0; t < n_tiles; ++t) {
-    const int q0 = t * T64;
-    __syncthreads();
-    stage_tile<DP, true, true>(Qb, a.ldq, q0, a.Sq, d, Qs, Qt);
-    stage_tile<DP, true, true>(GOb, a.ldgo, q0, a.Sq, d, Gs, Gt);
+  PairTile<DP> qreg, greg;
+  float st_l = 0.f, st_d = 0.f;
+  auto load_stats = [&](int q0) {
     if (tid < T64) {
-      int qq = q0 + tid;
-      s_lse[tid] = qq < a.Sq ? lse_b[qq] : 0.f;
-      s_delta[tid] = qq < a.Sq ? delta_b[qq] : 0.f;
+      const int qq = q0 + tid;
+      st_l = qq < a.Sq ? -lse_b[qq] : 0.f;
+      st_d = qq < a.Sq ? delta_b[qq] : 0.f;
     }
-    __syncthreads();
-    f32x4 p[4], ds[4];
+  };
+  auto store_all = [&]() {
+    qreg.template store<true, true>(Qs, Qt);
+    greg.template store<true, true>(Gs, Gt);
+    if (tid < T64) { s_lse[tid] = st_l; s_delta[tid] = st_d; }
+  };
+  qreg.load(Qb, a.ldq, 0, a.Sq, d);
+  greg.load(GOb, a.ldgo, 0, a.Sq, d);
+  load_stats(0);
+  store_all();
+  __syncthreads();
+  for (int t = 0; t < n_tiles; ++t) {
+    if (t + 1 < n_tiles) {
+      qreg.load(Qb, a.ldq, (t + 1) * T64, a.Sq, d);
+      greg.load(GOb, a.ldgo, (t + 1) * T64, a.Sq, d);
+      load_stats((t + 1) * T64);
+    }
+    f32x4 p[KT][4], ds[KT][4];
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
-      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      half8_t qa[NDC], ga[NDC];
 #pragma unroll
       for (int dc = 0; dc < NDC; ++dc) {
-        half8_t qa = *reinterpret_cast<const half8_t*>(Qs + (qt * 16 + c16) * K_LD + dc * 32 + g * 8);
-        half8_t ga = *reinterpret_cast<const half8_t*>(Gs + (qt * 16 + c16) * K_LD + dc * 32 + g * 8);
-        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, kf[dc], s, 0, 0, 0);    // D[q][key]
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga, vf[dc], dp, 0, 0, 0);  // D[q][key]
+        qa[dc] = *reinterpret_cast<const half8_t*>(Qs + (qt * 16 + c16) * K_LD + dc * 32 + g * 8);
+        ga[dc] = *reinterpret_cast<const half8_t*>(Gs + (qt * 16 + c16) * K_LD + dc * 32 + g * 8);
       }
+      const float4 nl = *reinterpret_cast<const float4*>(s_lse + qt * 16 + g * 4);
+      const float4 dl = *reinterpret_cast<const float4*>(s_delta + qt * 16 + g * 4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ql = qt * 16 + g * 4 + r;
-        const bool ok = k_ok && (q0 + ql < a.Sq);
-        float pv = ok ? exp2f(s[r] * a.scale_log2 - s_lse[ql]) : 0.f;
-        p[qt][r] = pv;
-        ds[qt][r] = pv * (dp[r] - s_delta[ql]);
+      for (int k2 = 0; k2 < KT; ++k2) {
+        f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dc = 0; dc < NDC; ++dc) {
+          sv = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[dc], kf[k2][dc], sv, 0, 0, 0);   // D[q][key]
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga[dc], vf[k2][dc], dp, 0, 0, 0);   // D[q][key]
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float nlr = r == 0 ? nl.x : (r == 1 ? nl.y : (r == 2 ? nl.z : nl.w));
+          const float dlr = r == 0 ? dl.x : (r == 1 ? dl.y : (r == 2 ? dl.z : dl.w));
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sv[r], sl2, nlr));
+          p[k2][qt][r] = pv;
+          ds[k2][qt][r] = pv * (dp[r] - dlr);
+        }
       }
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      half8_t pf, dsf;
+      half8_t pf[KT], dsf[KT];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pf[r] = (half_t)p[2 * c][r];
-        pf[4 + r] = (half_t)p[2 * c + 1][r];
-        dsf[r] = (half_t)ds[2 * c][r];
-        dsf[4 + r] = (half_t)ds[2 * c + 1][r];
-      }
+      for (int k2 = 0; k2 < KT; ++k2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pf[k2][r] = (half_t)p[k2][2 * c][r];
+          pf[k2][4 + r] = (half_t)p[k2][2 * c + 1][r];
+          dsf[k2][r] = (half_t)ds[k2][2 * c][r];
+          dsf[k2][4 + r] = (half_t)ds[k2][2 * c + 1][r];
+        }
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
         half8_t gtf = tr_frag(Gt, dt * 16 + c16, c, g);
         half8_t qtf = tr_frag(Qt, dt * 16 + c16, c, g);
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gtf, pf, dv[dt], 0, 0, 0);   // dV^T[dv][key]
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qtf, dsf, dk[dt], 0, 0, 0);  // dK^T[j][key]
+#pragma unroll
+        for (int k2 = 0; k2 < KT; ++k2) {
+          dv[k2][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gtf, pf[k2], dv[k2][dt], 0, 0, 0);   // dV^T[dv][key]
+          dk[k2][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qtf, dsf[k2], dk[k2][dt], 0, 0, 0);  // dK^T[j][key]
+        }
       }
     }
+    __syncthreads();
+    if (t + 1 < n_tiles) {
+      store_all();
+      __syncthreads();
+    }
   }
-  if (k_ok) {
-    half_t* outk = a.gk + (long)b * a.gk_bs + (long)krow * a.ldgk + (long)h * d;
-    half_t* outv = a.gv + (long)b * a.gv_bs + (long)krow * a.ldgv + (long)h * d;
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-      const int j = dt * 16 + g * 4;
-      if (j < d) {
-        half4_t ok_, ov_;
+  for (int k2 = 0; k2 < KT; ++k2) {
+    const int krow = k0 + k2 * 16 + c16;
+    if (krow < a.Sk) {
+      half_t* outk = a.gk + (long)b * a.gk_bs + (long)krow * a.ldgk + (long)h * d;
+      half_t* outv = a.gv + (long)b * a.gv_bs + (long)krow * a.ldgv + (long)h * d;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          ok_[r] = (half_t)(dk[dt][r] * a.scale);
-          ov_[r] = (half_t)dv[dt][r];
+      for (int dt = 0; dt < NDT; ++dt) {
+        const int j = dt * 16 + g * 4;
+        if (j < d) {
+          half4_t ok_, ov_;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            ok_[r] = (half_t)(dk[k2][dt][r] * a.scale);
+            ov_[r] = (half_t)dv[k2][dt][r];
+          }
+          *reinterpret_cast<half4_t*>(outk + j) = ok_;
+          *reinterpret_cast<half4_t*>(outv + j) = ov_;
         }
-        *reinterpret_cast<half4_t*>(outk + j) = ok_;
-        *reinterpret_cast<half4_t*>(outv + j) = ov_;
       }
     }
   }
@@ -574,24 +687,34 @@ int launch_cross_bwd_mfma(const CrossBwdArgs& a, hipStream_t st) {
   return lgd_check_launch();
 }
 
-template <int DP>
-int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
+template <int DP, int NQ, int NK>
+int launch_bwd_nt(const AttnBwdArgs& a, hipStream_t st) {
   constexpr int K_LD = DP + 8;
   const size_t smem_dq = (size_t)(2 * T64 * K_LD + DP * TR_LD) * 2;
   const size_t smem_dkv = (size_t)(2 * T64 * K_LD + 2 * DP * TR_LD) * 2 + 2 * T64 * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DP, NK>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dkv);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DP, NQ>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dq);
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<DP>), dim3((a.Sq + 63) / 64, a.H, a.B), dim3(256), smem_dq,
-                     st, a);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP>), dim3((a.Sk + 63) / 64, a.H, a.B), dim3(256),
-                     smem_dkv, st, a);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, NQ>), dim3((a.Sq + 64 * NQ - 1) / (64 * NQ), a.H, a.B),
+                     dim3(256), smem_dq, st, a);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, NK>), dim3((a.Sk + 64 * NK - 1) / (64 * NK), a.H, a.B),
+                     dim3(256), smem_dkv, st, a);
   return lgd_check_launch();
+}
+
+template <int DP>
+int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
+  // two 16-row tiles per wave once there are enough 128-row workgroups to fill the chip
+  if constexpr (DP <= 96) {
+    const long wgs = (long)((a.Sq < a.Sk ? a.Sq : a.Sk) / 128) * a.H * a.B;
+    if (wgs >= 512) return launch_bwd_nt<DP, 2, 2>(a, st);
+  }
+  return launch_bwd_nt<DP, 1, 1>(a, st);
 }
 
 }  // namespace
