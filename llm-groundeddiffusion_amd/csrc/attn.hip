@@ -381,7 +381,8 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const AttnArgs a) {
   __syncthreads();
   if (ONES && tid < 2 * VT_LD) {
     const int st = tid / VT_LD, col = tid - st * VT_LD;
-    smem[st * STAGE + KV_T * K_LD + d * VT_LD + col] = (half_t)1.f;
+    smem[st * STAGE + KV_T * K_LD + d * VT_LD + col] = (half_t)1.f;        // V^T row d  -> row sums
+    if (col < KV_T) smem[st * STAGE + col * K_LD + d] = (half_t)1.f;         // K column d -> -m_ref term
   }
 
   // ---- Q fragments
@@ -396,8 +397,22 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const AttnArgs a) {
         qf[qt][dc] = *reinterpret_cast<const half8_t*>(Qb + (long)qrow * a.ldq + dd);
       else
         qf[qt][dc] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+      if (ONES) {  // scores come out of the MFMA already in the log2 domain
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[qt][dc][e] = (half_t)((float)qf[qt][dc][e] * a.scale_log2);
+      }
     }
   }
+  // ONES: head-dim slot d of Q carries -m_ref (K holds 1 there), so the MFMA result is already
+  // s * scale * log2(e) - m_ref.  The slot lives in fragment dc_m, lane group g_m, element 0.
+  const int dc_m = d >> 5, g_m = (d & 31) >> 3;
+  auto set_ref = [&](int qt, float m) {
+    if (g == g_m) {
+#pragma unroll
+      for (int dc = 0; dc < NDC; ++dc)
+        if (dc == dc_m) qf[qt][dc][0] = (half_t)(-m);
+    }
+  };
 
   // ---- hoisted staging coordinates
   const half_t* kp[K_IT];
@@ -523,23 +538,48 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const AttnArgs a) {
       mx = fmaxf(mx, s[qt][3][3]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      mxs[qt] = mx * sc;
-      raise = raise || (mxs[qt] > m_ref[qt] + 8.f);
+      if (ONES) {
+        mxs[qt] = mx;  // already relative to m_ref
+        raise = raise || (mx > 8.f) || (t == 0);
+      } else {
+        mxs[qt] = mx * sc;
+        raise = raise || (mxs[qt] > m_ref[qt] + 8.f);
+      }
     }
     if (__builtin_amdgcn_ballot_w64(raise) != 0) {
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
-        const float m_new = fmaxf(m_ref[qt], mxs[qt]);
-        const float alpha = __builtin_amdgcn_exp2f(m_ref[qt] - m_new);
+        if (ONES) {
+          // new reference, rounded to fp16 so that the Q slot holds it exactly (first tile: the
+          // slot is still 0, i.e. the scores are absolute)
+          const float m_old = t == 0 ? 0.f : m_ref[qt];
+          const float m_abs = mxs[qt] + m_old;
+          const float m_new = (float)(half_t)(t == 0 ? m_abs : fmaxf(m_old, m_abs));
+          const float shift = m_new - m_old;
+          const float alpha = __builtin_amdgcn_exp2f(-shift);
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
+          for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) oacc[qt][dt][r] *= alpha;
-        if (!ONES) l_run[qt] *= alpha;
-        m_ref[qt] = m_new;
+            for (int r = 0; r < 4; ++r) oacc[qt][dt][r] *= alpha;
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[qt][kt][r] -= shift;
+          m_ref[qt] = m_new;
+          set_ref(qt, m_new);
+        } else {
+          const float m_new = fmaxf(m_ref[qt], mxs[qt]);
+          const float alpha = __builtin_amdgcn_exp2f(m_ref[qt] - m_new);
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[qt][dt][r] *= alpha;
+          l_run[qt] *= alpha;
+          m_ref[qt] = m_new;
+        }
       }
     }
-    // ---- P = exp2(s * scale - m_ref), packed to the fp16 B operand of the PV product
+    // ---- P = exp2(.), packed to the fp16 B operand of the PV product
     half8_t pf[QT][2];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -548,8 +588,13 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const AttnArgs a) {
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[qt][kt][r], sc, nm));
-          if (!ONES) l_run[qt] += p;
+          float p;
+          if (ONES) {
+            p = __builtin_amdgcn_exp2f(s[qt][kt][r]);
+          } else {
+            p = __builtin_amdgcn_exp2f(fmaf(s[qt][kt][r], sc, nm));
+            l_run[qt] += p;
+          }
           pf[qt][kt >> 1][(kt & 1) * 4 + r] = (half_t)p;
         }
     }
