@@ -352,16 +352,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 //   * softmax pared down to max3 / fma / v_exp_f32 / packed convert: the reference exponent m_ref
 //     is only raised when a row's tile max exceeds it by more than 2^8 (wave-uniform vote), the
 //     row sum is produced by the PV MFMA from a row of ones at V^T row d (ONES, needs d < DP).
-template <int DP, bool ONES, int QT>
+// NDT: 16-row tiles of V^T / O^T actually multiplied (d = 40 with the ones row needs 3, not DP/16 = 4).
+template <int DP, bool ONES, int QT, int NDT = DP / 16>
 __global__ __launch_bounds__(256) void attn_self_kernel(const AttnArgs a) {
   constexpr int K_LD = DP + 8;
   constexpr int NDC = DP / 32;
-  constexpr int NDT = DP / 16;
   constexpr int KSEG = DP / 8;
   constexpr int K_IT = (KV_T * KSEG + 255) / 256;
   constexpr int V_ITEMS = (KV_T / 2) * KSEG;
   constexpr int V_IT = (V_ITEMS + 255) / 256;
-  constexpr int STAGE = KV_T * K_LD + DP * VT_LD;
+  constexpr int STAGE = KV_T * K_LD + NDT * 16 * VT_LD;
 
   __shared__ __attribute__((aligned(16))) half_t smem[2 * STAGE];
 
@@ -662,12 +662,14 @@ void launch_attn_dp(const AttnArgs& a, hipStream_t st) {
     dim3 grid(qt2 ? (a.Sq + 127) / 128 : (a.Sq + 63) / 64, a.H, a.B);
     if constexpr (DP <= 96) {
       if (qt2) {
-        if (a.d < DP) hipLaunchKernelGGL((attn_self_kernel<DP, true, 2>), grid, dim3(256), 0, st, a);
+        if (DP == 64 && a.d < 48) hipLaunchKernelGGL((attn_self_kernel<DP, true, 2, DP == 64 ? 3 : DP / 16>), grid, dim3(256), 0, st, a);
+        else if (a.d < DP) hipLaunchKernelGGL((attn_self_kernel<DP, true, 2>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((attn_self_kernel<DP, false, 2>), grid, dim3(256), 0, st, a);
         return;
       }
     }
-    if (a.d < DP) hipLaunchKernelGGL((attn_self_kernel<DP, true, 1>), grid, dim3(256), 0, st, a);
+    if (DP == 64 && a.d < 48) hipLaunchKernelGGL((attn_self_kernel<DP, true, 1, DP == 64 ? 3 : DP / 16>), grid, dim3(256), 0, st, a);
+    else if (a.d < DP) hipLaunchKernelGGL((attn_self_kernel<DP, true, 1>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_self_kernel<DP, false, 1>), grid, dim3(256), 0, st, a);
   }
 }
