@@ -99,10 +99,10 @@ __device__ __forceinline__ half8_t tr_frag(const half_t* tr, int row, int c, int
 
 // dQ.  Each wave owns QT x 16 queries (K / V / K^T fragments read from LDS feed QT MFMAs each);
 // the next key tile is fetched into registers while the current one is multiplied.
-template <int DP, int QT>
+template <int DP, int QT, int NDT>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
   constexpr int K_LD = DP + 8;
-  constexpr int NDC = DP / 32, NDT = DP / 16;
+  constexpr int NDC = DP / 32;   // NDT: 16-row output tiles that hold data (3 of DP/16 = 4 for d = 40)
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
   half_t* Ks = reinterpret_cast<half_t*>(dyn_smem);
   half_t* Vs = Ks + T64 * K_LD;
@@ -248,10 +248,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
 // dK, dV.  Each wave owns KT x 16 keys; loops over query tiles (Q, dO row-major and transposed,
 // lse and delta in LDS), next tile prefetched into registers.  Padded query rows are all-zero in
 // Q and dO, so they contribute nothing whatever their recomputed probability is.
-template <int DP, int KT>
+template <int DP, int KT, int NDT>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
   constexpr int K_LD = DP + 8;
-  constexpr int NDC = DP / 32, NDT = DP / 16;
+  constexpr int NDC = DP / 32;
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
   half_t* Qs = reinterpret_cast<half_t*>(dyn_smem);
   half_t* Gs = Qs + T64 * K_LD;          // dO row-major
@@ -687,22 +687,22 @@ int launch_cross_bwd_mfma(const CrossBwdArgs& a, hipStream_t st) {
   return lgd_check_launch();
 }
 
-template <int DP, int NQ, int NK>
+template <int DP, int NQ, int NK, int NDT>
 int launch_bwd_nt(const AttnBwdArgs& a, hipStream_t st) {
   constexpr int K_LD = DP + 8;
   const size_t smem_dq = (size_t)(2 * T64 * K_LD + DP * TR_LD) * 2;
   const size_t smem_dkv = (size_t)(2 * T64 * K_LD + 2 * DP * TR_LD) * 2 + 2 * T64 * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DP, NK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DP, NK, NDT>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dkv);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DP, NQ>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DP, NQ, NDT>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dq);
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, NQ>), dim3((a.Sq + 64 * NQ - 1) / (64 * NQ), a.H, a.B),
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, NQ, NDT>), dim3((a.Sq + 64 * NQ - 1) / (64 * NQ), a.H, a.B),
                      dim3(256), smem_dq, st, a);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, NK>), dim3((a.Sk + 64 * NK - 1) / (64 * NK), a.H, a.B),
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, NK, NDT>), dim3((a.Sk + 64 * NK - 1) / (64 * NK), a.H, a.B),
                      dim3(256), smem_dkv, st, a);
   return lgd_check_launch();
 }
@@ -710,11 +710,17 @@ int launch_bwd_nt(const AttnBwdArgs& a, hipStream_t st) {
 template <int DP>
 int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
   // two 16-row tiles per wave once there are enough 128-row workgroups to fill the chip
-  if constexpr (DP <= 96) {
-    const long wgs = (long)((a.Sq < a.Sk ? a.Sq : a.Sk) / 128) * a.H * a.B;
-    if (wgs >= 512) return launch_bwd_nt<DP, 2, 2>(a, st);
+  const long wgs = (long)((a.Sq < a.Sk ? a.Sq : a.Sk) / 128) * a.H * a.B;
+  if constexpr (DP == 64) {
+    if (a.d <= 48) {  // d = 40: the fourth 16-row tile of dQ / dK / dV would be all padding
+      if (wgs >= 512) return launch_bwd_nt<DP, 2, 2, 3>(a, st);
+      return launch_bwd_nt<DP, 1, 1, 3>(a, st);
+    }
   }
-  return launch_bwd_nt<DP, 1, 1>(a, st);
+  if constexpr (DP <= 96) {
+    if (wgs >= 512) return launch_bwd_nt<DP, 2, 2, DP / 16>(a, st);
+  }
+  return launch_bwd_nt<DP, 1, 1, DP / 16>(a, st);
 }
 
 }  // namespace
