@@ -439,6 +439,89 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   }
 }
 
+// Same arithmetic as layernorm_kernel, restructured for memory-level parallelism: a wave owns ROWS
+// consecutive rows and issues all their loads before the first reduction; gamma / beta of the lane's
+// channel vectors are fetched once per wave.  MAXV = 16-byte vectors per lane (C <= 512 * MAXV).
+template <int MAXV, int ROWS>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(
+    const half_t* __restrict__ x, long ldx, half_t* __restrict__ y, long ldy, int rows, int C,
+    float eps, const float* __restrict__ gamma, const float* __restrict__ beta, float* stats,
+    int rpb, long x_bs, long y_bs) {
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+  if (row0 >= rows) return;
+  const int nvec = C / 8;
+  float gm[MAXV][8], bt[MAXV][8];
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int v = lane + j * 64;
+    if (v < nvec) {
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + v * 8);
+      const float4 g1 = *reinterpret_cast<const float4*>(gamma + v * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(beta + v * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(beta + v * 8 + 4);
+      gm[j][0] = g0.x; gm[j][1] = g0.y; gm[j][2] = g0.z; gm[j][3] = g0.w;
+      gm[j][4] = g1.x; gm[j][5] = g1.y; gm[j][6] = g1.z; gm[j][7] = g1.w;
+      bt[j][0] = b0.x; bt[j][1] = b0.y; bt[j][2] = b0.z; bt[j][3] = b0.w;
+      bt[j][4] = b1.x; bt[j][5] = b1.y; bt[j][6] = b1.z; bt[j][7] = b1.w;
+    }
+  }
+  half8_t h[ROWS][MAXV];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const int row = row0 + r;
+    if (row < rows) {
+      const int bb = row / rpb, rr = row - bb * rpb;
+      const half_t* xr = x + bb * x_bs + (long)rr * ldx;
+#pragma unroll
+      for (int j = 0; j < MAXV; ++j) {
+        const int v = lane + j * 64;
+        if (v < nvec) h[r][j] = *reinterpret_cast<const half8_t*>(xr + v * 8);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const int row = row0 + r;
+    if (row >= rows) break;  // wave-uniform
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j)
+      if (lane + j * 64 < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)h[r][j][e];
+      }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j)
+      if (lane + j * 64 < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dlt = (float)h[r][j][e] - mean;
+          q += dlt * dlt;
+        }
+      }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    if (stats && lane == 0) {
+      stats[(long)row * 2] = mean;
+      stats[(long)row * 2 + 1] = rstd;
+    }
+    const int bb = row / rpb, rr = row - bb * rpb;
+    half_t* yr = y + bb * y_bs + (long)rr * ldy;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+      const int v = lane + j * 64;
+      if (v < nvec) {
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)(((float)h[r][j][e] - mean) * rstd * gm[j][e] + bt[j][e]);
+        *reinterpret_cast<half8_t*>(yr + v * 8) = o;
+      }
+    }
+  }
+}
+
 // dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat))
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const half_t* __restrict__ gy, long ldgy, const half_t* __restrict__ x, long ldx, half_t* gx,
@@ -547,9 +630,21 @@ extern "C" int lgd_layernorm_f16(const void* x, int64_t ldx, void* y, int64_t ld
   if ((C % 8) || C > 64 * 8 * LN_MAXV || rows < 1) return LGD_ERR_ARG;
   if (rows_per_batch < 1) rows_per_batch = rows;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, (const half_t*)x,
-                     (long)ldx, (half_t*)y, (long)ldy, rows, C, eps, gamma, beta, stats,
-                     rows_per_batch, (long)x_bs, (long)y_bs);
+  const half_t* xp = (const half_t*)x;
+  half_t* yp = (half_t*)y;
+  const int nvec = C / 8;
+#define LGD_LN_LAUNCH(MAXV, ROWS)                                                                   \
+  hipLaunchKernelGGL((layernorm_rows_kernel<MAXV, ROWS>), dim3((rows + 4 * ROWS - 1) / (4 * ROWS)), \
+                     dim3(256), 0, st, xp, (long)ldx, yp, (long)ldy, rows, C, eps, gamma, beta,      \
+                     stats, rows_per_batch, (long)x_bs, (long)y_bs)
+  if (nvec <= 64) LGD_LN_LAUNCH(1, 4);
+  else if (nvec <= 128) LGD_LN_LAUNCH(2, 4);
+  else if (nvec <= 192) LGD_LN_LAUNCH(3, 2);
+  else
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, xp, (long)ldx, yp,
+                       (long)ldy, rows, C, eps, gamma, beta, stats, rows_per_batch, (long)x_bs,
+                       (long)y_bs);
+#undef LGD_LN_LAUNCH
   return lgd_check_launch();
 }
 
