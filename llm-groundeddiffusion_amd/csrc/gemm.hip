@@ -141,32 +141,38 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& ga, f32x4 (&acc)[N
   // all MI x NI fetches are issued before the first one is consumed, so the epilogue pays one
   // memory round trip, not MI x NI of them.  Out-of-range lanes fetch a clamped, valid address.
   const bool res16 = d.res && !(d.epi & LGD_EPI_RES_F32);
-  half4_t rpre[NI][MI];
-  if (res16) {
-    const half_t* rb = reinterpret_cast<const half_t*>(d.res) + r_off;
+  constexpr int NCH = NI > 5 ? 5 : NI;  // ni columns per prefetch round (bounds the live registers)
+  static_assert(NI % NCH == 0, "NI must split into equal prefetch rounds");
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      int n = n0 + wn * 16 * NI + ni * 16 + n_l;
-      if (n >= d.N) n = 0;
+  for (int nc = 0; nc < NI; nc += NCH) {
+    half4_t rpre[NCH][MI];
+    if (res16) {
+      const half_t* rb = reinterpret_cast<const half_t*>(d.res) + r_off;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        int m = m0 + wm * 16 * MI + mi * 16 + m_l;
-        if (m >= d.M) m = d.M - 1;
-        rpre[ni][mi] = *reinterpret_cast<const half4_t*>(rb + (long)m * d.ldr + n);
+      for (int nj = 0; nj < NCH; ++nj) {
+        int n = n0 + wn * 16 * NI + (nc + nj) * 16 + n_l;
+        if (n >= d.N) n = 0;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          int m = m0 + wm * 16 * MI + mi * 16 + m_l;
+          if (m >= d.M) m = d.M - 1;
+          rpre[nj][mi] = *reinterpret_cast<const half4_t*>(rb + (long)m * d.ldr + n);
+        }
       }
     }
-  }
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int n = n0 + wn * 16 * NI + ni * 16 + n_l;
-    if (n >= d.N) continue;
-    const float4 bv = ld_bias_sum4(d, n);
+    for (int nj = 0; nj < NCH; ++nj) {
+      const int ni = nc + nj;
+      const int n = n0 + wn * 16 * NI + ni * 16 + n_l;
+      if (n >= d.N) continue;
+      const float4 bv = ld_bias_sum4(d, n);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int m = m0 + wm * 16 * MI + mi * 16 + m_l;
-      if (m < d.M)
-        epilogue_store4<false>(d, c_off, r_off, m, n, acc[ni][mi], acc[ni][mi], bv, bv, res16,
-                               res16 ? rpre[ni][mi] : (half4_t){0, 0, 0, 0});
+      for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * 16 * MI + mi * 16 + m_l;
+        if (m < d.M)
+          epilogue_store4<false>(d, c_off, r_off, m, n, acc[ni][mi], acc[ni][mi], bv, bv, res16,
+                                 res16 ? rpre[nj][mi] : (half4_t){0, 0, 0, 0});
+      }
     }
   }
 }
@@ -361,12 +367,19 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 //     the 256-B bank row in each of the 4 hardware lane groups -> conflict-free.
 //   * requires every K tile to be full (K % 64 == 0) — true for every UNet contraction; the entry
 //     point routes other shapes to the register-staged variant.
-template <int MI, int NI>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs ga) {
-  constexpr int BM = 32 * MI;
+//   * WM waves along M x 2 along N (WM = 2: 256 threads, WM = 4: 512 threads).  The 8-wave 256-row
+//     tiles exist because the vector-memory path (64 B/clk/CU) bounds this loop before the matrix
+//     cores do: a 128x160 tile moves 1 B per 71 flop, right at the ridge (4069 flop/clk/CU / 64
+//     B/clk/CU); 256x320 moves 1 B per 142 flop.
+template <int MI, int NI, int WM>
+__global__ __launch_bounds__(128 * WM) void gemm_dma_kernel(const GemmArgs ga) {
+  constexpr int NT = 128 * WM;       // threads
+  constexpr int RP = NT / 8;         // tile rows filled per pass (one 16-B segment per thread)
+  constexpr int BM = WM * 16 * MI;
   constexpr int BN = 32 * NI;
-  constexpr int A_IT = BM / 32;
-  constexpr int B_IT = BN / 32;
+  static_assert(BM % RP == 0 && BN % RP == 0, "tile rows must be a multiple of the staging pass");
+  constexpr int A_IT = BM / RP;
+  constexpr int B_IT = BN / RP;
   constexpr int STAGE = (BM + BN) * BK;  // halfs per stage
 
   __shared__ __attribute__((aligned(1024))) half_t smem[2 * STAGE];
@@ -410,7 +423,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs ga) {
   const half_t* zero = reinterpret_cast<const half_t*>(g_zero_line);
 
   // ---- per-thread staging coordinates
-  const int rrow = tid >> 3;                       // row within a 32-row pass
+  const int rrow = tid >> 3;                       // row within an RP-row pass
   const int kseg = (tid & 7) ^ ((rrow >> 1) & 7);  // logical 8-half segment this lane fetches
   const int cin = ga.cin;
   const bool conv = d.taps == 9;
@@ -419,7 +432,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs ga) {
   long a_row[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    int m = m0 + rrow + 32 * i;
+    int m = m0 + rrow + RP * i;
     if (m >= d.M) m = d.M - 1;  // rows past M are computed on valid data and never stored
     if (conv) {
       int hw = d.hout * d.wout;
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs ga) {
   const half_t* w_row[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
-    int n = n0 + rrow + 32 * i;
+    int n = n0 + rrow + RP * i;
     if (n >= d.N) n = d.N - 1;
     w_row[i] = W + (long)n * d.ldw + k_beg + kseg * 8;
   }
@@ -484,12 +497,12 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs ga) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const half_t* p = a_ok[i] ? a_ptr[i] : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)(As + (32 * i + 8 * wid) * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)(As + (RP * i + 8 * wid) * BK), 16, 0, 0);
       a_ptr[i] += BK;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)w_row[i], (lds_ptr_t)(Bs + (32 * i + 8 * wid) * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)w_row[i], (lds_ptr_t)(Bs + (RP * i + 8 * wid) * BK), 16, 0, 0);
       w_row[i] += BK;
     }
     const int ch_prev = ch;
@@ -578,14 +591,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs ga) {
   }
 }
 
-template <int MI, int NI>
+template <int MI, int NI, int WM = 2>
 int launch_gemm(const GemmArgs& ga, hipStream_t st, bool dma) {
-  constexpr int BM = 32 * MI, BN = 32 * NI;
+  constexpr int BM = WM * 16 * MI, BN = 32 * NI;
   const LgdGemmDesc& d = ga.d;
   long tiles = (long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
   dim3 grid((unsigned)tiles, 1, (unsigned)(d.nb_o * d.nb_i * d.splits));
-  if (dma) hipLaunchKernelGGL((gemm_dma_kernel<MI, NI>), grid, dim3(256), 0, st, ga);
-  else hipLaunchKernelGGL((gemm_kernel<MI, NI>), grid, dim3(256), 0, st, ga);
+  if constexpr (WM == 2) {
+    if (dma) hipLaunchKernelGGL((gemm_dma_kernel<MI, NI, 2>), grid, dim3(256), 0, st, ga);
+    else hipLaunchKernelGGL((gemm_kernel<MI, NI>), grid, dim3(256), 0, st, ga);
+  } else {
+    if (!dma) return LGD_ERR_ARG;  // the 8-wave tiles exist only with the LDS-DMA main loop
+    hipLaunchKernelGGL((gemm_dma_kernel<MI, NI, WM>), grid, dim3(128 * WM), 0, st, ga);
+  }
   return lgd_check_launch();
 }
 
@@ -649,6 +667,8 @@ extern "C" int lgd_gemm_f16(const LgdGemmDesc* desc, void* stream) {
     case 5: rc = launch_gemm<1, 4>(ga, st, dma); break;
     case 6: rc = geglu ? LGD_ERR_ARG : launch_gemm<4, 5>(ga, st, dma); break;  // 128x160: N = 320 k exactly
     case 7: rc = geglu ? LGD_ERR_ARG : launch_gemm<2, 5>(ga, st, dma); break;  // 64x160
+    case 9: rc = geglu ? LGD_ERR_ARG : launch_gemm<4, 10, 4>(ga, st, dma); break;  // 256x320, 8 waves
+    case 10: rc = launch_gemm<4, 4, 4>(ga, st, dma); break;                         // 256x128, 8 waves
     default: return LGD_ERR_ARG;
   }
   if (rc) return rc;

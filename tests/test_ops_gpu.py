@@ -45,6 +45,9 @@ def pack_geglu(w, b):  # [2n,K] -> 16-row value/gate interleave
     (8192, 320, 320, 17, 1), (4100, 640, 640, 18, 1), (512, 1280, 1280, 19, 1), (128, 1280, 5120, 20, 4),
     (77, 320, 768, 21, 1), (30, 640, 768, 21, 3), (2048, 640, 2560, 19, 2), (100, 100, 72, 18, 1),
     (1000, 200, 64, 17, 1),
+    # 8-wave 256-row tiles (25: 256x320, 26: 256x128)
+    (8192, 320, 320, 25, 1), (4100, 640, 640, 25, 1), (2048, 640, 2560, 26, 2), (300, 1280, 1280, 26, 1),
+    (515, 960, 192, 25, 1),
 ])
 def test_gemm_plain(dev, M, N, K, tile, splits):
     x = rnd(M, K, dev=dev, seed=1).half()
@@ -109,6 +112,21 @@ def test_conv3x3(dev, B, H, C0, C1, Cout, stride, ups, splits, dma):
     y = ops.conv3x3(x0, pack_conv_w(w), B, H, H, x1=x1, bias=b, res=res, stride=stride,
                     ups=int(ups), splits=splits, tile=(dma + 3 if dma else 0))
     ref = ref.permute(0, 2, 3, 1).reshape(-1, Cout) + res.float()
+    assert relerr(y, ref) < 3e-3
+
+
+@pytest.mark.parametrize("tile", [25, 26])
+def test_conv3x3_8wave_tiles(dev, tile):
+    B, H, C0, C1, Cout = 2, 32, 320, 320, 320
+    C = C0 + C1
+    x = rnd(B, C, H, H, dev=dev, seed=1).half()
+    w = rnd(Cout, C, 3, 3, dev=dev, seed=2, scale=(9 * C) ** -0.5).half()
+    b = rnd(Cout, dev=dev, seed=3)
+    xl = x.permute(0, 2, 3, 1).reshape(B * H * H, C).contiguous()
+    res = rnd(B * H * H, Cout, dev=dev, seed=7).half()
+    y = ops.conv3x3(xl[:, :C0].contiguous(), pack_conv_w(w), B, H, H, x1=xl[:, C0:].contiguous(), bias=b, res=res,
+                    tile=tile, splits=1)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout) + res.float()
     assert relerr(y, ref) < 3e-3
 
 
