@@ -189,6 +189,10 @@ def main():
                         unit="TFLOP/s", frac=round(ach / MFMA_PEAK_F16, 4), traffic=None,
                         avg_launch_us=round(a["raw_ms"] * 1e3 / a["raw_n"], 2),
                         launches_per_image=round(a["n"]), est_ms_per_image=round(a["ms"], 1),
+                        traffic_note="null: a rocprofv3 --pmc pass over this command serialises ~50k dispatches and "
+                                     "does not finish; the PMC HBM traffic of this kernel on its top shape is in "
+                                     "profiles/r01e_gemm_traffic_pmc.json (182 MB measured vs 128 MB algorithmic per "
+                                     "launch, 1.2 TB/s: not HBM-bound)",
                         method="HIP events around each launch, eager replay of the benchmark's plans right after "
                                "the timed region (the timed region itself replays hipGraphs)",
                         all_kernels={k: dict(ms_per_image=round(v["ms"], 1), launches_per_image=round(v["n"]),

@@ -13,6 +13,7 @@ SHAPES = [  # (M, N, K, taps, c0, c1, h, geglu)
     (1024, 1280, 1280, 1, 1280, 0, 0, 0), (256, 1280, 1280, 1, 1280, 0, 0, 0), (256, 1280, 11520, 9, 1280, 0, 8, 0),
     (64, 1280, 11520, 9, 1280, 0, 8, 0), (16384, 640, 640, 1, 640, 0, 0, 0),
 ]
+if os.environ.get("CONVBIG"): SHAPES = [s for s in SHAPES if s[3] == 9 and s[0] >= 16384]
 if os.environ.get("SMALL"): SHAPES = [s for s in SHAPES if s[0] <= 4096 or s[2] <= 640]
 tiles = [int(x) for x in os.environ.get("TILES", "0").split(",")]
 tot = 0.0

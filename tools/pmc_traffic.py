@@ -1,0 +1,30 @@
+"""Aggregates rocprofv3 --pmc counter_collection CSVs (one pass per counter set) into per-kernel averages.
+
+    python tools/pmc_traffic.py out.json pass1_counter_collection.csv [pass2_counter_collection.csv ...]
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB-like units of the TCC request counters; on gfx950
+FETCH_SIZE counts 128-B read requests at 64 B (MI355X_MICROARCH.md, HBM section), so fetched bytes are
+doubled here; WRITE_SIZE is left as reported (uncalibrated, per the same section)."""
+import csv, json, sys
+from collections import defaultdict
+out = sys.argv[1]
+agg = defaultdict(lambda: defaultdict(float))
+cnt = defaultdict(lambda: defaultdict(int))
+for path in sys.argv[2:]:
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[k][r["Counter_Name"]] += 1
+res = {}
+for k, v in agg.items():
+    e = {"launches": max(cnt[k].values())}
+    for c, x in v.items():
+        e[c + "_per_launch"] = x / cnt[k][c]
+    if "FETCH_SIZE" in v:   # KB per launch -> bytes, x2 gfx950 correction
+        e["hbm_read_bytes_per_launch"] = e["FETCH_SIZE_per_launch"] * 1024 * 2
+    if "WRITE_SIZE" in v:
+        e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE_per_launch"] * 1024
+    res[k] = e
+json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+print("wrote", out, len(res), "kernels")
