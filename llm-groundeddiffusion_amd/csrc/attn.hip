@@ -21,7 +21,10 @@
 namespace {
 
 constexpr int KV_T = 64;         // keys per tile
-constexpr int VT_LD = KV_T + 8;  // halfs per row of the transposed V tile
+constexpr int VT_LD = KV_T + 8;  // halfs per row of the transposed V tile (ds_read_b64: conflict-free)
+// Row-major K tiles use DP + 16 halfs per row: the only padding <= 48 for which the 4 hardware lane
+// groups of a ds_read_b128 fragment read ({0-3,12-15,20-27}, ...) each hit 16 distinct 16-B slots
+// (DP + 8 is 2-way conflicted: 9 % of wave cycles in the PMC profile).
 constexpr float NEG_BIG = -1.0e30f;
 
 struct AttnArgs {
@@ -39,7 +42,7 @@ struct AttnArgs {
 // MFMA also produces the softmax row sum (in accumulator row d) and the VALU never adds it up.
 template <int DP, bool SAVE_P, bool ONES>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
-  constexpr int K_LD = DP + 8;
+  constexpr int K_LD = DP + 16;
   constexpr int NDC = DP / 32;  // 32-wide chunks of the head dim (QK^T contraction)
   constexpr int NDT = DP / 16;  // 16-row tiles of dv (O^T rows)
   constexpr int KSEG = DP / 8;  // 16-byte segments per K row
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 // NDT: 16-row tiles of V^T / O^T actually multiplied (d = 40 with the ones row needs 3, not DP/16 = 4).
 template <int DP, bool ONES, int QT, int NDT = DP / 16>
 __global__ __launch_bounds__(256) void attn_self_kernel(const AttnArgs a) {
-  constexpr int K_LD = DP + 8;
+  constexpr int K_LD = DP + 16;
   constexpr int NDC = DP / 32;
   constexpr int KSEG = DP / 8;
   constexpr int K_IT = (KV_T * KSEG + 255) / 256;

@@ -53,8 +53,8 @@ struct PairTile {
       if (idx >= ITEMS) continue;
       const int pair = idx & 31, seg = idx >> 5;
       if (RM) {
-        *reinterpret_cast<uint4*>(rm + (pair * 2) * (DP + 8) + seg * 8) = v[i][0];
-        *reinterpret_cast<uint4*>(rm + (pair * 2 + 1) * (DP + 8) + seg * 8) = v[i][1];
+        *reinterpret_cast<uint4*>(rm + (pair * 2) * (DP + 16) + seg * 8) = v[i][0];
+        *reinterpret_cast<uint4*>(rm + (pair * 2 + 1) * (DP + 16) + seg * 8) = v[i][1];
       }
       if (TR) {
         // (row 2p, row 2p+1) halves of column seg*8+e packed into one dword, by integer ops on the
@@ -101,7 +101,7 @@ __device__ __forceinline__ half8_t tr_frag(const half_t* tr, int row, int c, int
 // the next key tile is fetched into registers while the current one is multiplied.
 template <int DP, int QT, int NDT>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
-  constexpr int K_LD = DP + 8;
+  constexpr int K_LD = DP + 16;
   constexpr int NDC = DP / 32;   // NDT: 16-row output tiles that hold data (3 of DP/16 = 4 for d = 40)
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
   half_t* Ks = reinterpret_cast<half_t*>(dyn_smem);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
 // Q and dO, so they contribute nothing whatever their recomputed probability is.
 template <int DP, int KT, int NDT>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
-  constexpr int K_LD = DP + 8;
+  constexpr int K_LD = DP + 16;
   constexpr int NDC = DP / 32;
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
   half_t* Qs = reinterpret_cast<half_t*>(dyn_smem);
@@ -532,7 +532,7 @@ constexpr int XM_LD = XM_KEYS + 8;  // halfs per row of the transposed K image
 
 template <int DP>
 __global__ __launch_bounds__(256) void cross_attn_bwd_mfma_kernel(const CrossBwdArgs a) {
-  constexpr int K_LD = DP + 8;
+  constexpr int K_LD = DP + 16;
   constexpr int NDC = DP / 32, NDT = DP / 16, KSEG = DP / 8;
   constexpr int NKT = XM_KEYS / 16;
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_mfma_kernel(const CrossBwd
 
 template <int DP>
 int launch_cross_bwd_mfma(const CrossBwdArgs& a, hipStream_t st) {
-  const size_t smem = (size_t)(2 * XM_KEYS * (DP + 8) + DP * XM_LD) * 2;
+  const size_t smem = (size_t)(2 * XM_KEYS * (DP + 16) + DP * XM_LD) * 2;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn_bwd_mfma_kernel<DP>),
@@ -689,7 +689,7 @@ int launch_cross_bwd_mfma(const CrossBwdArgs& a, hipStream_t st) {
 
 template <int DP, int NQ, int NK, int NDT>
 int launch_bwd_nt(const AttnBwdArgs& a, hipStream_t st) {
-  constexpr int K_LD = DP + 8;
+  constexpr int K_LD = DP + 16;
   const size_t smem_dq = (size_t)(2 * T64 * K_LD + DP * TR_LD) * 2;
   const size_t smem_dkv = (size_t)(2 * T64 * K_LD + 2 * DP * TR_LD) * 2 + 2 * T64 * 4;
   static bool attr_set = false;

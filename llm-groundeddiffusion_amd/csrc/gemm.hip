@@ -10,8 +10,8 @@
 //   * tile BM x BN x 64; each wave owns (BM/2)x(BN/2) as MI x NI MFMA 16x16x32 tiles;
 //   * operands are register-staged: global -> VGPR (issued before the MFMAs of the current
 //     K-tile) -> LDS after the barrier, so the HBM/L2 latency hides under the MFMA phase;
-//   * LDS rows are padded to 72 halfs (144 B) so the 16-lane ds_read_b128 groups spread
-//     over the banks;
+//   * LDS rows are padded to 80 halfs (160 B): with that stride each of the 4 hardware lane groups of
+//     a ds_read_b128 fragment read touches 16 distinct 16-B slots (72 halfs is 2-way conflicted);
 //   * the MFMA is issued "swapped" (A := weight rows, B := activation rows), which makes each lane
 //     own 4 consecutive output channels of one pixel -> one 8-byte store, and 4-wide bias /
 //     residual loads in the epilogue;
@@ -24,7 +24,7 @@
 namespace {
 
 constexpr int BK = 64;
-constexpr int LDS_LD = BK + 8;  // halfs per LDS row
+constexpr int LDS_LD = BK + 16;  // halfs per LDS row (160 B: the 4 ds_read_b128 lane groups hit 16 distinct 16-B slots)
 
 struct GemmArgs {
   LgdGemmDesc d;
