@@ -21,8 +21,8 @@ def run(spec, bg_seed=1, overall_prompt_override="", fg_seed_start=20, frozen_st
     """Argument names of generation/lmd.py:215-256.  Differences from the reference defaults, stated:
     `so_center_box` / `align_with_overall_bboxes` default to False here (the centred-box + re-alignment
     variant needs SAM masks to be meaningful; with box masks the per-box generation runs in place)."""
-    if so_center_box or align_with_overall_bboxes or use_fast_schedule:
-        raise NotImplementedError("so_center_box / align_with_overall_bboxes / use_fast_schedule: not wired on the HIP path")
+    if so_center_box or align_with_overall_bboxes:
+        raise NotImplementedError("so_center_box / align_with_overall_bboxes: not wired on the HIP path")
     if num_inference_steps <= 10:
         # the reference crashes here too (attn_aggregation_step_start=10, generation/lmd.py:36,124-131)
         print("note: the reference's SAM point prompt aggregates maps from step 10 on; with <=10 steps it would fail")
@@ -37,5 +37,5 @@ def run(spec, bg_seed=1, overall_prompt_override="", fg_seed_start=20, frozen_st
                        overall_fg_top_p=overall_fg_top_p, overall_bg_top_p=overall_bg_top_p, fg_weight=fg_weight,
                        bg_weight=bg_weight, overall_fg_weight=overall_fg_weight, overall_bg_weight=overall_bg_weight,
                        ref_ca_loss_weight=ref_ca_loss_weight, fg_blending_ratio=fg_blending_ratio, use_ref_ca=use_ref_ca,
-                       height=height, width=width)
+                       height=height, width=width, use_fast_schedule=use_fast_schedule)
     return EasyDict(image=out["image"], so_img_list=out["so_images"])

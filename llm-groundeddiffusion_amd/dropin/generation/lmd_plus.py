@@ -25,8 +25,8 @@ def run(spec, bg_seed=1, overall_prompt_override="", fg_seed_start=20, frozen_st
     if max_index_step != 0:
         raise NotImplementedError("per-box attention guidance in LMD+ (max_index_step>0) is disabled in the reference "
                                   "by default and not wired on the HIP path")
-    if align_with_overall_bboxes or use_fast_schedule:
-        raise NotImplementedError("align_with_overall_bboxes / use_fast_schedule are off by default in LMD+")
+    if align_with_overall_bboxes:
+        raise NotImplementedError("align_with_overall_bboxes is off by default in LMD+ and not wired on the HIP path")
     sm = models.model_dict.sampler
     lay = build_layout(spec, bg_seed, fg_seed_start, so_negative_prompt, overall_negative_prompt, height, width,
                        overall_prompt_override, so_center_box, so_horizontal_center_only, verbose)
@@ -41,5 +41,5 @@ def run(spec, bg_seed=1, overall_prompt_override="", fg_seed_start=20, frozen_st
                             overall_fg_top_p=overall_fg_top_p, overall_bg_top_p=overall_bg_top_p,
                             overall_fg_weight=overall_fg_weight, overall_bg_weight=overall_bg_weight,
                             ref_ca_loss_weight=ref_ca_loss_weight, fg_blending_ratio=fg_blending_ratio,
-                            use_ref_ca=use_ref_ca, height=height, width=width)
+                            use_ref_ca=use_ref_ca, height=height, width=width, use_fast_schedule=use_fast_schedule)
     return EasyDict(image=out["image"], so_img_list=out["so_images"])

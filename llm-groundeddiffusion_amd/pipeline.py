@@ -90,7 +90,8 @@ def _ref_maps(sampler: LMDSampler, saved_list, keys, L, T):
     out = torch.zeros((T, len(saved_list), len(keys), heads, max_hw), device=sampler.dev, dtype=F32)
     for b, saved in enumerate(saved_list):
         for ki, k in enumerate(keys):
-            out[:, b, ki, :, :hw[k]] = saved[k][:, 0, :, :, 0]      # [T,1,H,HW,1] (cond only, word token)
+            n = min(T, saved[k].shape[0])                            # a fast-schedule stage A ran fewer steps
+            out[:n, b, ki, :, :hw[k]] = saved[k][:n, 0, :, :, 0]     # [T,1,H,HW,1] (cond only, word token)
     return out
 
 
@@ -105,7 +106,8 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
                             overall_loss_threshold=5.0, overall_max_iter=None, overall_max_index_step=30,
                             overall_fg_top_p=0.2, overall_bg_top_p=0.2, overall_fg_weight=1.0,
                             overall_bg_weight=4.0, ref_ca_loss_weight=2.0, fg_blending_ratio=0.1,
-                            use_ref_ca=True, height=512, width=512, decode=True, guidance_attn_keys=None):
+                            use_ref_ca=True, height=512, width=512, decode=True, guidance_attn_keys=None,
+                            use_fast_schedule=False):
     """LMD+ (generation/lmd_plus.py:193-520, default arguments; per-box guidance is off there:
     max_index_step=0, :203) for a batch of independent layouts: the per-box generations of ALL layouts run
     as one batched denoising call (B = 2 x total boxes), then the overall generations of all layouts as
@@ -119,6 +121,10 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
     C = sampler.eng.cfg.in_channels
     prep = [get_input_latents_list(lay.bg_seed, lay.fg_seed_start, lay.boxes, fg_blending_ratio, C, L, L)
             for lay in lays]
+    # use_fast_schedule (lmd_plus.py:360-367): the per-box generations only feed SAM after the steps needed
+    # for latent / attention transfer, so the rest runs on every second timestep.
+    fast_after = (max(frozen_steps, overall_max_index_step) if use_ref_ca else frozen_steps) if use_fast_schedule else None
+    comp_steps = fast_after if use_fast_schedule else T                       # latents.py:46-48,77-78
     # ---- stage A: one GLIGEN generation per box (lmd_plus.py:44-145,162-188), all boxes batched
     jobs, owner = [], []
     if use_ref_ca or frozen_steps > 0:
@@ -131,7 +137,7 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
     res_a = sampler.denoise_batch(jobs, T, guidance_scale=guidance_scale, use_gligen=True,
                                   gligen_scheduled_sampling_beta=so_gligen_scheduled_sampling_beta,
                                   saved_cross_attn_keys=[OBJ_ATTN_KEY, *keys] if use_ref_ca else [OBJ_ATTN_KEY],
-                                  return_cond_ca_only=True) if jobs else []
+                                  return_cond_ca_only=True, fast_after_steps=fast_after) if jobs else []
     per_lay = [dict(latents_all=[], masks=[], saved=[], so_images=[]) for _ in lays]
     if decode and res_a:
         imgs = sampler.decode(torch.cat([r["latents"] for r in res_a]))      # feeds SAM in the reference
@@ -146,7 +152,7 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
     jobs_b, comps = [], []
     for li, lay in enumerate(lays):
         d = per_lay[li]
-        composed, fg_idx = compose_latents(d["latents_all"], d["masks"], T, prep[li][1].to(dev))
+        composed, fg_idx = compose_latents(d["latents_all"], d["masks"], comp_steps, prep[li][1].to(dev))
         comps.append((composed, fg_idx))
         overall_bboxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
         flat = [i for grp in lay.overall_groups for i in grp]
@@ -172,57 +178,83 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
             for li in range(len(lays))]
 
 
-def lmd_generate(sampler: LMDSampler, lay: CachedLayout, *, num_inference_steps=50, frozen_step_ratio=0.4,
-                 guidance_scale=7.5, loss_scale=5, loss_threshold=5.0, max_iter=None, max_index_step=30,
-                 overall_loss_scale=5, overall_loss_threshold=5.0, overall_max_iter=None,
-                 overall_max_index_step=30, fg_top_p=0.2, bg_top_p=0.2, overall_fg_top_p=0.2,
-                 overall_bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0, overall_fg_weight=1.0,
-                 overall_bg_weight=4.0, ref_ca_loss_weight=2.0, fg_blending_ratio=0.01, use_ref_ca=True,
-                 height=512, width=512, decode=True, guidance_attn_keys=None):
-    """Training-free LMD for one layout (generation/lmd.py:215-551, defaults :215-256): per-box stage
-    = generate_semantic_guidance WITH guidance (lmd.py:340-352), overall stage = generate_partial_frozen
-    with the reference-attention term (lmd.py:530-542)."""
+def lmd_generate(sampler: LMDSampler, lay: CachedLayout, **kw):
+    """Training-free LMD for one layout (generation/lmd.py:215-551, defaults :215-256)."""
+    return lmd_generate_batch(sampler, [lay], **kw)[0]
+
+
+def lmd_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, num_inference_steps=50,
+                       frozen_step_ratio=0.4, guidance_scale=7.5, loss_scale=5, loss_threshold=5.0, max_iter=None,
+                       max_index_step=30, overall_loss_scale=5, overall_loss_threshold=5.0, overall_max_iter=None,
+                       overall_max_index_step=30, fg_top_p=0.2, bg_top_p=0.2, overall_fg_top_p=0.2,
+                       overall_bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0, overall_fg_weight=1.0,
+                       overall_bg_weight=4.0, ref_ca_loss_weight=2.0, fg_blending_ratio=0.01, use_ref_ca=True,
+                       height=512, width=512, decode=True, guidance_attn_keys=None, use_fast_schedule=False):
+    """Training-free LMD (generation/lmd.py:215-551) for a batch of independent layouts: per-box stage =
+    generate_semantic_guidance WITH guidance (lmd.py:340-352), all boxes of all layouts in one batched
+    denoising call (each image keeps its own guidance loop exit); overall stage = generate_partial_frozen
+    with the reference-attention term (lmd.py:530-542), all layouts in another."""
     L = height // 8
     T = num_inference_steps
     frozen_steps = int(T * min(max(frozen_step_ratio, 0.0), 1.0))
     keys = [tuple(k) for k in (guidance_attn_keys or DEFAULT_GUIDANCE_ATTN_KEYS)]
     dev = sampler.dev
     C = sampler.eng.cfg.in_channels
-    input_latents, latents_bg = get_input_latents_list(lay.bg_seed, lay.fg_seed_start, lay.boxes,
-                                                       fg_blending_ratio, C, L, L)
-    latents_all_list, mask_list, saved_list, so_images = [], [], [], []
-    for i, box in enumerate(lay.boxes):
-        text = torch.cat([lay.so_uncond, lay.so_cond[i:i + 1]])
-        guid = dict(bboxes=[list(box)], object_positions=[lay.so_object_positions[i]], loss_scale=loss_scale,
-                    loss_threshold=loss_threshold, max_iter=max_iter or DEFAULT_MAX_ITER,
-                    max_index_step=max_index_step, fg_top_p=fg_top_p, bg_top_p=bg_top_p, fg_weight=fg_weight,
-                    bg_weight=bg_weight, guidance_attn_keys=keys)
-        r = sampler.denoise(input_latents[i], text, T, guidance_scale=guidance_scale, guidance=guid,
-                            saved_cross_attn_keys=[OBJ_ATTN_KEY, *keys], return_cond_ca_only=True,
-                            return_token_ca_only=lay.so_word_token_index[i])
+    prep = [get_input_latents_list(lay.bg_seed, lay.fg_seed_start, lay.boxes, fg_blending_ratio, C, L, L)
+            for lay in lays]
+    fast_after = (max(frozen_steps, overall_max_index_step) if use_ref_ca else frozen_steps) \
+        if use_fast_schedule else None                                        # lmd.py:399-406
+    comp_steps = fast_after if use_fast_schedule else T
+    # ---- stage A
+    jobs, owner = [], []
+    for li, lay in enumerate(lays):
+        for i, box in enumerate(lay.boxes):
+            guid = dict(bboxes=[list(box)], object_positions=[lay.so_object_positions[i]], loss_scale=loss_scale,
+                        loss_threshold=loss_threshold, max_iter=max_iter or DEFAULT_MAX_ITER,
+                        max_index_step=max_index_step, fg_top_p=fg_top_p, bg_top_p=bg_top_p, fg_weight=fg_weight,
+                        bg_weight=bg_weight, guidance_attn_keys=keys)
+            jobs.append(Job(prep[li][0][i], torch.cat([lay.so_uncond, lay.so_cond[i:i + 1]]), guidance=guid,
+                            token=lay.so_word_token_index[i]))
+            owner.append((li, i))
+    res_a = sampler.denoise_batch(jobs, T, guidance_scale=guidance_scale,
+                                  saved_cross_attn_keys=[OBJ_ATTN_KEY, *keys], return_cond_ca_only=True,
+                                  fast_after_steps=fast_after) if jobs else []
+    per_lay = [dict(latents_all=[], masks=[], saved=[], so_images=[]) for _ in lays]
+    if decode and res_a:
+        imgs = sampler.decode(torch.cat([r["latents"] for r in res_a]))
+    for n, ((li, i), r) in enumerate(zip(owner, res_a)):
+        d = per_lay[li]
+        d["latents_all"].append(r["latents_all"])
+        d["saved"].append(r["saved"])
+        d["masks"].append(proportion_to_mask(lays[li].boxes[i], L, L).bool())   # SAM stand-in (SURVEY.md §8d)
         if decode:
-            so_images.append(sampler.decode(r["latents"]))
-        latents_all_list.append(r["latents_all"])
-        saved_list.append(r["saved"])
-        mask_list.append(proportion_to_mask(box, L, L).bool())
-    composed, fg_idx = compose_latents(latents_all_list, mask_list, T, latents_bg.to(dev))
-    overall_bboxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
-    flat = [i for grp in lay.overall_groups for i in grp]
-    guid = None
-    if overall_bboxes:
-        guid = dict(bboxes=overall_bboxes, object_positions=lay.overall_object_positions,
-                    loss_scale=overall_loss_scale, loss_threshold=overall_loss_threshold,
-                    max_iter=overall_max_iter or DEFAULT_MAX_ITER, max_index_step=overall_max_index_step,
-                    fg_top_p=overall_fg_top_p, bg_top_p=overall_bg_top_p, fg_weight=overall_fg_weight,
-                    bg_weight=overall_bg_weight, ref_ca_word_token_only=True, ref_ca_last_token_only=True,
-                    word_token_indices=lay.overall_word_token_indices, ref_ca_loss_weight=ref_ca_loss_weight,
-                    guidance_attn_keys=keys,
-                    ref_maps=_ref_maps(sampler, [saved_list[i] for i in flat], keys, L, T) if use_ref_ca else None)
-    text = torch.cat([lay.overall_uncond, lay.overall_cond])
-    r = sampler.denoise(composed, text, T, guidance_scale=guidance_scale, guidance=guid,
-                        frozen_steps=frozen_steps, frozen_mask=(fg_idx != 0), save_all_latents=False)
-    image = sampler.decode(r["latents"])[0] if decode else None
-    return dict(image=image, latents=r["latents"], so_images=so_images, guidance_iters=r["guidance_iters"])
+            d["so_images"].append(imgs[n:n + 1])
+    # ---- composition + stage B
+    jobs_b = []
+    for li, lay in enumerate(lays):
+        d = per_lay[li]
+        composed, fg_idx = compose_latents(d["latents_all"], d["masks"], comp_steps, prep[li][1].to(dev))
+        overall_bboxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
+        flat = [i for grp in lay.overall_groups for i in grp]
+        guid = None
+        if overall_bboxes:
+            guid = dict(bboxes=overall_bboxes, object_positions=lay.overall_object_positions,
+                        loss_scale=overall_loss_scale, loss_threshold=overall_loss_threshold,
+                        max_iter=overall_max_iter or DEFAULT_MAX_ITER, max_index_step=overall_max_index_step,
+                        fg_top_p=overall_fg_top_p, bg_top_p=overall_bg_top_p, fg_weight=overall_fg_weight,
+                        bg_weight=overall_bg_weight, ref_ca_word_token_only=True, ref_ca_last_token_only=True,
+                        word_token_indices=lay.overall_word_token_indices, ref_ca_loss_weight=ref_ca_loss_weight,
+                        guidance_attn_keys=keys,
+                        ref_maps=_ref_maps(sampler, [d["saved"][i] for i in flat], keys, L, T) if use_ref_ca else None)
+        jobs_b.append(Job(composed, torch.cat([lay.overall_uncond, lay.overall_cond]), guidance=guid,
+                          frozen_mask=(fg_idx != 0)))
+    res_b = sampler.denoise_batch(jobs_b, T, guidance_scale=guidance_scale, frozen_steps=frozen_steps,
+                                  save_all_latents=False)
+    images = sampler.decode(torch.cat([r["latents"] for r in res_b])) if decode else [None] * len(lays)
+    return [dict(image=images[li], latents=res_b[li]["latents"], so_images=per_lay[li]["so_images"],
+                 guidance_iters=res_b[li]["guidance_iters"],
+                 so_guidance_iters=[r["guidance_iters"] for (lj, _), r in zip(owner, res_a) if lj == li])
+            for li in range(len(lays))]
 
 
 def backward_guidance_generate(sampler: LMDSampler, lay: CachedLayout, *, num_inference_steps=50,

@@ -271,7 +271,7 @@ class LMDSampler:
                       use_gligen: bool = False, gligen_scheduled_sampling_beta: float = 0.3,
                       frozen_steps: int = 0, saved_cross_attn_keys: Sequence[Tuple] = (),
                       return_cond_ca_only: bool = False, save_all_latents: bool = True,
-                      trace: Optional[list] = None):
+                      trace: Optional[list] = None, fast_after_steps: Optional[int] = None, fast_rate: int = 2):
         """Generic 50-step loop over a batch of independent images (one UNet call serves all of them:
         B = 2*len(jobs) for the CFG pass, len(jobs) for the guidance pass).
 
@@ -280,7 +280,10 @@ class LMDSampler:
         job.text: (2,77,Cx) = [uncond; cond];  job.gligen: (boxes (2,30,4), embeddings (2,30,768), masks (2,30));
         job.guidance: dict(bboxes, object_positions, **semantic_guidance_kwargs, [ref_maps]) or None;
         job.token: return_token_ca_only.
-        Returns per job dict(latents (1,C,L,L), latents_all (T+1,1,C,L,L), saved {key: [T,Bp,H,HW,Tp]},
+        fast_after_steps / fast_rate: the optional fast tail (pipelines.py:151-152,358-359 + schedule.py):
+          after that many steps only every fast_rate-th timestep is run, with the DDIM step size re-derived
+          per step (dynamic_num_inference_steps, lmd_plus.py:109); T_run < T steps are executed.
+        Returns per job dict(latents (1,C,L,L), latents_all (T_run+1,1,C,L,L), saved {key: [T_run,Bp,H,HW,Tp]},
         guidance_iters).
         """
         eng, sch, dev = self.eng, self.scheduler, self.dev
@@ -290,9 +293,13 @@ class LMDSampler:
         T = num_inference_steps
         st = self._state(nb, C, L, T)
         sch.set_timesteps(T)
-        st.ctab.copy_(sch.coef_table(guidance_scale, dev))
-        st.gtab.copy_(sch.guidance_step_table(dev))
-        n_ground = int(gligen_scheduled_sampling_beta * T) if use_gligen else 0
+        ts = sch.timesteps
+        if fast_after_steps is not None:
+            ts = sch.fast_schedule(ts, int(fast_after_steps), int(fast_rate))
+        Tr = len(ts)                                                          # steps actually run
+        st.ctab[:Tr].copy_(sch.coef_table(guidance_scale, dev, timesteps=ts, step_ratios=sch.dynamic_step_sizes(ts)))
+        st.gtab[:Tr].copy_(sch.guidance_step_table(dev, timesteps=ts))
+        n_ground = int(gligen_scheduled_sampling_beta * Tr) if use_gligen else 0   # pipelines.py:405
         save_keys = [tuple(k) for k in saved_cross_attn_keys]
         # a superset of keys is always captured by the main plans so that one graph serves every caller
         plan_keys = sorted(set(save_keys) | {OBJ_KEY_DEFAULT, *DEFAULT_GUIDANCE_ATTN_KEYS}) if save_keys else []
@@ -316,14 +323,14 @@ class LMDSampler:
         max_guided = max([gs.max_index_step for gs in gstates if gs is not None] + [0])
 
         # ---- per-run constants (before graph capture so that warm-up launches see valid inputs)
-        eng.prepare_timesteps([int(t) for t in sch.timesteps])
+        eng.prepare_timesteps([int(t) for t in ts])
         eng.prepare_text(torch.cat([j.text[0:1] for j in jobs] + [j.text[1:2] for j in jobs]))
         eng.set_step(0)
         eng.dyn[1:2].fill_(0)
 
         # ---- plans + launch sequences (built/captured once per shape, cached)
         runners_main, plans_main, runners_guide = {}, {}, {}
-        for f in {fuser_at(i) for i in range(T)}:
+        for f in {fuser_at(i) for i in range(Tr)}:
             plan = plans_main[f] = eng.plan(2 * nb, L, fuser=f, save_keys=plan_keys)
 
             def main_fn(plan=plan):
@@ -334,7 +341,7 @@ class LMDSampler:
                                   mask=st.mask, hist=st.hist)
             runners_main[f] = (main_fn, ("main", f, tuple(plan_keys)))
         if guided:
-            for f in {fuser_at(i) for i in range(min(max_guided, T))}:
+            for f in {fuser_at(i) for i in range(min(max_guided, Tr))}:
                 runners_guide[f] = self._guide_runners(st, nb, L, f, gkeys)
         if use_gligen:                                                        # after the plans exist
             eng.prepare_gligen(boxes=torch.cat([j.gligen[0][0:1] for j in jobs] + [j.gligen[0][1:2] for j in jobs]),
@@ -350,15 +357,16 @@ class LMDSampler:
         if frozen_steps > 0:
             for b, j in enumerate(jobs):
                 if j.frozen_mask is not None and j.latents.dim() == 5:
-                    st.frozen_ref[:, b].copy_(j.latents[:, 0].to(dev, F32))
+                    rows = min(j.latents.shape[0], st.frozen_ref.shape[0])   # a fast-schedule history is shorter
+                    st.frozen_ref[:rows, b].copy_(j.latents[:rows, 0].to(dev, F32))
                     st.mask[b].copy_(j.frozen_mask.to(dev, F32).clamp(0., 1.).reshape(L * L))
             eng.dyn[1:2].fill_(int(frozen_steps))
         hw = self.map_hw(L)
         Bp = 1 if return_cond_ca_only else 2
-        saved = [{k: torch.zeros((T, Bp, self.heads_of(k), hw[k], 1 if j.token is not None else eng.text_len),
+        saved = [{k: torch.zeros((Tr, Bp, self.heads_of(k), hw[k], 1 if j.token is not None else eng.text_len),
                                  device=dev, dtype=F32) for k in save_keys} for j in jobs]
 
-        for index in range(T):
+        for index in range(Tr):
             eng.set_step(index)
             fuser_on = fuser_at(index)
             if guided and index < max_guided:
@@ -372,7 +380,7 @@ class LMDSampler:
                     for k in save_keys:
                         m = maps[k][nb + b:nb + b + 1] if return_cond_ca_only else maps[k][[b, nb + b]]
                         saved[b][k][index].copy_(m[..., int(j.token):int(j.token) + 1] if j.token is not None else m)
-        hist = st.hist.clone() if save_all_latents else None
+        hist = st.hist[:Tr + 1].clone() if save_all_latents else None
         return [dict(latents=st.lat[b:b + 1].clone(), latents_all=hist[:, b:b + 1] if hist is not None else None,
                      saved=saved[b], guidance_iters=gstates[b].iterations if gstates[b] is not None else 0)
                 for b in range(nb)]

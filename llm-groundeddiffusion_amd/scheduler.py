@@ -81,8 +81,28 @@ class DDIMScheduler:
             rows.append([a_t, a_p, guidance_scale, 1.0 if self.config.prediction_type == "v_prediction" else 0.0])
         return torch.tensor(rows, dtype=torch.float32, device=device)
 
-    def guidance_step_table(self, device) -> torch.Tensor:
+    def guidance_step_table(self, device, timesteps=None) -> torch.Tensor:
         """fp32 [T][4] with column 0 = sqrt(1 - alpha_bar_t): DDIM has no `sigmas`, so the latent
         update of backward guidance is scaled this way (pipelines.py:62-69)."""
-        rows = [[float((1 - self.alphas_cumprod[int(t)]) ** 0.5), 0.0, 0.0, 0.0] for t in self.timesteps]
+        ts = self.timesteps if timesteps is None else timesteps
+        rows = [[float((1 - self.alphas_cumprod[int(t)]) ** 0.5), 0.0, 0.0, 0.0] for t in ts]
         return torch.tensor(rows, dtype=torch.float32, device=device)
+
+    # ---- utils/schedule.py (the optional fast tail of the per-box generations)
+    @staticmethod
+    def fast_schedule(timesteps, fast_after_steps, fast_rate=2):
+        """schedule.py:4-8: keep the first `fast_after_steps` timesteps, then every `fast_rate`-th."""
+        if fast_after_steps >= len(timesteps) - 1:
+            return timesteps
+        return torch.cat((timesteps[:fast_after_steps], timesteps[fast_after_steps + 1::fast_rate]), dim=0)
+
+    def dynamic_step_sizes(self, timesteps):
+        """schedule.py:10-12 followed by the scheduler's own prev_timestep rule: before each step the
+        reference sets num_inference_steps = N_train // (t - next_t) (next_t = -1 after the last one) and
+        DDIM then steps by N_train // num_inference_steps.  Returns that step size per index."""
+        n_train = self.config.num_train_timesteps
+        out = []
+        for i, t in enumerate(timesteps):
+            nxt = int(timesteps[i + 1]) if i + 1 < len(timesteps) else -1
+            out.append(n_train // (n_train // (int(t) - nxt)))
+        return out

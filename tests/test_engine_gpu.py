@@ -234,3 +234,53 @@ def test_batched_denoise_matches_single(dev):
         em = rel_l2(rb["saved"][("up", 1, 1, 0)], rs["saved"][("up", 1, 1, 0)])
         print(f"batched vs single: latents {e:.3e} maps {em:.3e}")
         assert e < 3e-2 and em < 6e-2
+
+
+def test_fast_schedule_denoise(dev):
+    """Optional fast tail (schedule.py / pipelines.py:358-359,439-440): the first `fast_after_steps - 1`
+    steps are the plain schedule's steps (bit-identical history rows), fewer steps are run, grounding steps
+    scale with the shortened schedule, and fast_after >= T-1 is a no-op."""
+    from lgd_amd.sampler import Job
+    g = np.load(os.path.join(GOLD, "loops_tiny_gligen.npz"))
+    eng = engine("tiny_gligen", dev)
+    sm = LMDSampler(eng, DDIMScheduler())
+    ehs = torch.from_numpy(g["ehs"])
+    gl = prepare_gligen_condition(BBOXES, torch.from_numpy(g["phrase_emb"]), dev)
+    x0 = torch.from_numpy(g["lat_all_in"])[0]
+    T, fa = 10, 4
+    kw = dict(use_gligen=True, gligen_scheduled_sampling_beta=0.5, saved_cross_attn_keys=[OBJ_KEY, *KEYS],
+              return_cond_ca_only=True)
+    plain = sm.denoise_batch([Job(x0, ehs, gligen=gl, token=7)], T, **kw)[0]
+    fast = sm.denoise_batch([Job(x0, ehs, gligen=gl, token=7)], T, fast_after_steps=fa, **kw)[0]
+    n_run = fa + len(range(fa + 1, T, 2))
+    assert plain["latents_all"].shape[0] == T + 1 and fast["latents_all"].shape[0] == n_run + 1
+    assert fast["saved"][OBJ_KEY].shape[0] == n_run
+    # steps 0..fa-2 are identical (step fa-1 already jumps two timestep ratios, as in the reference)
+    assert torch.equal(plain["latents_all"][:fa], fast["latents_all"][:fa])
+    assert not torch.equal(plain["latents_all"][fa], fast["latents_all"][fa])
+    assert torch.isfinite(fast["latents"]).all()
+    noop = sm.denoise_batch([Job(x0, ehs, gligen=gl, token=7)], T, fast_after_steps=T - 1, **kw)[0]
+    assert torch.equal(noop["latents_all"], plain["latents_all"])
+
+
+def test_lmd_batched_layouts_match_single_and_fast_schedule_runs(dev):
+    """Training-free LMD: two layouts through one batched call equal their separate runs (per-box guided
+    stage A with per-image loop exits + overall stage); the use_fast_schedule variant executes."""
+    from lgd_amd.pipeline import CachedLayout, lmd_generate, lmd_generate_batch
+    cfg = weights.CONFIGS["tiny"]
+    eng = engine("tiny", dev)
+    sm = LMDSampler(eng, DDIMScheduler())
+    lay1 = CachedLayout.synthetic(cfg, [("a white deer", [74, 177, 183, 235]), ("a gray bear", [314, 193, 189, 216])], 3)
+    lay2 = CachedLayout.synthetic(cfg, [("a red ball", [40, 60, 200, 180])], 5)
+    kw = dict(num_inference_steps=6, height=8 * L, width=8 * L, decode=False, loss_threshold=0.0, max_index_step=2,
+              max_iter=[1], overall_loss_threshold=0.0, overall_max_index_step=3, overall_max_iter=[1])
+    both = lmd_generate_batch(sm, [lay1, lay2], **kw)
+    for lay, rb in zip([lay1, lay2], both):
+        rs = lmd_generate(sm, lay, **kw)
+        e = relerr(rb["latents"], rs["latents"])
+        print(f"LMD batched vs single: latents {e:.3e}; iters {rb['guidance_iters']} / {rs['guidance_iters']}")
+        assert rb["guidance_iters"] == rs["guidance_iters"] == 3
+        assert rb["so_guidance_iters"] == rs["so_guidance_iters"] == [2] * len(lay.boxes)
+        assert e < 3e-2
+    fast = lmd_generate(sm, lay1, use_fast_schedule=True, **kw)
+    assert torch.isfinite(fast["latents"]).all() and fast["guidance_iters"] == 3
