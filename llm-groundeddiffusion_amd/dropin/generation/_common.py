@@ -42,8 +42,9 @@ def convert_spec(spec, height, width, include_counts=True, verbose=False):
 
 
 def build_layout(spec, bg_seed, fg_seed_start, so_negative_prompt, overall_negative_prompt, height=512, width=512,
-                 overall_prompt_override="", so_center_box=False, so_horizontal_center_only=True, verbose=False):
-    """Text side of lmd_plus.run / lmd.run for one spec -> CachedLayout + overall bboxes."""
+                 overall_prompt_override="", verbose=False):
+    """Text side of lmd_plus.run / lmd.run for one spec -> CachedLayout (boxes are the ORIGINAL boxes; the
+    optional centring of the per-box generations is done by the pipeline, lgd_amd.pipeline._centered_so_boxes)."""
     md = models.model_dict
     tok, te = md.tokenizer, md.text_encoder
     if tok is None or te is None:
@@ -52,10 +53,6 @@ def build_layout(spec, bg_seed, fg_seed_start, so_negative_prompt, overall_negat
     so_list, overall_prompt, overall = convert_spec(spec, height, width, verbose=verbose)
     if overall_prompt_override and overall_prompt_override.strip():
         overall_prompt = overall_prompt_override.strip()
-    if so_center_box:
-        import utils
-        so_list = [(p, ph, w, utils.get_centered_box(b, horizontal_center_only=so_horizontal_center_only))
-                   for p, ph, w, b in so_list]
     if spec.get("extra_neg_prompt"):
         so_negative_prompt = spec["extra_neg_prompt"] + ", " + so_negative_prompt
         overall_negative_prompt = spec["extra_neg_prompt"] + ", " + overall_negative_prompt

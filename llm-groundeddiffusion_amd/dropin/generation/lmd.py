@@ -13,22 +13,21 @@ def run(spec, bg_seed=1, overall_prompt_override="", fg_seed_start=20, frozen_st
         loss_scale=5, loss_threshold=5.0, max_iter=DEFAULT_MAX_ITER, max_index_step=30, overall_loss_scale=5,
         overall_loss_threshold=5.0, overall_max_iter=DEFAULT_MAX_ITER, overall_max_index_step=30, fg_top_p=0.2,
         bg_top_p=0.2, overall_fg_top_p=0.2, overall_bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0, overall_fg_weight=1.0,
-        overall_bg_weight=4.0, ref_ca_loss_weight=2.0, so_center_box=False, fg_blending_ratio=0.01,
+        overall_bg_weight=4.0, ref_ca_loss_weight=2.0, so_center_box=True, fg_blending_ratio=0.01,
         so_negative_prompt=DEFAULT_SO_NEGATIVE_PROMPT, overall_negative_prompt=DEFAULT_OVERALL_NEGATIVE_PROMPT,
-        mask_th_for_point=0.25, so_horizontal_center_only=False, align_with_overall_bboxes=False,
+        mask_th_for_point=0.25, so_horizontal_center_only=False, align_with_overall_bboxes=True,
         horizontal_shift_only=False, use_fast_schedule=False, so_vertical_placement="floor_padding",
         so_floor_padding=0.2, use_box_input=False, use_ref_ca=True, use_autocast=False, verbose=False):
-    """Argument names of generation/lmd.py:215-256.  Differences from the reference defaults, stated:
-    `so_center_box` / `align_with_overall_bboxes` default to False here (the centred-box + re-alignment
-    variant needs SAM masks to be meaningful; with box masks the per-box generation runs in place)."""
-    if so_center_box or align_with_overall_bboxes:
-        raise NotImplementedError("so_center_box / align_with_overall_bboxes: not wired on the HIP path")
+    """Argument names and defaults of generation/lmd.py:215-256 (incl. so_center_box=True /
+    align_with_overall_bboxes=True: per-box generations run on a centred box, histories, masks and
+    reference maps are shifted back onto the overall boxes before composition).  SAM-only arguments
+    (`mask_th_for_point`, `use_box_input`) are accepted and unused: masks are the box masks."""
     if num_inference_steps <= 10:
         # the reference crashes here too (attn_aggregation_step_start=10, generation/lmd.py:36,124-131)
         print("note: the reference's SAM point prompt aggregates maps from step 10 on; with <=10 steps it would fail")
     sm = models.model_dict.sampler
     lay = build_layout(spec, bg_seed, fg_seed_start, so_negative_prompt, overall_negative_prompt, height, width,
-                       overall_prompt_override, False, so_horizontal_center_only, verbose)
+                       overall_prompt_override, verbose)
     out = lmd_generate(sm, lay, num_inference_steps=num_inference_steps, frozen_step_ratio=frozen_step_ratio,
                        guidance_scale=guidance_scale, loss_scale=loss_scale, loss_threshold=loss_threshold,
                        max_iter=max_iter, max_index_step=max_index_step, overall_loss_scale=overall_loss_scale,
@@ -37,5 +36,8 @@ def run(spec, bg_seed=1, overall_prompt_override="", fg_seed_start=20, frozen_st
                        overall_fg_top_p=overall_fg_top_p, overall_bg_top_p=overall_bg_top_p, fg_weight=fg_weight,
                        bg_weight=bg_weight, overall_fg_weight=overall_fg_weight, overall_bg_weight=overall_bg_weight,
                        ref_ca_loss_weight=ref_ca_loss_weight, fg_blending_ratio=fg_blending_ratio, use_ref_ca=use_ref_ca,
-                       height=height, width=width, use_fast_schedule=use_fast_schedule)
+                       height=height, width=width, use_fast_schedule=use_fast_schedule,
+                       so_center_box=so_center_box, so_horizontal_center_only=so_horizontal_center_only,
+                       so_vertical_placement=so_vertical_placement, so_floor_padding=so_floor_padding,
+                       align_with_overall_bboxes=align_with_overall_bboxes, horizontal_shift_only=horizontal_shift_only)
     return EasyDict(image=out["image"], so_img_list=out["so_images"])

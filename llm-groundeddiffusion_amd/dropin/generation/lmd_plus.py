@@ -25,11 +25,9 @@ def run(spec, bg_seed=1, overall_prompt_override="", fg_seed_start=20, frozen_st
     if max_index_step != 0:
         raise NotImplementedError("per-box attention guidance in LMD+ (max_index_step>0) is disabled in the reference "
                                   "by default and not wired on the HIP path")
-    if align_with_overall_bboxes:
-        raise NotImplementedError("align_with_overall_bboxes is off by default in LMD+ and not wired on the HIP path")
     sm = models.model_dict.sampler
     lay = build_layout(spec, bg_seed, fg_seed_start, so_negative_prompt, overall_negative_prompt, height, width,
-                       overall_prompt_override, so_center_box, so_horizontal_center_only, verbose)
+                       overall_prompt_override, verbose)
     print("Key generation settings:", spec, bg_seed, fg_seed_start, frozen_step_ratio,
           so_gligen_scheduled_sampling_beta, overall_gligen_scheduled_sampling_beta, overall_max_index_step)
     out = lmd_plus_generate(sm, lay, num_inference_steps=num_inference_steps, frozen_step_ratio=frozen_step_ratio,
@@ -41,5 +39,8 @@ def run(spec, bg_seed=1, overall_prompt_override="", fg_seed_start=20, frozen_st
                             overall_fg_top_p=overall_fg_top_p, overall_bg_top_p=overall_bg_top_p,
                             overall_fg_weight=overall_fg_weight, overall_bg_weight=overall_bg_weight,
                             ref_ca_loss_weight=ref_ca_loss_weight, fg_blending_ratio=fg_blending_ratio,
-                            use_ref_ca=use_ref_ca, height=height, width=width, use_fast_schedule=use_fast_schedule)
+                            use_ref_ca=use_ref_ca, height=height, width=width, use_fast_schedule=use_fast_schedule,
+                            so_center_box=so_center_box, so_horizontal_center_only=so_horizontal_center_only,
+                            align_with_overall_bboxes=align_with_overall_bboxes,
+                            horizontal_shift_only=horizontal_shift_only)
     return EasyDict(image=out["image"], so_img_list=out["so_images"])

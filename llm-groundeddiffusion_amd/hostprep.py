@@ -78,8 +78,9 @@ def binary_mask_to_center(mask, normalize=False):
     h, w = mask.shape
     total = mask.sum()
     if isinstance(mask, torch.Tensor):
-        x_coord = ((mask.sum(dim=0) @ torch.arange(w)) / total).item()
-        y_coord = ((mask.sum(dim=1) @ torch.arange(h)) / total).item()
+        cs, rs = mask.sum(dim=0), mask.sum(dim=1)          # bool masks (the reference's case) sum to int64
+        x_coord = ((cs @ torch.arange(w, dtype=cs.dtype)) / total).item()
+        y_coord = ((rs @ torch.arange(h, dtype=rs.dtype)) / total).item()
     else:
         x_coord = (mask.sum(axis=0) @ np.arange(w)) / total
         y_coord = (mask.sum(axis=1) @ np.arange(h)) / total
@@ -173,7 +174,7 @@ def align_with_bboxes(latents_all_list, mask_list, bboxes, horizontal_shift_only
     """latents.py:85-106."""
     new_l, new_m, offsets = [], [], []
     for lat, m, bbox in zip(latents_all_list, mask_list, bboxes):
-        xs, ys = binary_mask_to_center(m.cpu().float(), normalize=True)
+        xs, ys = binary_mask_to_center(m.cpu(), normalize=True)
         x_off = (bbox[0] + bbox[2]) / 2 - xs
         y_off = 0. if horizontal_shift_only else (bbox[1] + bbox[3]) / 2 - ys
         new_l.append(shift_tensor(lat, x_off, y_off, offset_normalized=True))

@@ -74,7 +74,8 @@ class CachedLayout:
             bg_seed=index, fg_seed_start=index + 123456789)                      # generate.py:226-229,317-344
 
 
-from .hostprep import compose as compose_latents, input_latents_list as _input_latents_list, proportion_to_mask
+from .hostprep import (align_with_bboxes, compose as compose_latents, get_centered_box,
+                       input_latents_list as _input_latents_list, proportion_to_mask, shift_tensor)
 
 
 def get_input_latents_list(bg_seed, fg_seed_start, so_boxes, fg_blending_ratio, in_channels=4, H=64, W=64):
@@ -95,6 +96,34 @@ def _ref_maps(sampler: LMDSampler, saved_list, keys, L, T):
     return out
 
 
+def _centered_so_boxes(lay, so_center_box, **centered_box_kwargs):
+    """lmd.py:314-324 / lmd_plus.py:286-297: the per-box generations may run on a centred copy of each box
+    (the overall generation keeps the original boxes)."""
+    if not so_center_box:
+        return [list(b) for b in lay.boxes]
+    return [get_centered_box(list(b), **centered_box_kwargs) for b in lay.boxes]
+
+
+def _align_stage_a(d, lay, keys, align_with_overall_bboxes, horizontal_shift_only):
+    """latents.py:85-118 + attn.py:40-70 (lmd.py:489-497): shift every per-box history, its mask and its
+    saved reference maps so that the mask's centre of mass lands on the centre of the box it will occupy
+    in the overall generation (offsets quantised on the 8x8 grid, zero fill)."""
+    if not (align_with_overall_bboxes and d["latents_all"]):
+        return
+    flat = [i for grp in lay.overall_groups for i in grp]                    # utils.expand_overall_bboxes order
+    targets = [list(lay.boxes[i]) for i in flat]
+    d["latents_all"], d["masks"], offsets = align_with_bboxes(d["latents_all"], d["masks"], targets,
+                                                              horizontal_shift_only=horizontal_shift_only)
+    for saved, (x_off, y_off) in zip(d["saved"], offsets):
+        for k in keys:
+            if k not in saved:
+                continue
+            m = saved[k]                                                      # [T, Bp, heads, HW, Tp]
+            side = int(round(m.shape[3] ** 0.5))
+            m = shift_tensor(m.unflatten(3, (side, side)), x_off, y_off, offset_normalized=True, ignore_last_dim=True)
+            saved[k] = m.flatten(3, 4)
+
+
 def lmd_plus_generate(sampler: LMDSampler, lay: CachedLayout, **kw):
     """LMD+ for one layout (generation/lmd_plus.py:193-520 with its default arguments)."""
     return lmd_plus_generate_batch(sampler, [lay], **kw)[0]
@@ -107,7 +136,8 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
                             overall_fg_top_p=0.2, overall_bg_top_p=0.2, overall_fg_weight=1.0,
                             overall_bg_weight=4.0, ref_ca_loss_weight=2.0, fg_blending_ratio=0.1,
                             use_ref_ca=True, height=512, width=512, decode=True, guidance_attn_keys=None,
-                            use_fast_schedule=False):
+                            use_fast_schedule=False, so_center_box=False, so_horizontal_center_only=True,
+                            align_with_overall_bboxes=False, horizontal_shift_only=True):
     """LMD+ (generation/lmd_plus.py:193-520, default arguments; per-box guidance is off there:
     max_index_step=0, :203) for a batch of independent layouts: the per-box generations of ALL layouts run
     as one batched denoising call (B = 2 x total boxes), then the overall generations of all layouts as
@@ -119,8 +149,10 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
     keys = [tuple(k) for k in (guidance_attn_keys or DEFAULT_GUIDANCE_ATTN_KEYS)]
     dev = sampler.dev
     C = sampler.eng.cfg.in_channels
-    prep = [get_input_latents_list(lay.bg_seed, lay.fg_seed_start, lay.boxes, fg_blending_ratio, C, L, L)
-            for lay in lays]
+    so_boxes = [_centered_so_boxes(lay, so_center_box, horizontal_center_only=so_horizontal_center_only)
+                for lay in lays]
+    prep = [get_input_latents_list(lay.bg_seed, lay.fg_seed_start, so_boxes[li], fg_blending_ratio, C, L, L)
+            for li, lay in enumerate(lays)]
     # use_fast_schedule (lmd_plus.py:360-367): the per-box generations only feed SAM after the steps needed
     # for latent / attention transfer, so the rest runs on every second timestep.
     fast_after = (max(frozen_steps, overall_max_index_step) if use_ref_ca else frozen_steps) if use_fast_schedule else None
@@ -129,7 +161,7 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
     jobs, owner = [], []
     if use_ref_ca or frozen_steps > 0:
         for li, lay in enumerate(lays):
-            for i, box in enumerate(lay.boxes):
+            for i, box in enumerate(so_boxes[li]):
                 jobs.append(Job(prep[li][0][i], torch.cat([lay.so_uncond, lay.so_cond[i:i + 1]]),
                                 gligen=prepare_gligen_condition([list(box)], lay.phrase_embeddings[i:i + 1], dev),
                                 token=lay.so_word_token_index[i]))
@@ -145,13 +177,14 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
         d = per_lay[li]
         d["latents_all"].append(r["latents_all"])
         d["saved"].append(r["saved"])
-        d["masks"].append(proportion_to_mask(lays[li].boxes[i], L, L).bool())   # SAM stand-in
+        d["masks"].append(proportion_to_mask(so_boxes[li][i], L, L).bool())   # SAM stand-in
         if decode:
             d["so_images"].append(imgs[n:n + 1])
     # ---- composition (lmd_plus.py:398-416) and stage B: overall generation with attention guidance
     jobs_b, comps = [], []
     for li, lay in enumerate(lays):
         d = per_lay[li]
+        _align_stage_a(d, lay, keys, align_with_overall_bboxes, horizontal_shift_only)
         composed, fg_idx = compose_latents(d["latents_all"], d["masks"], comp_steps, prep[li][1].to(dev))
         comps.append((composed, fg_idx))
         overall_bboxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
@@ -189,7 +222,9 @@ def lmd_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, num_inf
                        overall_max_index_step=30, fg_top_p=0.2, bg_top_p=0.2, overall_fg_top_p=0.2,
                        overall_bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0, overall_fg_weight=1.0,
                        overall_bg_weight=4.0, ref_ca_loss_weight=2.0, fg_blending_ratio=0.01, use_ref_ca=True,
-                       height=512, width=512, decode=True, guidance_attn_keys=None, use_fast_schedule=False):
+                       height=512, width=512, decode=True, guidance_attn_keys=None, use_fast_schedule=False,
+                       so_center_box=False, so_horizontal_center_only=False, so_vertical_placement="floor_padding",
+                       so_floor_padding=0.2, align_with_overall_bboxes=False, horizontal_shift_only=False):
     """Training-free LMD (generation/lmd.py:215-551) for a batch of independent layouts: per-box stage =
     generate_semantic_guidance WITH guidance (lmd.py:340-352), all boxes of all layouts in one batched
     denoising call (each image keeps its own guidance loop exit); overall stage = generate_partial_frozen
@@ -200,15 +235,18 @@ def lmd_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, num_inf
     keys = [tuple(k) for k in (guidance_attn_keys or DEFAULT_GUIDANCE_ATTN_KEYS)]
     dev = sampler.dev
     C = sampler.eng.cfg.in_channels
-    prep = [get_input_latents_list(lay.bg_seed, lay.fg_seed_start, lay.boxes, fg_blending_ratio, C, L, L)
-            for lay in lays]
+    so_boxes = [_centered_so_boxes(lay, so_center_box, horizontal_center_only=so_horizontal_center_only,
+                                   vertical_placement=so_vertical_placement, floor_padding=so_floor_padding)
+                for lay in lays]                                              # lmd.py:314-324
+    prep = [get_input_latents_list(lay.bg_seed, lay.fg_seed_start, so_boxes[li], fg_blending_ratio, C, L, L)
+            for li, lay in enumerate(lays)]
     fast_after = (max(frozen_steps, overall_max_index_step) if use_ref_ca else frozen_steps) \
         if use_fast_schedule else None                                        # lmd.py:399-406
     comp_steps = fast_after if use_fast_schedule else T
     # ---- stage A
     jobs, owner = [], []
     for li, lay in enumerate(lays):
-        for i, box in enumerate(lay.boxes):
+        for i, box in enumerate(so_boxes[li]):
             guid = dict(bboxes=[list(box)], object_positions=[lay.so_object_positions[i]], loss_scale=loss_scale,
                         loss_threshold=loss_threshold, max_iter=max_iter or DEFAULT_MAX_ITER,
                         max_index_step=max_index_step, fg_top_p=fg_top_p, bg_top_p=bg_top_p, fg_weight=fg_weight,
@@ -226,13 +264,14 @@ def lmd_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, num_inf
         d = per_lay[li]
         d["latents_all"].append(r["latents_all"])
         d["saved"].append(r["saved"])
-        d["masks"].append(proportion_to_mask(lays[li].boxes[i], L, L).bool())   # SAM stand-in
+        d["masks"].append(proportion_to_mask(so_boxes[li][i], L, L).bool())   # SAM stand-in
         if decode:
             d["so_images"].append(imgs[n:n + 1])
-    # ---- composition + stage B
+    # ---- alignment (latents.py:107-118), composition, stage B
     jobs_b = []
     for li, lay in enumerate(lays):
         d = per_lay[li]
+        _align_stage_a(d, lay, keys, align_with_overall_bboxes, horizontal_shift_only)
         composed, fg_idx = compose_latents(d["latents_all"], d["masks"], comp_steps, prep[li][1].to(dev))
         overall_bboxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
         flat = [i for grp in lay.overall_groups for i in grp]

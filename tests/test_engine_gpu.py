@@ -284,3 +284,21 @@ def test_lmd_batched_layouts_match_single_and_fast_schedule_runs(dev):
         assert e < 3e-2
     fast = lmd_generate(sm, lay1, use_fast_schedule=True, **kw)
     assert torch.isfinite(fast["latents"]).all() and fast["guidance_iters"] == 3
+
+
+def test_lmd_reference_default_variant_centered_and_aligned(dev):
+    """generation/lmd.py defaults (so_center_box=True, align_with_overall_bboxes=True): per-box generations on
+    the centred boxes, histories / masks / reference maps shifted back before composition (host wiring is
+    pinned bit-exactly in tests/test_align_host.py); here the whole path runs on the device."""
+    from lgd_amd.pipeline import CachedLayout, lmd_generate
+    cfg = weights.CONFIGS["tiny"]
+    sm = LMDSampler(engine("tiny", dev), DDIMScheduler())
+    lay = CachedLayout.synthetic(cfg, [("a white deer", [74, 177, 183, 235]), ("a gray bear", [314, 193, 189, 216])], 3)
+    kw = dict(num_inference_steps=6, height=8 * L, width=8 * L, decode=False, loss_threshold=0.0, max_index_step=2,
+              max_iter=[1], overall_loss_threshold=0.0, overall_max_index_step=3, overall_max_iter=[1])
+    plain = lmd_generate(sm, lay, **kw)
+    ref_default = lmd_generate(sm, lay, so_center_box=True, align_with_overall_bboxes=True, **kw)
+    again = lmd_generate(sm, lay, so_center_box=True, align_with_overall_bboxes=True, **kw)
+    assert torch.isfinite(ref_default["latents"]).all() and ref_default["guidance_iters"] == 3
+    assert torch.equal(ref_default["latents"], again["latents"])              # deterministic
+    assert not torch.equal(ref_default["latents"], plain["latents"])
