@@ -294,7 +294,8 @@ def test_lmd_reference_default_variant_centered_and_aligned(dev):
     cfg = weights.CONFIGS["tiny"]
     sm = LMDSampler(engine("tiny", dev), DDIMScheduler())
     lay = CachedLayout.synthetic(cfg, [("a white deer", [74, 177, 183, 235]), ("a gray bear", [314, 193, 189, 216])], 3)
-    kw = dict(num_inference_steps=6, height=8 * L, width=8 * L, decode=False, loss_threshold=0.0, max_index_step=2,
+    # 64x64 latents: the 8x8-grid shift quantisation needs the mid-block map to be at least 8x8 (utils.py:150)
+    kw = dict(num_inference_steps=6, height=512, width=512, decode=False, loss_threshold=0.0, max_index_step=2,
               max_iter=[1], overall_loss_threshold=0.0, overall_max_index_step=3, overall_max_iter=[1])
     plain = lmd_generate(sm, lay, **kw)
     ref_default = lmd_generate(sm, lay, so_center_box=True, align_with_overall_bboxes=True, **kw)
