@@ -58,6 +58,10 @@ CONFIGS = {
                        sample_size=32),
     "tiny_gligen": UNetConfig(name="tiny_gligen", block_out_channels=(64, 128, 256, 256),
                               cross_attention_dim=768, use_gated_attention=True, sample_size=32),
+    # SD2.x-style topology in small: linear proj_in/proj_out, heads per level chosen so that every head is
+    # 64 wide (the SD2.1 head dim), text width != 768
+    "tiny_sd21": UNetConfig(name="tiny_sd21", block_out_channels=(64, 128, 256, 256), cross_attention_dim=192,
+                            attention_head_dim=(1, 2, 4, 4), use_linear_projection=True, sample_size=32),
     "sd15": UNetConfig(name="sd15"),
     "sd14_gligen": UNetConfig(name="sd14_gligen", use_gated_attention=True),
     "sd21": UNetConfig(name="sd21", cross_attention_dim=1024, attention_head_dim=(5, 10, 20, 20),

@@ -61,8 +61,9 @@ def engine(name, dev):
     return _ENG[name]
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_gligen"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_gligen", "tiny_sd21"])
 def test_unet_forward_and_maps_vs_reference_golden(dev, name):
+    """tiny_sd21: SD2.x-style topology (linear proj_in/out, 1/2/4/4 heads of width 64, text width 192)."""
     g = np.load(os.path.join(GOLD, f"unet_fwd_{name}.npz"))
     eng = engine(name, dev)
     gl = "gl_boxes" in g
