@@ -1,7 +1,9 @@
 // Flash-style scaled-dot-product attention for gfx950 — forward.
 //
-// Work decomposition: grid = (ceil(Sq/64), H, B); 4 waves per workgroup, each wave owns 16 query
-// rows; K/V are consumed in tiles of 64 keys staged in LDS (register-prefetched one tile ahead).
+// Two kernels: attn_fwd_kernel (cross-attention WITH probability-map capture: exact two-pass softmax) and
+// attn_self_kernel (everything without map capture: self-attention, GLIGEN fuser attention, plain
+// cross-attention).  Both: 4 waves per workgroup, each wave owns 16 (or 2x16) query rows; K/V are
+// consumed in tiles of 64 keys staged in LDS (register-prefetched one tile ahead).
 //
 // MFMA layout trick (no LDS round trip for P): both products are issued transposed,
 //     S^T = K Q^T   (A := K rows,  B := Q rows)   -> lane holds query (lane&15), 4 keys per tile
@@ -12,9 +14,8 @@
 // on both operands: element j of lane group g is key 32c + (j<4 ? g*4+j : 16+g*4+j-4), which is
 // why V is staged transposed ([dv][key]) and read as two 8-byte pieces.
 //
-// SAVE_P variant (cross-attention map capture, attention_processor.py:440-480): two passes over
-// the keys — pass 1 row max / row sum, pass 2 normalised probabilities, which are written to the
-// fp32 map and fed to the PV product.
+// Map capture (attention_processor.py:440-480): two passes over the keys — pass 1 row max / row sum,
+// pass 2 normalised probabilities, which are written to the fp32 map and fed to the PV product.
 #include "common.h"
 #include "../../include/lgd_hip.h"
 
@@ -38,9 +39,9 @@ struct AttnArgs {
   float scale_log2;  // scale * log2(e)
 };
 
-// ONES (only without SAVE_P, needs d < DP): row d of the transposed V tile is set to 1, so the PV
-// MFMA also produces the softmax row sum (in accumulator row d) and the VALU never adds it up.
-template <int DP, bool SAVE_P, bool ONES>
+// Map-capture kernel (cross-attention with a saved probability map).  Attention WITHOUT map capture
+// goes through attn_self_kernel below.
+template <int DP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   constexpr int K_LD = DP + 16;
   constexpr int NDC = DP / 32;  // 32-wide chunks of the head dim (QK^T contraction)
@@ -119,7 +120,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           half2_t pr = {e0[e], e1[e]};
-          if (ONES && seg * 8 + e == d) pr = (half2_t){(half_t)1.f, (half_t)1.f};
           *reinterpret_cast<half2_t*>(Vt + (seg * 8 + e) * VT_LD + pair * 2) = pr;
         }
       }
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 
   const int n_tiles = (a.Sk + KV_T - 1) / KV_T;
 
-  if (SAVE_P) {
+  {
     // ---- pass 1: exact row max and row sum
     load_tile(0);
     store_tile();
@@ -238,91 +238,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
       }
     }
     l_run = 1.f;  // already normalised
-  } else {
-    // Softmax work per score is what bounds this kernel at head dims 40/80 (one MFMA pass covers 32
-    // of the contraction, the exp is quarter rate), so the VALU side is pared down to:
-    //   max3 chain, one fma (scale and reference shift), v_exp_f32, packed fp16 convert.
-    //  * the running reference m_ref is only raised when some row's tile max exceeds it by more
-    //    than 2^8 (wave-uniform vote): P stays <= 256 (exact in the fp32 accumulators, fine as an
-    //    fp16 MFMA operand) and the accumulator rescale all but disappears after the first tiles;
-    //  * the row sum comes out of the PV MFMA (ONES), and the tail mask is a uniform branch.
-    float m_ref = NEG_BIG;
-    const float sc = a.scale_log2;
-    load_tile(0);
-    store_tile();
-    __syncthreads();
-    for (int t = 0; t < n_tiles; ++t) {
-      if (t + 1 < n_tiles) load_tile((t + 1) * KV_T);
-      const int kv0 = t * KV_T;
-      f32x4 s[4];
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int dc = 0; dc < NDC; ++dc) {
-          half8_t kf =
-              *reinterpret_cast<const half8_t*>(Ks + (kt * 16 + c16) * K_LD + dc * 32 + g * 8);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[dc], acc, 0, 0, 0);
-        }
-        s[kt] = acc;
-      }
-      if (kv0 + KV_T > a.Sk) {  // ragged last tile
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (kv0 + kt * 16 + g * 4 + r >= a.Sk) s[kt][r] = NEG_BIG;
-      }
-      float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
-      mx = fmaxf(fmaxf(mx, s[0][3]), s[1][0]);
-      mx = fmaxf(fmaxf(mx, s[1][1]), s[1][2]);
-      mx = fmaxf(fmaxf(mx, s[1][3]), s[2][0]);
-      mx = fmaxf(fmaxf(mx, s[2][1]), s[2][2]);
-      mx = fmaxf(fmaxf(mx, s[2][3]), s[3][0]);
-      mx = fmaxf(fmaxf(mx, s[3][1]), s[3][2]);
-      mx = fmaxf(mx, s[3][3]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mxs = mx * sc;
-      if (__builtin_amdgcn_ballot_w64(mxs > m_ref + 8.f) != 0) {
-        const float m_new = fmaxf(m_ref, mxs);
-        const float alpha = __builtin_amdgcn_exp2f(m_ref - m_new);
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
-        if (!ONES) l_run *= alpha;
-        m_ref = m_new;
-      }
-      const float nm = -m_ref;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc, nm));
-          s[kt][r] = p;
-          if (!ONES) l_run += p;
-        }
-      pv(s);
-      __syncthreads();
-      if (t + 1 < n_tiles) {
-        store_tile();
-        __syncthreads();
-      }
-    }
-    m_run = m_ref;
-    if (ONES) {
-      // row sum of query c16 sits in accumulator row d: tile d/16, lane group (d%16)/4, register 0
-      const int dt_l = d >> 4, g_l = (d & 15) >> 2;
-      float lv = 0.f;
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt)
-        if (dt == dt_l) lv = oacc[dt][0];
-      l_run = __shfl(lv, g_l * 16 + c16, 64);
-    } else {
-      l_run += __shfl_xor(l_run, 16, 64);
-      l_run += __shfl_xor(l_run, 32, 64);
-    }
   }
 
   // ---- epilogue: lane owns query q0+c16, dv = dt*16 + g*4 + r
@@ -340,8 +255,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         *reinterpret_cast<half4_t*>(orow + dv) = o;
       }
     }
-    if (a.lse && g == 0 && !SAVE_P)
-      a.lse[((long)b * a.H + h) * a.Sq + qrow] = m_run + log2f(l_run);
   }
 }
 
@@ -658,7 +571,7 @@ template <int DP, bool SAVE_P>
 void launch_attn_dp(const AttnArgs& a, hipStream_t st) {
   if constexpr (SAVE_P) {
     dim3 grid((a.Sq + 63) / 64, a.H, a.B);
-    hipLaunchKernelGGL((attn_fwd_kernel<DP, true, false>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<DP>), grid, dim3(256), 0, st, a);
   } else {
     // two query tiles per wave once there are enough 128-query blocks to fill the chip
     const bool qt2 = (long)((a.Sq + 127) / 128) * a.H * a.B >= 1024 && DP <= 96;

@@ -107,8 +107,19 @@ def test_plugin_run_contract(dropin):
     import generation.backward_guidance as gb
     assert gl.version == "lmd" and gb.version == "backward_guidance"
     gl.height = gl.width = 256
-    out = gl.run(spec, bg_seed=3, fg_seed_start=99, num_inference_steps=12, max_index_step=3, overall_max_index_step=3)
+    # 256^2 (32x32 latents): the centred-box + re-alignment defaults need the mid-block map to be >= 8x8
+    # (utils/utils.py:150 asserts, in the reference as well), so they are switched off at this size ...
+    out = gl.run(spec, bg_seed=3, fg_seed_start=99, num_inference_steps=12, max_index_step=3, overall_max_index_step=3,
+                 so_center_box=False, align_with_overall_bboxes=False)
     assert out.image.shape == (256, 256, 3)
+    with pytest.raises(AssertionError):
+        gl.run(spec, bg_seed=3, fg_seed_start=99, num_inference_steps=12, max_index_step=3, overall_max_index_step=3)
+    # ... and exercised with the reference defaults at 512^2
+    gl.height = gl.width = 512
+    spec512 = dict(spec, gen_boxes=[("a white deer", [74, 177, 183, 235]), ("a gray bear", [314, 193, 189, 216])])
+    out = gl.run(spec512, bg_seed=3, fg_seed_start=99, num_inference_steps=12, max_index_step=3, overall_max_index_step=3,
+                 use_fast_schedule=True)
+    assert out.image.shape == (512, 512, 3) and out.image.dtype == np.uint8
 
 
 def test_phrase_indices_and_energy_hook(dropin, dev):
