@@ -26,6 +26,12 @@ def init(backend=None):
     dist.init_process_group(backend=backend)
 
 
+def shutdown():
+    """Tear the process group down (local operation; no rank is inside a collective when it is called)."""
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def world():
     return dist.get_world_size() if dist.is_initialized() else 1
 
