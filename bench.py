@@ -146,8 +146,8 @@ def main():
     dt = time.perf_counter() - t0
     dt = ldist.max_over_ranks(dt)
     n_images = args.steps * args.layouts * world
+    ldist.shutdown()            # all ranks together, right after the last collective; the rest is rank-0 local
     if rank != 0:
-        ldist.shutdown()
         return
     it_per_image = iters / max(args.steps * args.layouts, 1)
     # ---- roofline of the dominant kernel.  The timed region replays captured hipGraphs (one launch per
@@ -222,7 +222,6 @@ def main():
             res["cpu_baseline"] = dict(value=None, unit="images/s", cores=os.cpu_count(), kind="port",
                                        sample=f"failed: {e}")
     print(json.dumps(res))
-    ldist.shutdown()
 
 
 if __name__ == "__main__":
