@@ -304,3 +304,24 @@ def test_lmd_reference_default_variant_centered_and_aligned(dev):
     assert torch.isfinite(ref_default["latents"]).all() and ref_default["guidance_iters"] == 3
     assert torch.equal(ref_default["latents"], again["latents"])              # deterministic
     assert not torch.equal(ref_default["latents"], plain["latents"])
+
+
+def test_fast_schedule_loop_vs_reference_golden(dev):
+    """The reference's own generate_gligen(dynamic_num_inference_steps=True, fast_after_steps=4, fast_rate=2)
+    on the tiny GLIGEN config (oracle/make_golden_fast.py): 7 of 10 timesteps run, grounding for int(0.5*7)
+    steps, history kept for the slow steps only."""
+    from lgd_amd.sampler import Job
+    g = np.load(os.path.join(GOLD, "fast_tiny_gligen.npz"))
+    sm = LMDSampler(engine("tiny_gligen", dev), DDIMScheduler())
+    gl = prepare_gligen_condition(BBOXES, torch.from_numpy(g["phrase_emb"]), dev)
+    T, fa = int(g["T"]), int(g["fast_after"])
+    out = sm.denoise_batch([Job(torch.from_numpy(g["lat0"]), torch.from_numpy(g["ehs"]), gligen=gl, token=7)], T,
+                           use_gligen=True, gligen_scheduled_sampling_beta=0.5, saved_cross_attn_keys=[OBJ_KEY, *KEYS],
+                           return_cond_ca_only=True, fast_after_steps=fa)[0]
+    n_run = int(g["n_saved"])
+    assert out["saved"][OBJ_KEY].shape[0] == n_run == len(g["timesteps"])
+    e_hist = relerr(out["latents_all"][:fa + 1], g["latents_all"])
+    e_fin = relerr(out["latents"], g["latents"])
+    em = rel_l2(out["saved"][("up", 1, 1, 0)][n_run - 1], g["saved_up11_last"])
+    print(f"fast schedule: history relerr {e_hist:.3e}, final latents {e_fin:.3e}, last map rel-L2 {em:.3e}")
+    assert e_hist < 3e-2 and e_fin < 5e-2 and em < 1e-1
