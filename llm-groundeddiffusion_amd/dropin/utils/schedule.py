@@ -1,22 +1,25 @@
-"""utils/schedule.py of the reference (host side)."""
+"""`utils.schedule` of the reference (optional fast tail of the per-box generations) — adapters over
+lgd_amd.scheduler.DDIMScheduler, whose `fast_schedule` / `dynamic_step_sizes` are pinned bit-exactly against
+the reference's own functions (tests/test_schedule.py)."""
 import warnings
 
-import torch
+from lgd_amd.scheduler import DDIMScheduler as _Sched
 
 
 def get_fast_schedule(origial_timesteps, fast_after_steps, fast_rate):
-    """schedule.py:4-8: stride `fast_rate` after `fast_after_steps`."""
-    if fast_after_steps >= len(origial_timesteps) - 1:
-        return origial_timesteps
-    return torch.cat((origial_timesteps[:fast_after_steps], origial_timesteps[fast_after_steps + 1::fast_rate]), dim=0)
+    """Same (misspelt) argument names as schedule.py:4."""
+    return _Sched.fast_schedule(origial_timesteps, fast_after_steps, fast_rate)
 
 
 def dynamically_adjust_inference_steps(scheduler, index, t):
-    """schedule.py:10-19: keep DDIM's prev_t = t - 1000//n consistent with an irregular schedule."""
-    prev_t = scheduler.timesteps[index + 1] if index + 1 < len(scheduler.timesteps) else -1
-    scheduler.num_inference_steps = scheduler.config.num_train_timesteps // int(t - prev_t)
-    if index + 1 < len(scheduler.timesteps):
-        if scheduler.config.num_train_timesteps // scheduler.num_inference_steps != t - prev_t:
-            warnings.warn(f"({scheduler.config.num_train_timesteps} // {scheduler.num_inference_steps}) != ({t} - {prev_t}), so the step sizes may not be accurate")
-    elif scheduler.config.num_train_timesteps // scheduler.num_inference_steps > t - prev_t:
-        warnings.warn(f"({scheduler.config.num_train_timesteps} // {scheduler.num_inference_steps}) > ({t} - {prev_t}), so the step sizes may not be accurate")
+    """schedule.py:10-19: sets `scheduler.num_inference_steps` so that DDIM's own `prev_t = t - N // n` lands
+    on the next timestep of an irregular schedule (N = num_train_timesteps); warns when it cannot."""
+    ts = scheduler.timesteps
+    last = index + 1 >= len(ts)
+    gap = int(t) - (-1 if last else int(ts[index + 1]))
+    n_train = scheduler.config.num_train_timesteps
+    scheduler.num_inference_steps = n_train // gap
+    step = n_train // scheduler.num_inference_steps
+    if (step > gap) if last else (step != gap):
+        warnings.warn(f"DDIM step {step} ({n_train} // {scheduler.num_inference_steps}) does not match the "
+                      f"schedule gap {gap} at index {index}; step sizes may not be accurate")

@@ -8,122 +8,151 @@ import numpy as np
 import torch
 
 
+# -------------------------------------------------------------------------------------------------
+# box / mask geometry.  The RULES are the reference's (utils/utils.py, cited per function) because box
+# rounding decides which latent pixels are guided, blended and frozen; the code is this repo's own and is
+# pinned against known-answer vectors made by the reference functions (tests/test_hostgeom.py).
+# -------------------------------------------------------------------------------------------------
 def get_centered_box(box, horizontal_center_only=True, vertical_placement='centered', vertical_center=0.5,
                      floor_padding=None):
-    """utils/utils.py:20-44."""
-    x_min, y_min, x_max, y_max = box
-    w = x_max - x_min
-    x_min_new, x_max_new = 0.5 - w / 2, 0.5 + w / 2
+    """Rule of utils/utils.py:20-44: same size, horizontally centred; vertically untouched, centred on
+    `vertical_center`, or standing `floor_padding` above the bottom edge."""
+    x0, y0, x1, y1 = box
+    half_w = (x1 - x0) / 2
+    out = [0.5 - half_w, y0, 0.5 + half_w, y1]
     if horizontal_center_only:
-        return [x_min_new, y_min, x_max_new, y_max]
-    h = y_max - y_min
+        return out
+    h = y1 - y0
     if vertical_placement == 'centered':
-        assert floor_padding is None, "Set vertical_placement to floor_padding to use floor padding"
-        y_min_new, y_max_new = vertical_center - h / 2, vertical_center + h / 2
+        if floor_padding is not None:
+            raise AssertionError("Set vertical_placement to floor_padding to use floor padding")
+        out[1], out[3] = vertical_center - h / 2, vertical_center + h / 2
     elif vertical_placement == 'floor_padding':
-        y_max_new = 1 - floor_padding
-        y_min_new = y_max_new - h
+        bottom = 1 - floor_padding
+        out[1], out[3] = bottom - h, bottom
     else:
         raise ValueError(f"Unknown vertical placement: {vertical_placement}")
-    return [x_min_new, y_min_new, x_max_new, y_max_new]
+    return out
+
+
+def _snap_axis(lo, hi, n):
+    """One axis of a [0,1] box on an n-pixel grid: start and EXTENT are rounded independently (a box keeps
+    its pixel size wherever it sits; Python round = half-to-even), then clipped to the grid."""
+    start = round(lo * n)
+    end = start + round((hi - lo) * n)
+    return max(start, 0), min(end, n)
 
 
 def scale_proportion(obj_box, H, W, use_legacy=False):
-    """utils/utils.py:57-70."""
+    """[0,1] xyxy box -> integer pixel rectangle (x_min, y_min, x_max, y_max), rule of utils/utils.py:57-70
+    (`use_legacy`: plain truncation of the four corners)."""
+    bx0, by0, bx1, by1 = obj_box
     if use_legacy:
-        x_min, y_min, x_max, y_max = int(obj_box[0] * W), int(obj_box[1] * H), int(obj_box[2] * W), int(obj_box[3] * H)
-    else:
-        x_min, y_min = round(obj_box[0] * W), round(obj_box[1] * H)
-        box_w, box_h = round((obj_box[2] - obj_box[0]) * W), round((obj_box[3] - obj_box[1]) * H)
-        x_max, y_max = x_min + box_w, y_min + box_h
-        x_min, y_min = max(x_min, 0), max(y_min, 0)
-        x_max, y_max = min(x_max, W), min(y_max, H)
-    return x_min, y_min, x_max, y_max
+        return int(bx0 * W), int(by0 * H), int(bx1 * W), int(by1 * H)
+    (x0, x1), (y0, y1) = _snap_axis(bx0, bx1, W), _snap_axis(by0, by1, H)
+    return x0, y0, x1, y1
+
+
+def _filled(H, W, x0, y0, x1, y1, as_numpy=False):
+    m = np.zeros((H, W)) if as_numpy else torch.zeros(H, W)
+    m[y0:y1, x0:x1] = 1.
+    return m
 
 
 def proportion_to_mask(obj_box, H, W, use_legacy=False, return_np=False):
-    """utils/utils.py:46-55."""
-    x_min, y_min, x_max, y_max = scale_proportion(obj_box, H, W, use_legacy)
-    mask = np.zeros((H, W)) if return_np else torch.zeros(H, W)
-    mask[y_min: y_max, x_min: x_max] = 1.
-    return mask
+    """Box mask on the H x W latent grid (utils/utils.py:46-55)."""
+    return _filled(H, W, *scale_proportion(obj_box, H, W, use_legacy), as_numpy=return_np)
+
+
+def _as_bool_array(mask):
+    return (mask.detach().cpu().numpy() if isinstance(mask, torch.Tensor) else np.asarray(mask)).astype(bool)
+
+
+def _span(flags):
+    hit = np.flatnonzero(flags)
+    if hit.size == 0:
+        raise ValueError('The mask is empty')
+    return int(hit[0]), int(hit[-1])
 
 
 def binary_mask_to_box(mask, enlarge_box_by_one=True, w_scale=1, h_scale=1):
-    """utils/utils.py:72-88."""
-    mask_loc = torch.where(mask) if isinstance(mask, torch.Tensor) else np.where(mask)
-    height, width = mask.shape
-    if len(mask_loc) == 0:
-        raise ValueError('The mask is empty')
+    """Bounding box [xmin, ymin, xmax, ymax] of the set pixels, optionally grown by one pixel per side and
+    clipped to the mask size (utils/utils.py:72-88; the max side is clipped to `size`, not `size - 1`)."""
+    m = _as_bool_array(mask)
+    H, W = m.shape
+    (y_lo, y_hi), (x_lo, x_hi) = _span(m.any(axis=1)), _span(m.any(axis=0))
     if enlarge_box_by_one:
-        ymin, ymax = max(min(mask_loc[0]) - 1, 0), min(max(mask_loc[0]) + 1, height)
-        xmin, xmax = max(min(mask_loc[1]) - 1, 0), min(max(mask_loc[1]) + 1, width)
-    else:
-        ymin, ymax = min(mask_loc[0]), max(mask_loc[0])
-        xmin, xmax = min(mask_loc[1]), max(mask_loc[1])
-    return [xmin * w_scale, ymin * h_scale, xmax * w_scale, ymax * h_scale]
+        y_lo, y_hi, x_lo, x_hi = max(y_lo - 1, 0), min(y_hi + 1, H), max(x_lo - 1, 0), min(x_hi + 1, W)
+    return [x_lo * w_scale, y_lo * h_scale, x_hi * w_scale, y_hi * h_scale]
 
 
 def binary_mask_to_box_mask(mask):
-    """utils/utils.py:90-100."""
-    x_min, y_min, x_max, y_max = binary_mask_to_box(mask)
-    H, W = mask.shape
-    mask = torch.zeros(H, W)
-    mask[y_min: y_max + 1, x_min: x_max + 1] = 1.
-    return mask
+    """Mask of the (grown, inclusive) bounding box of a mask (utils/utils.py:90-100)."""
+    x0, y0, x1, y1 = binary_mask_to_box(mask)
+    return _filled(mask.shape[0], mask.shape[1], x0, y0, x1 + 1, y1 + 1)
 
 
 def binary_mask_to_center(mask, normalize=False):
-    """utils/utils.py:102-123: mass centre of a mask."""
-    h, w = mask.shape
-    total = mask.sum()
-    if isinstance(mask, torch.Tensor):
-        cs, rs = mask.sum(dim=0), mask.sum(dim=1)          # bool masks (the reference's case) sum to int64
-        x_coord = ((cs @ torch.arange(w, dtype=cs.dtype)) / total).item()
-        y_coord = ((rs @ torch.arange(h, dtype=rs.dtype)) / total).item()
+    """Mass centre (x, y) of a mask in pixels, or as fractions of the width / height (utils/utils.py:102-123).
+    The value feeds `round()` in the alignment shift, so the reference's number format is kept: for torch
+    masks (bool / integer) the quotient of the two integer sums is a float32 division, for numpy masks a
+    float64 one."""
+    is_torch = isinstance(mask, torch.Tensor)
+    if is_torch and mask.is_floating_point():
+        m = mask.detach().cpu()
+        h, w = m.shape
+        total = m.sum()
+        x = float((m.sum(dim=0) @ torch.arange(w, dtype=m.dtype)) / total)
+        y = float((m.sum(dim=1) @ torch.arange(h, dtype=m.dtype)) / total)
     else:
-        x_coord = (mask.sum(axis=0) @ np.arange(w)) / total
-        y_coord = (mask.sum(axis=1) @ np.arange(h)) / total
+        m = mask.detach().cpu().numpy() if is_torch else np.asarray(mask)
+        h, w = m.shape
+        cols, rows, total = m.sum(axis=0), m.sum(axis=1), m.sum()
+        num_x, num_y = cols @ np.arange(w), rows @ np.arange(h)
+        if is_torch:
+            x = float(np.float32(num_x) / np.float32(total))
+            y = float(np.float32(num_y) / np.float32(total))
+        else:
+            x, y = num_x / total, num_y / total
     if normalize:
-        x_coord, y_coord = x_coord / w, y_coord / h
-    return x_coord, y_coord
+        x, y = x / w, y / h
+    return x, y
 
 
 def iou(mask, masks, eps=1e-6):
-    mask = mask[None].astype(bool)
-    masks = masks.astype(bool)
-    i = (mask & masks).sum(axis=(1, 2))
-    u = (mask | masks).sum(axis=(1, 2))
-    return i / (u + eps)
+    """IoU of one [h, w] mask against a stack [n, h, w] (utils/utils.py:125-131)."""
+    a = np.asarray(mask).astype(bool)[None]
+    b = np.asarray(masks).astype(bool)
+    inter = np.logical_and(a, b).reshape(b.shape[0], -1).sum(axis=1)
+    union = np.logical_or(a, b).reshape(b.shape[0], -1).sum(axis=1)
+    return inter / (union + eps)
 
 
 def expand_overall_bboxes(overall_bboxes):
     """[[box 1 for phrase 1, box 2 for phrase 1], ...] -> [box 1, box 2, ...] (utils/utils.py:136-143)."""
-    return sum(overall_bboxes, start=[])
+    return [box for group in overall_bboxes for box in group]
 
 
 def shift_tensor(tensor, x_offset, y_offset, base_w=8, base_h=8, offset_normalized=False, ignore_last_dim=False):
-    """utils/utils.py:145-180: integer shift with zero fill; normalised offsets are quantised on the
-    8x8 base grid so latents and all cross-attention levels move consistently."""
-    if ignore_last_dim:
-        tensor_h, tensor_w = tensor.shape[-3:-1]
-    else:
-        tensor_h, tensor_w = tensor.shape[-2:]
+    """Translate the 2-D image held in the last two dims (or, with `ignore_last_dim`, in dims -3/-2 of an
+    attention map [..., h, w, tokens]) by an integer pixel offset with zero fill (utils/utils.py:145-180).
+    Normalised offsets are quantised on the base_w x base_h grid first, so that 64x64 latents and the 8x8 /
+    16x16 attention maps of one object move by the same fraction of the image."""
+    ydim, xdim = (-3, -2) if ignore_last_dim else (-2, -1)
+    H, W = tensor.shape[ydim], tensor.shape[xdim]
     if offset_normalized:
-        assert tensor_h % base_h == 0 and tensor_w % base_w == 0, f"{tensor_h, tensor_w} is not a multiple of {base_h, base_w}"
-        sh, sw = tensor_h // base_h, tensor_w // base_w
-        x_offset, y_offset = round(x_offset * base_w) * sw, round(y_offset * base_h) * sh
-    new_tensor = torch.zeros_like(tensor)
-    overlap_w, overlap_h = tensor_w - abs(x_offset), tensor_h - abs(y_offset)
-    y_src, y_dst = (0, y_offset) if y_offset >= 0 else (-y_offset, 0)
-    x_src, x_dst = (0, x_offset) if x_offset >= 0 else (-x_offset, 0)
-    if ignore_last_dim:
-        new_tensor[..., y_dst:y_dst + overlap_h, x_dst:x_dst + overlap_w, :] = \
-            tensor[..., y_src:y_src + overlap_h, x_src:x_src + overlap_w, :]
-    else:
-        new_tensor[..., y_dst:y_dst + overlap_h, x_dst:x_dst + overlap_w] = \
-            tensor[..., y_src:y_src + overlap_h, x_src:x_src + overlap_w]
-    return new_tensor
+        if H % base_h or W % base_w:
+            raise AssertionError(f"{H, W} is not a multiple of {base_h, base_w}")
+        x_offset, y_offset = round(x_offset * base_w) * (W // base_w), round(y_offset * base_h) * (H // base_h)
+    out = torch.zeros_like(tensor)
+    src, dst = tensor, out
+    for dim, off, size in ((ydim, int(y_offset), H), (xdim, int(x_offset), W)):
+        keep = size - abs(off)
+        if keep <= 0:
+            return out                                                        # shifted out of the frame
+        src, dst = src.narrow(dim, max(-off, 0), keep), dst.narrow(dim, max(off, 0), keep)
+    dst.copy_(src)
+    return out
 
 
 # -------------------------------------------------------------------------------------------------
