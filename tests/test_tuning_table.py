@@ -1,0 +1,45 @@
+"""Host logic of the GEMM launch configuration: the measured table only holds tile codes the library
+accepts, split-K factors keep whole K tiles, and the fallback heuristic always returns a legal code."""
+import json
+import os
+import re
+
+import lgd_amd  # noqa: F401
+from lgd_amd import ops
+
+TABLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llm-groundeddiffusion_amd",
+                     "tuning_gfx950.json")
+LEGAL = set(range(1, 11)) | {16 + t for t in range(1, 11)} - {8, 24}
+TILE_BN = {1: 128, 2: 64, 3: 128, 4: 64, 5: 128, 6: 160, 7: 160, 9: 320, 10: 128}
+
+
+def test_table_entries_are_legal():
+    table = json.load(open(TABLE))
+    assert len(table) >= 200
+    for key, e in table.items():
+        m = re.match(r"M(\d+)_N(\d+)_K(\d+)_t(\d)_c(\d+)\+(\d+)_h(\d+)x(\d+)_s(\d)_u(\d)_e(\d)_b(\d+)$", key)
+        assert m, key
+        M, N, K, taps, c0, c1 = (int(m.group(i)) for i in range(1, 7))
+        geglu = int(m.group(11))
+        assert e["tile"] in LEGAL, (key, e)
+        assert K == taps * (c0 + c1)
+        assert 1 <= e["splits"] <= 16 and (e["splits"] == 1 or K // 64 >= e["splits"])
+        if geglu:
+            assert (e["tile"] & 15) not in (6, 7, 9), (key, e)            # 160/320-wide tiles cannot pair value|gate rows
+        assert e["us"] > 0 and e["tflops"] > 0
+
+
+def test_heuristic_returns_legal_codes():
+    for M in (1, 30, 64, 256, 1024, 4100, 16384, 65536):
+        for N in (64, 320, 640, 960, 1280, 2560, 5120, 10240):
+            for geglu in (False, True):
+                if geglu and N % 32:
+                    continue
+                for batches in (1, 8):
+                    t = ops.choose_tile(M, N, batches, geglu, 640)
+                    assert t in LEGAL and t > 16
+                    if geglu:
+                        assert (t & 15) not in (6, 7, 9)
+                    if (t & 15) in (6, 7):
+                        assert N % 160 == 0
+    assert ops.choose_splits(64, 1280, 11520) > 1 and ops.choose_splits(65536, 320, 2880) == 1
