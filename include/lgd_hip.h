@@ -73,7 +73,8 @@ typedef struct LgdGemmDesc {
   int32_t splits;     /* split-K factor (>=1); >1 needs ws                                  */
   float* ws;          /* fp32 [batch][splits][M][N]                                         */
   int32_t tile;       /* 0 auto; 1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64, 5: 32x128, 6: 128x160, 7: 64x160
-                         (register-staged main loop); +16 = same tile, LDS-DMA main loop (K % 64 == 0) */
+                         (register-staged main loop); +16 = same tile, LDS-DMA main loop (K % 64 == 0);
+                         25: 256x320, 26: 256x128 (8 waves, LDS-DMA only) */
 } LgdGemmDesc;
 
 int lgd_gemm_f16(const LgdGemmDesc* desc /* host */, void* stream);

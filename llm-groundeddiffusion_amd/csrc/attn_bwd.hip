@@ -11,8 +11,9 @@
 //
 // Cross-attention (77 text tokens): only dQ is needed (text K/V are constants), but the
 // probability map is itself an output that receives a gradient from the energy, so the kernel
-// takes gP in addition to gO:  dP_total = gP + gO V^T.  One wave per query row, VALU only — the
-// contraction sizes (77 x d) are tiny and the pass is latency-bound.
+// takes gP in addition to gO:  dP_total = gP + gO V^T.  cross_attn_bwd_mfma_kernel does this on the
+// matrix cores with all (<= 96) keys of a query in registers; the older VALU kernel (one wave per query
+// row) remains as the fallback for 96 < Sk <= 128.
 #include "common.h"
 #include "../../include/lgd_hip.h"
 
@@ -407,9 +408,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Cross-attention dQ.  grid = (ceil(Sq/4), H, B): one wave per query row; K and V of the head
-// (Sk <= 128 rows) are staged in LDS as fp32? no — fp16 [Sk][d+2] (odd dword stride: lanes walk
-// rows conflict-free).
+// Cross-attention dQ, VALU fallback (96 < Sk <= 128; the 77-token case runs cross_attn_bwd_mfma_kernel).
+// grid = (ceil(Sq/64), H, B): a wave walks 16 query rows; K and V of the head are staged in LDS as fp16
+// [Sk][d+2] (odd dword stride: lanes walk rows conflict-free).
 // ---------------------------------------------------------------------------------------------
 struct CrossBwdArgs {
   const half_t* q; long ldq, q_bs;

@@ -6,12 +6,16 @@
 // reference call sites): nn.Linear, 1x1 conv, 3x3 conv (stride 1/2, nearest-2x upsample folded into
 // the gather, channel-concat of two sources folded into the K loop) and their dgrad forms.
 //
+// Two main loops share one epilogue:
+//   gemm_dma_kernel  (the one every UNet contraction runs on, K % 64 == 0): operands go global -> LDS by
+//                    LDS-DMA, see its header further down;
+//   gemm_kernel      (fallback for any K): register-staged, described here.
 // Structure (per workgroup, 256 threads = 4 waves in a 2x2 grid):
 //   * tile BM x BN x 64; each wave owns (BM/2)x(BN/2) as MI x NI MFMA 16x16x32 tiles;
-//   * operands are register-staged: global -> VGPR (issued before the MFMAs of the current
-//     K-tile) -> LDS after the barrier, so the HBM/L2 latency hides under the MFMA phase;
-//   * LDS rows are padded to 80 halfs (160 B): with that stride each of the 4 hardware lane groups of
-//     a ds_read_b128 fragment read touches 16 distinct 16-B slots (72 halfs is 2-way conflicted);
+//   * gemm_kernel: operands are register-staged: global -> VGPR (issued before the MFMAs of the current
+//     K-tile) -> LDS after the barrier, so the HBM/L2 latency hides under the MFMA phase; LDS rows are
+//     padded to 80 halfs (160 B): with that stride each of the 4 hardware lane groups of a ds_read_b128
+//     fragment read touches 16 distinct 16-B slots (72 halfs is 2-way conflicted);
 //   * the MFMA is issued "swapped" (A := weight rows, B := activation rows), which makes each lane
 //     own 4 consecutive output channels of one pixel -> one 8-byte store, and 4-wide bias /
 //     residual loads in the epilogue;
@@ -654,7 +658,7 @@ extern "C" int lgd_gemm_f16(const LgdGemmDesc* desc, void* stream) {
     else if (wgs(64, 128) >= 256 && d.N % 128 == 0) tile = 19;
     else tile = 20;
   }
-  // tile codes 1..7 = register-staged main loop, 17..23 (16 + code) = LDS-DMA main loop
+  // tile codes 1..7 = register-staged main loop; 16 + code = LDS-DMA main loop (17..23, and the 8-wave 25/26)
   bool dma = tile > 16;
   if (dma) tile -= 16;
   if (dma && (d.K % BK)) dma = false;
