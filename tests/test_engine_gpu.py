@@ -325,3 +325,24 @@ def test_fast_schedule_loop_vs_reference_golden(dev):
     em = rel_l2(out["saved"][("up", 1, 1, 0)][n_run - 1], g["saved_up11_last"])
     print(f"fast schedule: history relerr {e_hist:.3e}, final latents {e_fin:.3e}, last map rel-L2 {em:.3e}")
     assert e_hist < 3e-2 and e_fin < 5e-2 and em < 1e-1
+
+
+def test_layout_without_boxes(dev):
+    """25 % of the cached lmd layouts have no boxes: no per-box stage, no guidance, the
+    overall generation starts from the background noise and still runs GLIGEN with an empty (all-masked)
+    grounding list.  Batched together with a 2-box layout it must not disturb it."""
+    from lgd_amd.pipeline import CachedLayout, lmd_plus_generate, lmd_plus_generate_batch
+    cfg = weights.CONFIGS["tiny_gligen"]
+    sm = LMDSampler(engine("tiny_gligen", dev), DDIMScheduler())
+    empty = CachedLayout.synthetic(cfg, [], 11)
+    full = CachedLayout.synthetic(cfg, [("a white deer", [74, 177, 183, 235]), ("a gray bear", [314, 193, 189, 216])], 3)
+    kw = dict(num_inference_steps=4, height=8 * L, width=8 * L, decode=False, overall_loss_threshold=0.0,
+              overall_max_index_step=2, overall_max_iter=[1])
+    out = lmd_plus_generate(sm, empty, **kw)
+    assert torch.isfinite(out["latents"]).all() and out["guidance_iters"] == 0 and out["so_images"] == []
+    assert int(out["fg_idx"].abs().sum()) == 0
+    both = lmd_plus_generate_batch(sm, [full, empty], **kw)
+    alone = lmd_plus_generate(sm, full, **kw)
+    assert both[1]["guidance_iters"] == 0 and both[0]["guidance_iters"] == alone["guidance_iters"] == 2
+    assert relerr(both[0]["latents"], alone["latents"]) < 3e-2
+    assert relerr(both[1]["latents"], out["latents"]) < 3e-2
