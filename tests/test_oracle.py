@@ -62,6 +62,21 @@ def test_unet_forward_and_maps(model):
         assert maxrel(saved[k], g["map_" + ks(k)]) < TOL
 
 
+def test_unet_forward_sd2x_topology():
+    """The restatement also covers the SD2.x-style topology (linear proj_in/out, per-level head counts, 64-wide
+    heads): pinned against the reference's own UNet (oracle/make_golden_sd21.py)."""
+    cfg = weights.CONFIGS["tiny_sd21"]
+    g = np.load(os.path.join(GOLD, "unet_fwd_tiny_sd21.npz"))
+    saved = {}
+    with torch.no_grad():
+        eps = R.unet_forward(weights.synth_state_dict(cfg, 0), cfg_dict(cfg), torch.from_numpy(g["x"]), int(g["t"]),
+                             torch.from_numpy(g["ehs"]), saved=saved, save_keys=[OBJ_KEY, *KEYS])
+    assert maxrel(eps, g["eps"]) < TOL
+    for k in [OBJ_KEY, *KEYS]:
+        assert saved[k].shape[1] == cfg.attention_head_dim[2 if k[0] != "mid" else 3]
+        assert maxrel(saved[k], g["map_" + ks(k)]) < TOL
+
+
 def test_backward_guidance(model):
     name, cd, sd = model
     g = np.load(os.path.join(GOLD, f"guidance_{name}.npz"))
