@@ -231,6 +231,20 @@ class DDIM:
         ratio = self.T // n
         self.timesteps = torch.from_numpy((np.arange(0, n) * ratio).round()[::-1].copy().astype(np.int64)) + self.steps_offset
 
+    # ---- utils/schedule.py ------------------------------------------------------------------
+    def use_fast_schedule(self, fast_after_steps, fast_rate=2):
+        """schedule.py:4-8 as applied at pipelines.py:151-152,358-359: keep the first `fast_after_steps`
+        timesteps, then every `fast_rate`-th one."""
+        ts = self.timesteps
+        if fast_after_steps < len(ts) - 1:
+            self.timesteps = torch.cat((ts[:fast_after_steps], ts[fast_after_steps + 1::fast_rate]), dim=0)
+
+    def adjust_inference_steps(self, index, t):
+        """schedule.py:10-12 (`dynamically_adjust_inference_steps`, pipelines.py:217-218,439-440): make the
+        next `step()` land on the following timestep of an irregular schedule."""
+        nxt = int(self.timesteps[index + 1]) if index + 1 < len(self.timesteps) else -1
+        self.num_inference_steps = self.T // (int(t) - nxt)
+
     def step(self, eps, t, x):
         t = int(t)
         prev_t = t - self.T // self.num_inference_steps
@@ -450,7 +464,7 @@ def generate_gligen(sd, cfg, sched, latents, input_embeddings, steps, bboxes, ph
                     saved_cross_attn_keys=None, return_saved_cross_attn=False, return_cond_ca_only=False,
                     return_token_ca_only=None, semantic_guidance=False, semantic_guidance_bboxes=None,
                     semantic_guidance_object_positions=None, semantic_guidance_kwargs=None, trace=None,
-                    per_step=None):
+                    per_step=None, dynamic_num_inference_steps=False, fast_after_steps=None, fast_rate=2):
     """pipelines.py:323-473.  bboxes: list of boxes of ONE image; phrase_embeddings (n,768)."""
     text_emb, _, cond_emb = input_embeddings
     latents_all_input = None
@@ -459,6 +473,8 @@ def generate_gligen(sd, cfg, sched, latents, input_embeddings, steps, bboxes, ph
     latents = latents.clone()
     latents_all = [latents]
     sched.set_timesteps(steps)
+    if fast_after_steps is not None:                                  # :358-359
+        sched.use_fast_schedule(fast_after_steps, fast_rate)
     if frozen_mask is not None:
         frozen_mask = frozen_mask.to(torch.float32).clamp(0., 1.)
     boxes, emb, masks, cond_len = prepare_gligen_condition([bboxes], [phrase_embeddings],
@@ -478,13 +494,16 @@ def generate_gligen(sd, cfg, sched, latents, input_embeddings, steps, bboxes, ph
                                                      gligen=g_gligen, fuser_enabled=fuser_on, trace=trace,
                                                      **semantic_guidance_kwargs)
         saved = {} if return_saved_cross_attn else None
+        if dynamic_num_inference_steps:                               # :439-440
+            sched.adjust_inference_steps(index, t)
         latents = _cfg_step(sd, cfg, sched, latents, t, text_emb, guidance_scale, saved=saved,
                             save_keys=saved_cross_attn_keys, cond_only=return_cond_ca_only,
                             token_only=return_token_ca_only, gligen=m_gligen, fuser_enabled=fuser_on)
         if frozen_mask is not None and index < frozen_steps:
             latents = latents_all_input[index + 1] * frozen_mask + latents * (1. - frozen_mask)
         saved_attns.append(saved)
-        latents_all.append(latents)
+        if fast_after_steps is None or index < fast_after_steps:      # :449 "do not save the latents in the fast steps"
+            latents_all.append(latents)
         if per_step is not None:
             per_step.append(latents.clone())
     return latents, saved_attns, torch.stack(latents_all, dim=0)

@@ -149,6 +149,24 @@ def test_sampler_loop_gligen():
     assert maxrel(saved[1][("up", 1, 1, 0)], g["gligen_saved_up11_step1"]) < TOL
 
 
+def test_fast_schedule_loop_gligen():
+    """generate_gligen with the optional fast tail (dynamic_num_inference_steps + fast_after_steps=4) vs the
+    reference's own run (oracle/make_golden_fast.py)."""
+    cfg = weights.CONFIGS["tiny_gligen"]
+    g = np.load(os.path.join(GOLD, "fast_tiny_gligen.npz"))
+    ehs = torch.from_numpy(g["ehs"])
+    sched = R.DDIM()
+    lat, saved, lat_all = R.generate_gligen(
+        weights.synth_state_dict(cfg, 0), cfg_dict(cfg), sched, torch.from_numpy(g["lat0"]), (ehs, ehs[:1], ehs[1:]),
+        int(g["T"]), BBOXES, torch.from_numpy(g["phrase_emb"]), gligen_scheduled_sampling_beta=0.5, frozen_steps=0,
+        return_saved_cross_attn=True, saved_cross_attn_keys=[OBJ_KEY, *KEYS], return_cond_ca_only=True,
+        return_token_ca_only=7, dynamic_num_inference_steps=True, fast_after_steps=int(g["fast_after"]), fast_rate=2)
+    assert [int(t) for t in sched.timesteps] == [int(t) for t in g["timesteps"]]
+    assert len(saved) == int(g["n_saved"]) and lat_all.shape[0] == int(g["fast_after"]) + 1
+    assert maxrel(lat_all, g["latents_all"]) < TOL and maxrel(lat, g["latents"]) < TOL
+    assert maxrel(saved[-1][("up", 1, 1, 0)], g["saved_up11_last"]) < TOL
+
+
 def test_host_latent_prep():
     g = np.load(os.path.join(GOLD, "latents_host.npz"))
     lst, bg = R.get_input_latents_list(3, 3 + 123456789, BBOXES, 0.1)
