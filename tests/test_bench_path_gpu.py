@@ -1,0 +1,304 @@
+"""Parity of the code path the BENCHMARK runs (BASELINE config[1]: sd14_gligen at 64x64 latents):
+
+  * every (tile, gather, sources, epilogue, split-K) combination the measured GEMM table selects, on a real
+    table shape, vs fp32 torch;
+  * the self-attention instantiations the timed region launches (two query tiles per wave: B*H*ceil(Sq/128)
+    >= 1024 at d = 40 / 80, incl. the S+30 GLIGEN tail), forward and backward, vs fp32 torch;
+  * the full-width network: one CFG forward (B = 2, fuser on and off, 5 captured maps) and one guidance
+    iteration vs the CPU oracle (oracle/restate.py, computed on the GPU box's host cores), and the
+    stage-A / stage-B batch sizes (B = 16 / 8) against the B = 2 result.
+
+Tolerances as DESIGN.md (c): fp16 compute / fp32 accumulate vs fp32, relative to the tensor's max."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import lgd_amd  # noqa: E402,F401
+from lgd_amd import ops, weights  # noqa: E402
+from lgd_amd.sampler import LMDSampler, prepare_gligen_condition  # noqa: E402
+from lgd_amd.scheduler import DDIMScheduler  # noqa: E402
+from lgd_amd.unet import UNetEngine  # noqa: E402
+import gemm_table_cases as gtc  # noqa: E402
+
+H16, F32 = torch.float16, torch.float32
+KEYS = [("mid", 0, 0, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 1, 2, 0)]
+OBJ_KEY = ("down", 2, 1, 0)
+BOXES = [[0.15, 0.35, 0.5, 0.8], [0.6, 0.38, 0.98, 0.8]]
+OBJ_POS = [[1, 2, 3], [5, 6, 7]]
+
+
+def relerr(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-20))
+
+
+def rnd(*shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+def pack_conv_w(w):  # [Cout,Cin,3,3] -> [Cout, 9*Cin] (ky,kx,ci)
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+def geglu_perm(n, dev):  # natural [value | gate] rows -> 16-row (value, gate) blocks
+    idx = []
+    for j in range(n // 16):
+        idx += list(range(16 * j, 16 * j + 16)) + list(range(n + 16 * j, n + 16 * j + 16))
+    return torch.tensor(idx, device=dev)
+
+
+# -------------------------------------------------------------------------------------------------
+# 1. every launch mode of the tuning table
+# -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("s", gtc.cases(), ids=lambda s: f"tile{s.tile}_sp{s.splits}_{s.key}")
+def test_tuned_gemm_mode_on_its_table_shape(dev, s):
+    M, N, K = s.M, s.N, s.K
+    cin = s.c0 + s.c1
+    b = rnd(N, dev=dev, seed=3)
+    if s.taps == 1:
+        x = rnd(M, cin, dev=dev, seed=1).half()
+        w = rnd(N, K, dev=dev, seed=2, scale=K ** -0.5).half()
+        x0 = x[:, :s.c0].contiguous()
+        x1 = x[:, s.c0:].contiguous() if s.c1 else None
+        ref = x.float() @ w.float().t() + b
+        kw = dict(taps=1)
+    else:
+        hw_out = s.hout * s.hout
+        B = M // hw_out
+        assert B * hw_out == M
+        x = rnd(B, cin, s.hin, s.hin, dev=dev, seed=1).half()
+        w4 = rnd(N, cin, 3, 3, dev=dev, seed=2, scale=K ** -0.5).half()
+        w = pack_conv_w(w4)
+        xin = x.float()
+        if s.ups == 1:
+            xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+        elif s.ups == 2:
+            z = torch.zeros(B, cin, 2 * s.hin, 2 * s.hin, device=dev)
+            z[:, :, ::2, ::2] = xin
+            xin = z
+        ref = F.conv2d(xin, w4.float(), b, stride=s.stride, padding=1)
+        assert ref.shape[-1] == s.hout
+        ref = ref.permute(0, 2, 3, 1).reshape(M, N)
+        xl = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous()
+        x0 = xl[:, :s.c0].contiguous()
+        x1 = xl[:, s.c0:].contiguous() if s.c1 else None
+        kw = dict(taps=9, hin=s.hin, win=s.hin, hout=s.hout, wout=s.hout, stride=s.stride, ups=s.ups)
+    if s.geglu:
+        n = N // 2
+        perm = geglu_perm(n, dev)
+        v, g = ref.chunk(2, dim=-1)
+        ref = v * F.gelu(g)
+        out = torch.empty(M, n, device=dev, dtype=H16)
+        d = ops.gemm_desc(x0, w[perm].contiguous(), out, M, N, K, a1=x1, c0=s.c0, c1=s.c1, lda0=s.c0, lda1=s.c1,
+                          bias=b[perm].contiguous(), epi=ops.EPI_GEGLU, ldc=n, tile=s.tile, splits=s.splits, **kw)
+    else:
+        res = rnd(M, N, dev=dev, seed=4).half()
+        ref = ref * 0.5 + res.float()
+        out = torch.empty(M, N, device=dev, dtype=H16)
+        d = ops.gemm_desc(x0, w, out, M, N, K, a1=x1, c0=s.c0, c1=s.c1, lda0=s.c0, lda1=s.c1, bias=b, res=res,
+                          ldr=N, alpha=0.5, ldc=N, tile=s.tile, splits=s.splits, **kw)
+    assert d.tile == s.tile and d.splits == s.splits
+    ops.gemm_launch(d)
+    torch.cuda.synchronize()
+    assert relerr(out, ref) < 3e-3
+    # what the engine would pick for this shape (tile=0 / splits=None) is this very table entry
+    d2 = ops.gemm_desc(x0, w, out, M, N, K, a1=x1, c0=s.c0, c1=s.c1, lda0=s.c0, lda1=s.c1,
+                       epi=ops.EPI_GEGLU if s.geglu else 0, ldc=out.shape[1], **kw)
+    assert (d2.tile, d2.splits) == (s.tile, s.splits)
+
+
+# -------------------------------------------------------------------------------------------------
+# 2. the self-attention launches of the timed region
+# -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,Sq,Sk,d", [
+    (4, 8, 4096, 4096, 40),      # stage B main pass, 64x64 level (B >= 4 -> two query tiles per wave)
+    (4, 8, 4096, 4126, 40),      # + the 30 GLIGEN grounding tokens (attention.py:50)
+    (16, 8, 1024, 1024, 80),     # stage A main pass, 32x32 level
+    (16, 8, 1024, 1054, 80),
+    (16, 8, 256, 286, 160), (16, 8, 64, 94, 160),
+    (2, 5, 9216, 9216, 64),      # SD2.1-768 (BASELINE config 3), first level
+])
+def test_self_attention_at_benchmark_sizes(dev, B, H, Sq, Sk, d):
+    C = H * d
+    scale = d ** -0.5
+    q = rnd(B, Sq, C, dev=dev, seed=1).half()
+    k = rnd(B, Sk, C, dev=dev, seed=2).half()
+    v = rnd(B, Sk, C, dev=dev, seed=3).half()
+    o = torch.empty(B, Sq, C, device=dev, dtype=H16)
+    lse = torch.empty(B, H, Sq, device=dev)
+    ops.attn_fwd(q, k, v, o, B, H, Sq, Sk, d, scale, lse=lse)
+    sp = lambda t, S: t.float().reshape(B, S, H, d).permute(0, 2, 1, 3).clone().requires_grad_(True)
+    qr, kr, vr = sp(q, Sq), sp(k, Sk), sp(v, Sk)
+    go = rnd(B, Sq, C, dev=dev, seed=4).half()
+    # reference in slices of heads (the S x S scores of all heads at once do not need to be resident)
+    ref = torch.empty(B, H, Sq, d, device=dev)
+    for h in range(H):
+        s_ = torch.einsum("bqd,bkd->bqk", qr[:, h], kr[:, h]) * scale
+        p = s_.softmax(-1)
+        oh = torch.einsum("bqk,bkd->bqd", p, vr[:, h])
+        ref[:, h] = oh.detach()
+        oh.backward(go.float().reshape(B, Sq, H, d)[:, :, h])
+    assert relerr(o, ref.permute(0, 2, 1, 3).reshape(B, Sq, C)) < 4e-3
+    lse_ref = torch.stack([torch.logsumexp(torch.einsum("bqd,bkd->bqk", qr[:, h].detach(), kr[:, h].detach()) * scale,
+                                           dim=-1) for h in range(H)], dim=1) * 1.4426950408889634
+    assert float((lse - lse_ref).abs().max()) < 2e-2
+    gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty(B, H, Sq, device=dev)
+    ops.attn_bwd(q, k, v, o, go, lse, delta, gq, gk, gv, B, H, Sq, Sk, d, scale)
+    un = lambda t, S: t.permute(0, 2, 1, 3).reshape(B, S, C)
+    assert relerr(gq, un(qr.grad, Sq)) < 1e-2
+    assert relerr(gk, un(kr.grad, Sk)) < 1e-2
+    assert relerr(gv, un(vr.grad, Sk)) < 1e-2
+
+
+def test_self_attention_forced_rescale(dev):
+    """The running-max reference of the online softmax is raised lazily (only on a wave-uniform vote): spike
+    single (query, key) scores late in the key sequence so that the rescale branch is taken, in both the
+    one- and the two-query-tile instantiations."""
+    for B, H, S, d in [(1, 8, 1024, 40), (4, 8, 4096, 40), (16, 8, 1024, 80)]:
+        C = H * d
+        q = rnd(B, S, C, dev=dev, seed=1).half()
+        k = rnd(B, S, C, dev=dev, seed=2).half()
+        v = rnd(B, S, C, dev=dev, seed=3).half()
+        for qi, ki in [(5, S - 3), (S // 2 + 1, S // 2 + 70), (S - 1, 200)]:
+            k[:, ki] = q[:, qi] * 6.0           # raw q.k ~ 6 |q|^2 >> the row's other scores
+        o = torch.empty(B, S, C, device=dev, dtype=H16)
+        ops.attn_fwd(q, k, v, o, B, H, S, S, d, d ** -0.5)
+        sp = lambda t: t.float().reshape(B, S, H, d).permute(0, 2, 1, 3)
+        ref = torch.empty(B, H, S, d, device=dev)
+        for h in range(H):
+            p = (torch.einsum("bqd,bkd->bqk", sp(q)[:, h], sp(k)[:, h]) * d ** -0.5).softmax(-1)
+            ref[:, h] = torch.einsum("bqk,bkd->bqd", p, sp(v)[:, h])
+        assert relerr(o, ref.permute(0, 2, 1, 3).reshape(B, S, C)) < 4e-3, (B, S, d)
+
+
+# -------------------------------------------------------------------------------------------------
+# 3. the full-width network vs the CPU oracle
+# -------------------------------------------------------------------------------------------------
+_FULL = {}
+
+
+def full(dev):
+    if not _FULL:
+        cfg = weights.CONFIGS["sd14_gligen"]
+        sd = weights.synth_state_dict(cfg, 0)
+        _FULL.update(cfg=cfg, sd=sd, eng=UNetEngine(cfg, dev, sd),
+                     cd=dict(block_out_channels=cfg.block_out_channels, layers_per_block=cfg.layers_per_block,
+                             attention_head_dim=cfg.attention_head_dim, norm_num_groups=cfg.norm_num_groups,
+                             norm_eps=cfg.norm_eps, gligen_positive_len=cfg.gligen_positive_len))
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))    # the oracle's fp32 convs thrash when oversubscribed
+    return _FULL
+
+
+def _inputs(cfg, dev, L=64):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((2, 4, L, L), generator=g)
+    unc, cond = weights.synth_embeddings(cfg, 1, seed=1)
+    pe = torch.randn((2, cfg.gligen_positive_len), generator=g)
+    gl = prepare_gligen_condition(BOXES, pe, dev)
+    return x, torch.cat([unc, cond]), cond, gl
+
+
+@pytest.mark.parametrize("fuser", [True, False])
+def test_fullsize_cfg_forward_vs_oracle(dev, fuser):
+    """sd14_gligen (320/640/1280 channels, d = 40/80/160), L = 64, B = 2: noise prediction and the 5 captured
+    maps vs oracle/restate.py — the launch plan, tuning-table entries and attention instantiations are the
+    benchmark's own (reference: models/unet_2d_condition.py:704-980)."""
+    import restate as R
+    f = full(dev)
+    cfg, eng = f["cfg"], f["eng"]
+    x, ehs, _, gl = _inputs(cfg, dev)
+    keys = [OBJ_KEY, *KEYS]
+    plan = eng.plan(2, 64, fuser=fuser, save_keys=keys)
+    eng.prepare_timesteps([501])
+    eng.set_step(0)
+    eng.prepare_text(ehs)
+    eng.prepare_gligen(boxes=gl[0], positive_embeddings=gl[1], masks=gl[2])
+    eps = plan.forward(x.to(dev)).cpu()
+    saved = {}
+    with torch.no_grad():
+        ref = R.unet_forward(f["sd"], f["cd"], x, 501, ehs, saved=saved, save_keys=keys, fuser_enabled=fuser,
+                             gligen=dict(boxes=gl[0].cpu(), positive_embeddings=gl[1].cpu(), masks=gl[2].cpu()))
+    e = relerr(eps, ref)
+    print(f"[full, fuser={fuser}] eps relerr {e:.3e} rel-L2 {rel_l2(eps, ref):.3e}")
+    assert e < 2e-2
+    for k in keys:
+        em, el2 = relerr(plan.maps[k], saved[k]), rel_l2(plan.maps[k], saved[k])
+        print(f"[full, fuser={fuser}] map {k} relerr {em:.3e} rel-L2 {el2:.3e}")
+        assert em < 3e-2 and el2 < 1.5e-2
+    _FULL[("eps", fuser)] = eps
+    _FULL[("maps", fuser)] = {k: plan.maps[k].clone() for k in keys}
+
+
+@pytest.mark.parametrize("nb", [4, 8])
+def test_fullsize_batched_plans_match_b2(dev, nb):
+    """The stage-B (B = 2*4) and stage-A (B = 2*8) plans of the benchmark: every image of the batch is the
+    B = 2 problem again, so each must reproduce the B = 2 result up to the accumulation order of the
+    differently tiled GEMMs."""
+    f = full(dev)
+    cfg, eng = f["cfg"], f["eng"]
+    if ("eps", True) not in _FULL:
+        pytest.skip("needs test_fullsize_cfg_forward_vs_oracle[True] in the same session")
+    x, ehs, _, gl = _inputs(cfg, dev)
+    keys = [OBJ_KEY, *KEYS]
+    plan = eng.plan(2 * nb, 64, fuser=True, save_keys=keys)
+    eng.prepare_timesteps([501])
+    eng.set_step(0)
+    eng.prepare_text(torch.cat([ehs[0:1]] * nb + [ehs[1:2]] * nb))
+    eng.prepare_gligen(boxes=torch.cat([gl[0][0:1]] * nb + [gl[0][1:2]] * nb),
+                       positive_embeddings=torch.cat([gl[1][0:1]] * nb + [gl[1][1:2]] * nb),
+                       masks=torch.cat([gl[2][0:1]] * nb + [gl[2][1:2]] * nb))
+    xb = torch.cat([x[0:1]] * nb + [x[1:2]] * nb)
+    eps = plan.forward(xb.to(dev)).cpu()
+    ref = _FULL[("eps", True)]
+    for b in range(nb):
+        e = max(relerr(eps[b], ref[0]), relerr(eps[nb + b], ref[1]))
+        assert e < 1e-2, (b, e)
+    for k in keys:
+        m = plan.maps[k]
+        r = _FULL[("maps", True)][k]
+        e = max(max(relerr(m[b], r[0]), relerr(m[nb + b], r[1])) for b in range(nb))
+        print(f"[full B={2 * nb}] map {k} vs B=2: {e:.3e}")
+        assert e < 2e-2
+
+
+def test_fullsize_guidance_iteration_vs_oracle(dev):
+    """One latent_backward_guidance iteration (models/pipelines.py:16-82) at full width: loss and latent
+    gradient vs the oracle (fuser on, zero-masked grounding half as pipelines.py:381-384)."""
+    import restate as R
+    f = full(dev)
+    cfg, eng = f["cfg"], f["eng"]
+    x, _, cond, gl = _inputs(cfg, dev)
+    sm = LMDSampler(eng, DDIMScheduler())
+    guid = dict(bboxes=BOXES, object_positions=OBJ_POS, loss_scale=5, loss_threshold=0.0, max_iter=1,
+                max_index_step=30, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+    tr = []
+    sm.guidance_only(x[:1], cond, 50, 1, guid, gligen=gl, fuser=True, trace=tr)
+    rs = R.DDIM()
+    rs.set_timesteps(50)
+    tr_ref = []
+    R.latent_backward_guidance(f["sd"], f["cd"], rs, cond, 1, BOXES, OBJ_POS, rs.timesteps[1], x[:1].clone(),
+                               torch.tensor(1e4), loss_scale=5, loss_threshold=0.0, max_iter=1, max_index_step=30,
+                               guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0,
+                               gligen=dict(boxes=gl[0][:1].cpu(), positive_embeddings=gl[1][:1].cpu(),
+                                           masks=gl[2][:1].cpu()), trace=tr_ref)
+    a, b = tr[0]["grad"].cpu().double().reshape(-1), tr_ref[0]["grad"].double().reshape(-1)
+    cos = float(a @ b / (a.norm() * b.norm()))
+    l_hip, l_ref = tr[0]["loss"], tr_ref[0]["loss"]
+    print(f"[full] guidance loss hip {l_hip:.4f} oracle {l_ref:.4f}; latent-gradient cosine {cos:.5f} "
+          f"rel-L2 {rel_l2(a, b):.3e}")
+    assert abs(l_hip - l_ref) / abs(l_ref) < 2e-2 and cos > 0.98

@@ -43,3 +43,23 @@ def test_heuristic_returns_legal_codes():
                     if (t & 15) in (6, 7):
                         assert N % 160 == 0
     assert ops.choose_splits(64, 1280, 11520) > 1 and ops.choose_splits(65536, 320, 2880) == 1
+
+
+def test_every_table_mode_has_a_gpu_parity_case():
+    """tests/test_bench_path_gpu.py::test_tuned_gemm_mode_on_its_table_shape is parametrised over
+    gemm_table_cases.cases(); no table entry may select a (tile, gather, sources, epilogue, split-K)
+    combination outside that list, and every case must be a launchable table shape."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import gemm_table_cases as gtc
+    cases = gtc.cases()
+    covered = {gtc.mode(s) for s in cases}
+    for s in gtc.table().values():
+        assert gtc.mode(s) in covered, s.key
+    assert len(cases) == len(covered) >= 20
+    for s in cases:
+        assert s.K == s.taps * (s.c0 + s.c1) and s.K % 64 == 0 and s.tile in LEGAL
+        if s.taps == 9:
+            b = s.M // (s.hout * s.hout)
+            assert b >= 1 and b * s.hout * s.hout == s.M
+            assert s.hout == ((2 * s.hin if s.ups else s.hin) - 1) // s.stride + 1
