@@ -1,26 +1,34 @@
 #!/usr/bin/env python
 """bench.py — images/sec of the LMD+ stage-2 hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload batch4|lmd_v0.1]
 
-A "step" = one pass of the hot path over one batch of cached layouts on every rank: `--layouts`
-(default 4, BASELINE config[1] "batch=4 cached layouts") two-box layouts of the lmd_v0.1 cache, each
-taken through the full LMD+ stage 2 (per-box GLIGEN generations, composition, overall generation with
-cross-attention guidance, 50 DDIM steps each, VAE decodes; SAM replaced by box masks, text encoder
-outputs synthetic = "cached layouts").  Weights: seeded random SD1.4+GLIGEN architecture
-(no checkpoints in the sandbox).  Ranks shard layouts (weak scaling, one process per GPU); rank 0
-builds the weights and RCCL-broadcasts the two weight arenas; no collective inside the step loop.
+A "step" = one pass of the hot path over one batch of cached layouts on every rank.
 
-Prints ONE JSON line (rank 0) with the contract's fields plus `roofline` (dominant kernel, live HIP
-event timing of sampled launches inside the timed region) and, at N=1, `cpu_baseline`.
+  --workload batch4 (default; BASELINE config[1] "batch=4 cached layouts"): `--layouts` (4) two-box layouts
+      of the lmd_v0.1 cache per rank per step.
+  --workload lmd_v0.1 (BASELINE config[3]): `--prompts` (100) layouts taken evenly from the 400-entry
+      lmd_v0.1 cache (0..5 boxes each), partitioned over the ranks by cost (N+1 generations per layout,
+      longest-processing-time first; the reference's manual version is generate.py:23-25,243-250), global
+      prompt index preserved (seeds derive from it).  One step = every rank processes its whole share.
+
+Every layout goes through the full LMD+ stage 2 (per-box GLIGEN generations, composition, overall generation
+with cross-attention guidance, 50 DDIM steps each, VAE decodes; SAM replaced by box masks, text encoder outputs
+synthetic = "cached layouts").  Weights: seeded random SD1.4+GLIGEN architecture (no checkpoints in the
+sandbox).  One process per GPU: started by the driver under torch.distributed.run, or — when `--gpus N > 1`
+is given without a rendezvous in the environment — re-launched by this script itself the same way.  Rank 0
+builds the weights and RCCL-broadcasts the two weight arenas; there is no collective inside the step loop.
+
+Prints ONE JSON line (rank 0) with the contract's fields plus `roofline` (dominant kernel; per-launch HIP
+event timing) and, at N=1, `cpu_baseline`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -28,28 +36,46 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_F16 = 2.5e15       # dense fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
 
-
-def load_layouts(n_boxes=2):
-    rows = json.load(open(os.path.join(ROOT, "tests", "golden", "layouts_lmd_v0.1_gpt-4.json")))
-    return [r for r in rows if len(r["gen_boxes"]) == n_boxes]
-
-
-def algorithmic_tflop_per_image(cfg_name, n_boxes, iters_on, iters_off):
-    """SURVEY.md §8d per-unit figure (analytic, 2*MAC): LMD+ image = (N+1)(20*fwd_on + 30*fwd_off) +
-    guidance iterations (fwd to up.1.2 + dgrad back to the latents)."""
-    if cfg_name != "sd14_gligen":
-        return None
-    return (n_boxes + 1) * (20 * 2.2736 + 30 * 1.6065) + iters_on * (0.5872 + 0.6885) + iters_off * (0.4086 + 0.4585)
+# analytic 2*MAC TFLOP of one UNet call (sd14_gligen, 64x64 latents)
+TF_MAIN_ON, TF_MAIN_OFF = 2.2736, 1.6065            # CFG forward B=2, GLIGEN fuser on / off
+TF_GUIDE_ON, TF_GUIDE_OFF = 0.5872 + 0.6885, 0.4086 + 0.4585   # guidance fwd (to up.1.2) + dgrad to the latents
 
 
-def cpu_baseline(cfg, n_boxes, iters_on, iters_off):
+def load_cache():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "layouts_lmd_v0.1_gpt-4.json")))
+
+
+def algorithmic_tflop(n_boxes, n_steps, beta, iters_on, iters_off):
+    """LMD+ image = (N+1) generations x (grounded + plain CFG calls) + guidance iterations (fuser on / off)."""
+    n_on = int(beta * n_steps)
+    return (n_boxes + 1) * (n_on * TF_MAIN_ON + (n_steps - n_on) * TF_MAIN_OFF) + iters_on * TF_GUIDE_ON + iters_off * TF_GUIDE_OFF
+
+
+def partition_by_cost(costs, world):
+    """Longest-processing-time-first assignment of items (cost_i) to `world` ranks; deterministic.
+    Returns per-rank lists of item indices (ascending)."""
+    load = [0.0] * world
+    mine = [[] for _ in range(world)]
+    for i in sorted(range(len(costs)), key=lambda i: (-costs[i], i)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        load[r] += costs[i]
+        mine[r].append(i)
+    return [sorted(m) for m in mine]
+
+
+def select_prompts(rows, n):
+    """`n` cache entries spread evenly over the file (its four prompt categories are stored in blocks)."""
+    n = min(n, len(rows))
+    return [(i * len(rows)) // n for i in range(n)]
+
+
+def cpu_baseline(cfg, n_boxes, n_steps, beta, iters_on, iters_off):
     """The CPU oracle (oracle/restate.py: fp32 restatement of the reference path, pinned against the
-    reference's own code) timed on this box's host cores on a bounded sample (~10-30 s): one CFG UNet
-    call with the GLIGEN fuser on and one guidance iteration (fwd+bwd); the fuser-off call is priced
-    by its algorithmic-FLOP ratio to the fuser-on call (1.6065 / 2.2736), and the
-    whole is extrapolated to a full LMD+ image with the iteration counts the GPU run took.
-    Threads are capped at 32: the oracle's fp32 convolutions get slower, not faster, when oversubscribed
-    across a 256-thread host (measured 155 s vs 8 s per call)."""
+    reference's own code) timed on this box's host cores on a bounded sample (~20-30 s): one CFG UNet call with
+    the GLIGEN fuser on, one with it off, one guidance iteration (fwd+bwd); extrapolated to a full LMD+ image
+    with the call / iteration counts of the GPU run.  Threads are capped at 32: the oracle's fp32 convolutions
+    get slower, not faster, when oversubscribed across a 256-thread host (measured 155 s vs 8 s per call)."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import restate as R
     from lgd_amd import weights
@@ -59,33 +85,56 @@ def cpu_baseline(cfg, n_boxes, iters_on, iters_off):
     cd = dict(block_out_channels=cfg.block_out_channels, layers_per_block=cfg.layers_per_block,
               attention_head_dim=cfg.attention_head_dim, norm_num_groups=cfg.norm_num_groups,
               norm_eps=cfg.norm_eps, gligen_positive_len=cfg.gligen_positive_len)
-    L = 64
+    L = cfg.sample_size
     x = torch.randn(2, 4, L, L)
     unc, cond = weights.synth_embeddings(cfg, 1)
     ehs = torch.cat([unc, cond])
     boxes = [[0.15, 0.35, 0.5, 0.8], [0.6, 0.38, 0.98, 0.8]]
-    b, e, m, _ = R.prepare_gligen_condition([boxes], [torch.randn(2, 768)])
-    gl = dict(boxes=b, positive_embeddings=e, masks=m)
-    t0 = time.time()
+    gl = None
+    if cfg.use_gated_attention:
+        b, e, m, _ = R.prepare_gligen_condition([boxes], [torch.randn(2, cfg.gligen_positive_len)])
+        gl = dict(boxes=b, positive_embeddings=e, masks=m)
+    times = {}
     with torch.no_grad():
-        R.unet_forward(sd, cd, x, 500, ehs, gligen=gl, fuser_enabled=True)
-    t_on = time.time() - t0
-    t_off = t_on * 1.6065 / 2.2736
-    sched = R.DDIM()
-    sched.set_timesteps(50)
+        for on in ([True, False] if gl is not None else [False]):
+            t0 = time.time()
+            R.unet_forward(sd, cd, x, 500, ehs, gligen=gl, fuser_enabled=on)
+            times[on] = time.time() - t0
+    t_on, t_off = times.get(True, times[False]), times[False]
+    sched = R.DDIM(prediction_type=cfg.prediction_type)
+    sched.set_timesteps(n_steps)
     t0 = time.time()
     R.latent_backward_guidance(sd, cd, sched, cond, 0, boxes, [[1, 2, 3], [5, 6, 7]], sched.timesteps[0], x[:1],
                                torch.tensor(1e4), loss_scale=5, loss_threshold=0.0, max_iter=1, max_index_step=30,
                                guidance_attn_keys=R.DEFAULT_GUIDANCE_ATTN_KEYS, fg_top_p=0.2, bg_top_p=0.2,
                                fg_weight=1.0, bg_weight=4.0,
-                               gligen=dict(boxes=b[:1], positive_embeddings=e[:1], masks=m[:1]))
+                               gligen=dict(boxes=gl["boxes"][:1], positive_embeddings=gl["positive_embeddings"][:1],
+                                           masks=gl["masks"][:1]) if gl else None)
     t_g = time.time() - t0
-    per_image = (n_boxes + 1) * (20 * t_on + 30 * t_off) + (iters_on + iters_off) * t_g
+    n_on = int(beta * n_steps) if gl is not None else 0
+    per_image = (n_boxes + 1) * (n_on * t_on + (n_steps - n_on) * t_off) + (iters_on + iters_off) * t_g
     return dict(value=1.0 / per_image, unit="images/s", cores=cores, kind="port",
-                sample=(f"oracle/restate.py fp32 on {cores} host threads: 1 CFG UNet call (B=2, fuser on) {t_on:.2f}s, "
-                        f"fuser-off call priced at 1.6065/2.2736 of it ({t_off:.2f}s), 1 guidance iteration "
-                        f"(fwd+bwd, early exit) {t_g:.2f}s; extrapolated to one {n_boxes}-box LMD+ image = "
-                        f"(N+1)(20 on + 30 off) UNet calls + {iters_on + iters_off} guidance iterations (VAE excluded)"))
+                sample=(f"oracle/restate.py fp32 on {cores} host threads, measured: 1 CFG UNet call (B=2) fuser on "
+                        f"{t_on:.2f}s, fuser off {t_off:.2f}s, 1 guidance iteration (fwd+bwd, early exit, fuser on) "
+                        f"{t_g:.2f}s; extrapolated to one {n_boxes:.2f}-box LMD+ image = (N+1)({n_on} on + "
+                        f"{n_steps - n_on} off) UNet calls + {iters_on + iters_off:.1f} guidance iterations (VAE excluded)"))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def respawn(n):
+    """`python bench.py --gpus N` without a rendezvous in the environment: start N ranks of this script under
+    torch.distributed.run (one process per GPU), exactly as the driver would."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -93,131 +142,203 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--layouts", type=int, default=4, help="cached layouts per rank per step")
+    ap.add_argument("--workload", default="batch4", choices=["batch4", "lmd_v0.1"])
+    ap.add_argument("--layouts", type=int, default=4, help="batch4: cached layouts per rank per step")
+    ap.add_argument("--prompts", type=int, default=100, help="lmd_v0.1: prompts of the cache (whole job)")
     ap.add_argument("--config", default="sd14_gligen")
     ap.add_argument("--num-inference-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-dryrun", action="store_true",
+                    help="rendezvous / weight broadcast / partition / timing collectives on CPU (gloo), no GPU work")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn(args.gpus))
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import lgd_amd  # noqa: F401
-    from lgd_amd import dist as ldist, ops, weights
-    from lgd_amd.pipeline import CachedLayout, lmd_plus_generate_batch
+    from lgd_amd import dist as ldist, weights
+    from lgd_amd.pipeline import CachedLayout
+    cache = load_cache()
+    cfg = weights.CONFIGS["tiny_gligen" if args.cpu_dryrun else args.config]
+    T = args.num_inference_steps
+    beta = 0.4                                                      # lmd_plus.py:208-209
+
+    # ---- this rank's share of the work (global prompt index preserved: seeds derive from it) -----------------
+    if args.workload == "batch4":
+        pool = [i for i, r in enumerate(cache) if len(r["gen_boxes"]) == 2]
+        mine = [pool[(rank * args.layouts + i) % len(pool)] for i in range(args.layouts)]
+        seeds = [rank * args.layouts + i for i in range(args.layouts)]
+        n_total = args.layouts * world
+    else:
+        sel = select_prompts(cache, args.prompts)
+        parts = partition_by_cost([len(cache[i]["gen_boxes"]) + 1 for i in sel], world)
+        mine = [sel[j] for j in parts[rank]]
+        seeds = list(mine)
+        n_total = len(sel)
+    lays = [CachedLayout.synthetic(cfg, [(n, b) for n, b in cache[i]["gen_boxes"]], index=s) for i, s in zip(mine, seeds)]
+    my_boxes = sum(l.n_boxes for l in lays)
+
+    if args.cpu_dryrun:
+        from lgd_amd.weightstore import WeightStore
+        if world > 1:
+            ldist.init(backend="gloo")
+        ws = WeightStore(cfg, "cpu")
+        if rank == 0:
+            ws.load_state_dict(weights.synth_state_dict(cfg, 0))
+        bcast_s = ldist.broadcast_weights(ws, src=0, chunk_bytes=8 << 20)
+        ldist.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (len(lays) + my_boxes))
+        dt = ldist.max_over_ranks(time.perf_counter() - t0)
+        loads = ldist.gather_floats(float(len(lays) + my_boxes))
+        csum = ldist.sum_over_ranks(float(ws.arena16.float().abs().sum()))
+        ldist.shutdown()
+        if rank == 0:
+            print(json.dumps(dict(metric="dryrun", n_gpus=world, rccl_ranks=world, images=n_total,
+                                  weight_broadcast_s=round(bcast_s, 4), per_rank_cost=loads,
+                                  weights_identical=abs(csum / world - float(ws.arena16.float().abs().sum())) < 1e-3,
+                                  max_s=dt)))
+        return
+
+    from lgd_amd import ops
+    from lgd_amd.pipeline import lmd_plus_generate_batch
     from lgd_amd.sampler import LMDSampler
     from lgd_amd.scheduler import DDIMScheduler
     from lgd_amd.unet import UNetEngine
     from lgd_amd.vae import make_hip_vae
-
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         ldist.init(backend="nccl")
-    cfg = weights.CONFIGS[args.config]
     # rank 0 materialises the weights; everyone else receives the two arenas over RCCL/xGMI
     eng = UNetEngine(cfg, dev, weights.synth_state_dict(cfg, 0) if rank == 0 else None)
     bcast_s = ldist.broadcast_weights(eng.w, src=0) if world > 1 else 0.0
     vae = None if args.no_decode else make_hip_vae(dev)
     sm = LMDSampler(eng, DDIMScheduler(prediction_type=cfg.prediction_type), vae=vae)
 
-    pool = load_layouts(2)
-    mine = [pool[(rank * args.layouts + i) % len(pool)] for i in range(args.layouts)]
-    lays = [CachedLayout.synthetic(cfg, [(n, b) for n, b in r["gen_boxes"]], index=rank * args.layouts + i)
-            for i, r in enumerate(mine)]
-    T = args.num_inference_steps
-
     def one_step():
-        outs = lmd_plus_generate_batch(sm, lays, num_inference_steps=T, decode=not args.no_decode)
-        return sum(o["guidance_iters"] for o in outs)
+        return lmd_plus_generate_batch(sm, lays, num_inference_steps=T, decode=not args.no_decode) if lays else []
 
     for _ in range(args.warmup):
         one_step()
+    sm.pass_counts.clear()
     ldist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    iters = 0
+    it_on = it_all = 0
     for _ in range(args.steps):
-        iters += one_step()
+        outs = one_step()
+        it_all += sum(o["guidance_iters"] for o in outs)
+        it_on += sum(o["guidance_iters_fuser_on"] for o in outs)
     torch.cuda.synchronize()
+    busy = time.perf_counter() - t0
     ldist.barrier()
-    dt = time.perf_counter() - t0
-    dt = ldist.max_over_ranks(dt)
-    n_images = args.steps * args.layouts * world
+    dt = ldist.max_over_ranks(time.perf_counter() - t0)
+    per_rank_busy = ldist.gather_floats(busy)
+    tot_on, tot_all = ldist.sum_over_ranks(float(it_on)), ldist.sum_over_ranks(float(it_all))
+    tot_boxes = ldist.sum_over_ranks(float(my_boxes))
+    n_images = args.steps * n_total
     ldist.shutdown()            # all ranks together, right after the last collective; the rest is rank-0 local
     if rank != 0:
         return
-    it_per_image = iters / max(args.steps * args.layouts, 1)
+    iters_on, iters_off = tot_on / n_images, (tot_all - tot_on) / n_images       # per image, job-wide means
+    mean_boxes = tot_boxes / n_total
     # ---- roofline of the dominant kernel.  The timed region replays captured hipGraphs (one launch per
     # UNet call), so individual kernels cannot be bracketed there; right after it, the very same plans are
     # launched eagerly on the same stream with HIP events around every GEMM/attention launch, and the
-    # per-pass times are weighted by how often the timed region ran each pass.
-    n_box = 2
-    nl = args.layouts
-    n_on = int(0.4 * T)
-    # launches of each pass per timed step: stage A = one batched call over nl*n_box boxes, stage B = one
-    # batched call over nl layouts + its guidance iterations (the batch iterates until its slowest image exits)
-    per_step = {("main", True, nl * n_box): n_on, ("main", False, nl * n_box): T - n_on,
-                ("main", True, nl): n_on, ("main", False, nl): T - n_on,
-                ("guide", True, nl): it_per_image * 55.0 / 65.0, ("guide", False, nl): it_per_image * 10.0 / 65.0}
-    agg = {}
-    reps = 3
-    for kind, fz, nb_, fn in sm.profile_passes(64, T, cfg.use_gated_attention, main_batches=sorted({nl * n_box, nl}),
-                                               guide_batches=(nl,)):
-        fn()
-        torch.cuda.synchronize()
-        prof = ops.LaunchProfiler()
-        ops.PROFILER = prof
-        for _ in range(reps):
-            fn()
-        ops.PROFILER = None
-        w = per_step.get((kind, fz, nb_), 0.0) / reps / nl          # per image
-        for k, v in prof.summary().items():
-            a = agg.setdefault(k, dict(ms=0.0, flops=0.0, n=0.0, raw_ms=0.0, raw_n=0))
-            a["ms"] += v["ms"] * w
-            a["flops"] += v["flops"] * w
-            a["n"] += v["n"] * w
-            a["raw_ms"] += v["ms"]
-            a["raw_n"] += v["n"]
-    dom = max(agg.items(), key=lambda kv: kv[1]["ms"]) if agg else None
+    # per-pass times are weighted by how often the timed region actually ran each pass (LMDSampler.pass_counts).
     roofline = None
-    if dom is not None:
-        name, a = dom
-        ach = a["flops"] / (a["ms"] * 1e-3)
-        roofline = dict(bound="mfma", kernel=name, achieved=round(ach / 1e12, 2), peak=MFMA_PEAK_F16 / 1e12,
-                        unit="TFLOP/s", frac=round(ach / MFMA_PEAK_F16, 4), traffic=None,
-                        avg_launch_us=round(a["raw_ms"] * 1e3 / a["raw_n"], 2),
-                        launches_per_image=round(a["n"]), est_ms_per_image=round(a["ms"], 1),
-                        traffic_note="null: a rocprofv3 --pmc pass over this command serialises ~50k dispatches and "
-                                     "does not finish; the PMC HBM traffic of this kernel on its top shape is in "
-                                     "profiles/r01e_gemm_traffic_pmc.json (182 MB measured vs 128 MB algorithmic per "
-                                     "launch, 1.2 TB/s: not HBM-bound)",
-                        method="HIP events around each launch, eager replay of the benchmark's plans right after "
-                               "the timed region (the timed region itself replays hipGraphs)",
-                        all_kernels={k: dict(ms_per_image=round(v["ms"], 1), launches_per_image=round(v["n"]),
-                                             tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1))
-                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])})
-    it_per_image = iters / max(args.steps * args.layouts, 1)
+    if not args.no_roofline and sm.pass_counts:
+        counts = dict(sm.pass_counts)
+        my_images = max(args.steps * len(lays), 1)
+        agg, tag_agg = {}, {}
+        reps = 2
+        mains = sorted({nb for (k, f, nb) in counts if k == "main"})
+        guides = sorted({nb for (k, f, nb) in counts if k == "guide"})
+        for kind, fz, nb_, fn in sm.profile_passes(cfg.sample_size, T, cfg.use_gated_attention, main_batches=mains,
+                                                   guide_batches=guides):
+            n_runs = counts.get((kind, fz, nb_), 0)
+            if not n_runs:
+                continue
+            fn()
+            torch.cuda.synchronize()
+            prof = ops.LaunchProfiler(max_records=100000)
+            ops.PROFILER = prof
+            for _ in range(reps):
+                fn()
+            ops.PROFILER = None
+            w = n_runs / reps / my_images                                 # per image of this rank
+            for dst, summ in ((agg, prof.summary()), (tag_agg, prof.summary(by_tag=True))):
+                for k, v in summ.items():
+                    a = dst.setdefault(k, dict(ms=0.0, flops=0.0, n=0.0, raw_ms=0.0, raw_n=0))
+                    a["ms"] += v["ms"] * w
+                    a["flops"] += v["flops"] * w
+                    a["n"] += v["n"] * w
+                    a["raw_ms"] += v["ms"]
+                    a["raw_n"] += v["n"]
+        if agg:
+            name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+            ach = a["flops"] / (a["ms"] * 1e-3)
+            traffic, traffic_note = None, "no PMC summary for this kernel under profiles/"
+            tpath = os.path.join(ROOT, "profiles", "r02_bench_traffic_pmc.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                ent = tj.get("kernels", {}).get(name.split(" ")[0])
+                if ent:
+                    traffic, traffic_note = ent["hbm_bytes_per_launch"], tj.get("method", "")
+            gem = [v for k, v in agg.items() if k.startswith("gemm")]
+            gemm_tf = sum(v["flops"] for v in gem) / max(sum(v["ms"] for v in gem) * 1e-3, 1e-12) / 1e12 if gem else None
+            ap_ = tag_agg.get("attn_path")
+            roofline = dict(bound="mfma", kernel=name, achieved=round(ach / 1e12, 2), peak=MFMA_PEAK_F16 / 1e12,
+                            unit="TFLOP/s", frac=round(ach / MFMA_PEAK_F16, 4), traffic=traffic,
+                            avg_launch_us=round(a["raw_ms"] * 1e3 / a["raw_n"], 2),
+                            launches_per_image=round(a["n"]), est_ms_per_image=round(a["ms"], 1),
+                            traffic_note=traffic_note,
+                            method="HIP events around each launch, eager replay of the benchmark's plans right after "
+                                   "the timed region (the timed region itself replays hipGraphs); weights = the "
+                                   "timed region's own pass counts",
+                            all_gemm_tflops=round(gemm_tf, 1) if gemm_tf else None,
+                            attention_path=(dict(what="q/k/v/out projections + SDPA (self, GLIGEN fuser, cross)",
+                                                 ms_per_image=round(ap_["ms"], 1),
+                                                 tflops=round(ap_["flops"] / (ap_["ms"] * 1e-3) / 1e12, 1),
+                                                 frac_of_mfma_peak=round(ap_["flops"] / (ap_["ms"] * 1e-3) / MFMA_PEAK_F16, 4))
+                                            if ap_ else None),
+                            all_kernels={k: dict(ms_per_image=round(v["ms"], 1), launches_per_image=round(v["n"]),
+                                                 tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1))
+                                         for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])})
+    tf = algorithmic_tflop(mean_boxes, T, beta, iters_on, iters_off) if args.config == "sd14_gligen" else None
+    what = (f"{args.layouts} cached 2-box layouts/GPU/step" if args.workload == "batch4" else
+            f"{n_total} layouts of the lmd_v0.1 cache (0-5 boxes, mean {mean_boxes:.2f}) cost-balanced over {world} rank(s)")
     res = dict(metric="images/sec (50-step SD1.5 512^2, LMD+ guidance)", value=round(n_images / dt, 4),
                unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-               ms_per_step=round(dt * 1e3 / args.steps, 1), higher_is_better=True, scaling="weak",
+               ms_per_step=round(dt * 1e3 / args.steps, 1), higher_is_better=True,
+               scaling="weak" if args.workload == "batch4" else "strong",
                vs_baseline=None, dtype="fp16", data="synthetic",
-               config=dict(workload=f"LMD+ stage 2, {args.layouts} cached 2-box layouts/GPU/step (lmd_v0.1 cache), "
-                                    f"{T} DDIM steps, 512x512, {args.config} (SD1.4+GLIGEN architecture, seeded random "
-                                    f"weights), VAE decodes {'excluded' if args.no_decode else 'included'}",
-                           layouts_per_gpu=args.layouts, num_inference_steps=T, parallelism=f"dp{world}",
-                           guidance_iters_per_image=round(it_per_image, 1),
-                           algorithmic_tflop_per_image=algorithmic_tflop_per_image(args.config, 2, it_per_image, 0),
-                           weight_broadcast_s=round(bcast_s, 3)),
+               config=dict(workload=f"LMD+ stage 2, {what} (lmd_v0.1 cache), {T} DDIM steps, 512x512, {args.config} "
+                                    f"(SD1.4+GLIGEN architecture, seeded random weights), VAE decodes "
+                                    f"{'excluded' if args.no_decode else 'included'}",
+                           layouts_per_gpu=(args.layouts if args.workload == "batch4" else round(n_total / world, 2)),
+                           num_inference_steps=T, parallelism=f"dp{world}", rccl_ranks=world,
+                           guidance_iters_per_image=round(iters_on + iters_off, 2),
+                           guidance_iters_fuser_on=round(iters_on, 2),
+                           algorithmic_tflop_per_image=round(tf, 3) if tf else None,
+                           weight_broadcast_s=round(bcast_s, 3),
+                           per_rank_busy_s=[round(b, 3) for b in per_rank_busy]),
                roofline=roofline)
-    tf = res["config"]["algorithmic_tflop_per_image"]
     if tf:
         res["config"]["whole_path_frac_of_mfma_peak"] = round(tf * 1e12 * (n_images / dt) / world / MFMA_PEAK_F16, 4)
     if world == 1 and not args.no_cpu_baseline:
         try:
-            res["cpu_baseline"] = cpu_baseline(cfg, 2, it_per_image, 0)
+            res["cpu_baseline"] = cpu_baseline(cfg, mean_boxes, T, beta, iters_on, iters_off)
         except Exception as e:  # the baseline is reported, never gating
             res["cpu_baseline"] = dict(value=None, unit="images/s", cores=os.cpu_count(), kind="port",
                                        sample=f"failed: {e}")

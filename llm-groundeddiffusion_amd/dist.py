@@ -63,6 +63,17 @@ def sum_over_ranks(x: float) -> float:
     return float(t.item())
 
 
+def gather_floats(x: float):
+    """[x of rank 0, x of rank 1, ...] on every rank (per-rank busy time / load reports)."""
+    if not dist.is_initialized():
+        return [float(x)]
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def broadcast_weights(store, src=0, chunk_bytes=256 << 20) -> float:
     """Replicates a WeightStore: two flat arenas, broadcast in large chunks (fewer, larger
     collectives suit the point-to-point xGMI links).  Returns seconds."""

@@ -147,21 +147,24 @@ class LaunchProfiler:
         self.max = max_records
         self.enabled = True
 
-    def wrap(self, name, flops, nbytes, fn):
+    def wrap(self, name, flops, nbytes, fn, tag=None):
         if not self.enabled or len(self.recs) >= self.max:
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         r = fn()
         e1.record()
-        self.recs.append((name, flops, nbytes, e0, e1))
+        self.recs.append((name, flops, nbytes, e0, e1, tag))
         return r
 
-    def summary(self):
+    def summary(self, by_tag=False):
+        """Per kernel name (or per caller tag, e.g. "attn_path"): ms, algorithmic flops / bytes, launches."""
         torch.cuda.synchronize()
         agg = {}
-        for name, fl, nb, e0, e1 in self.recs:
-            a = agg.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
+        for name, fl, nb, e0, e1, tag in self.recs:
+            if by_tag and tag is None:
+                continue
+            a = agg.setdefault(tag if by_tag else name, dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
             a["ms"] += e0.elapsed_time(e1)
             a["flops"] += fl
             a["bytes"] += nb
@@ -172,13 +175,13 @@ class LaunchProfiler:
 PROFILER = None
 
 
-def gemm_launch(desc):
+def gemm_launch(desc, tag=None):
     if PROFILER is not None:
         nb = desc.nb_o * desc.nb_i
         flops = 2.0 * desc.M * desc.N * desc.K * nb
         nbytes = 2.0 * nb * (desc.M * desc.K / max(desc.taps, 1) + desc.N * desc.K + desc.M * desc.N)
         return PROFILER.wrap(TILE_NAMES.get(desc.tile, "gemm"), flops, nbytes,
-                             lambda: _call("lgd_gemm_f16", C.byref(desc), _stream()))
+                             lambda: _call("lgd_gemm_f16", C.byref(desc), _stream()), tag)
     _call("lgd_gemm_f16", C.byref(desc), _stream())
 
 
@@ -322,7 +325,8 @@ def attn_fwd(q, k, v, o, B, H, Sq, Sk, d, scale, *, lse=None, q_view=None, k_vie
     fn = lambda: _call("lgd_attn_fwd_f16", _p(q), qv[0], qv[1], _p(k), kv[0], kv[1], _p(v), vv[0], vv[1],
                        _p(o), ov[0], ov[1], _p(lse), B, H, Sq, Sk, d, float(scale), _stream())
     if PROFILER is not None:
-        PROFILER.wrap(f"attn_fwd_kernel d={d}", 4.0 * B * H * Sq * Sk * d, 2.0 * B * H * d * (2 * Sq + 2 * Sk), fn)
+        PROFILER.wrap(f"attn_self_kernel d={d}", 4.0 * B * H * Sq * Sk * d, 2.0 * B * H * d * (2 * Sq + 2 * Sk), fn,
+                      "attn_path")
     else:
         fn()
     return o
@@ -347,9 +351,14 @@ def cross_attn_fwd(q, k, v, o, B, H, Sq, Sk, d, scale, *, probs=None, tok=-1, co
     kv = k_view or (H * d, Sk * H * d)
     vv = v_view or (H * d, Sk * H * d)
     ov = o_view or (H * d, Sq * H * d)
-    _call("lgd_cross_attn_fwd_f16", _p(q), qv[0], qv[1], _p(k), kv[0], kv[1], _p(v), vv[0], vv[1],
-          _p(o), ov[0], ov[1], _p(probs), int(tok), 1 if cond_only else 0, B, H, Sq, Sk, d,
-          float(scale), _stream())
+    fn = lambda: _call("lgd_cross_attn_fwd_f16", _p(q), qv[0], qv[1], _p(k), kv[0], kv[1], _p(v), vv[0], vv[1],
+                       _p(o), ov[0], ov[1], _p(probs), int(tok), 1 if cond_only else 0, B, H, Sq, Sk, d,
+                       float(scale), _stream())
+    if PROFILER is not None:
+        PROFILER.wrap(f"attn_fwd_kernel(cross) d={d}", 4.0 * B * H * Sq * Sk * d,
+                      2.0 * B * H * d * (2 * Sq + 2 * Sk), fn, "attn_path")
+    else:
+        fn()
     return o
 
 

@@ -46,6 +46,14 @@ class CachedLayout:
     bg_seed: int = 0
     fg_seed_start: int = 20
 
+    def __post_init__(self):
+        # The reference pairs the f-th per-box generation with the f-th box of the flattened overall list
+        # (lmd_plus.py:441-456, latents.py:85-118): that only works because parse.convert_spec sorts boxes by
+        # name and groups them with np.unique.  Everything downstream relies on the same invariant.
+        flat = [i for grp in self.overall_groups for i in grp]
+        if flat != list(range(len(self.boxes))):
+            raise ValueError(f"overall_groups must list the boxes in order (got {self.overall_groups})")
+
     @property
     def n_boxes(self):
         return len(self.boxes)
@@ -198,7 +206,7 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
                         bg_weight=overall_bg_weight, ref_ca_word_token_only=True, ref_ca_last_token_only=True,
                         word_token_indices=lay.overall_word_token_indices, ref_ca_loss_weight=ref_ca_loss_weight,
                         guidance_attn_keys=keys,
-                        ref_maps=_ref_maps(sampler, [d["saved"][i] for i in flat], keys, L, T) if use_ref_ca else None)
+                        ref_maps=_ref_maps(sampler, d["saved"], keys, L, T) if use_ref_ca else None)
         gl = prepare_gligen_condition([list(lay.boxes[i]) for i in flat], lay.phrase_embeddings[flat], dev)
         jobs_b.append(Job(composed, torch.cat([lay.overall_uncond, lay.overall_cond]), gligen=gl, guidance=guid,
                           frozen_mask=(fg_idx != 0)))
@@ -207,7 +215,9 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
                                   frozen_steps=frozen_steps, save_all_latents=False)
     images = sampler.decode(torch.cat([r["latents"] for r in res_b])) if decode else [None] * len(lays)
     return [dict(image=images[li], latents=res_b[li]["latents"], so_images=per_lay[li]["so_images"],
-                 guidance_iters=res_b[li]["guidance_iters"], composed=comps[li][0], fg_idx=comps[li][1])
+                 guidance_iters=res_b[li]["guidance_iters"],
+                 guidance_iters_fuser_on=res_b[li]["guidance_iters_fuser_on"], composed=comps[li][0],
+                 fg_idx=comps[li][1])
             for li in range(len(lays))]
 
 
@@ -284,7 +294,7 @@ def lmd_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, num_inf
                         bg_weight=overall_bg_weight, ref_ca_word_token_only=True, ref_ca_last_token_only=True,
                         word_token_indices=lay.overall_word_token_indices, ref_ca_loss_weight=ref_ca_loss_weight,
                         guidance_attn_keys=keys,
-                        ref_maps=_ref_maps(sampler, [d["saved"][i] for i in flat], keys, L, T) if use_ref_ca else None)
+                        ref_maps=_ref_maps(sampler, d["saved"], keys, L, T) if use_ref_ca else None)
         jobs_b.append(Job(composed, torch.cat([lay.overall_uncond, lay.overall_cond]), guidance=guid,
                           frozen_mask=(fg_idx != 0)))
     res_b = sampler.denoise_batch(jobs_b, T, guidance_scale=guidance_scale, frozen_steps=frozen_steps,

@@ -53,6 +53,7 @@ class GuidanceState:
         self.max_iter, self.max_index_step = max_iter, int(max_index_step)
         self.loss = 10000.0             # carried across steps; pipelines.py:161,375,552
         self.iterations = 0
+        self.iterations_fuser_on = 0    # of which: taken while the GLIGEN fuser was enabled (accounting only)
 
     def iters_at(self, index):
         m = self.max_iter
@@ -106,8 +107,16 @@ class Job:
 
 
 class LMDSampler:
+    BUCKETS = (1, 2, 4, 8, 16)
+
     def __init__(self, engine: UNetEngine, scheduler: Optional[DDIMScheduler] = None, vae=None,
-                 grad_scale: float = 1024.0, use_graphs: bool = True):
+                 grad_scale: float = 1024.0, use_graphs: bool = True, max_batch: int = 8,
+                 max_batch_guided: int = 4):
+        """max_batch / max_batch_guided: images per UNet call for unguided / guided denoising calls; longer
+        job lists are chunked, and every chunk is padded to the next size in BUCKETS so that only a handful
+        of launch plans, captured graphs and (tuned) GEMM shapes ever exist."""
+        self.max_batch = max(1, min(int(max_batch), engine.max_text_batch // 2))
+        self.max_batch_guided = max(1, min(int(max_batch_guided), self.max_batch))
         self.eng = engine
         self.dev = engine.device
         self.scheduler = scheduler or DDIMScheduler(prediction_type=engine.cfg.prediction_type)
@@ -115,6 +124,7 @@ class LMDSampler:
         self.grad_scale = grad_scale
         self.use_graphs = use_graphs
         self.stats = dict(unet_main=0, guidance_iters=0)
+        self.pass_counts: Dict[Tuple, int] = {}      # (kind, fuser on?, images) -> launches of that plan
         self._states = {}
 
     # ------------------------------------------------------------------------------------------
@@ -153,10 +163,18 @@ class LMDSampler:
         return GuidanceState(en, loss_scale, loss_threshold, max_iter, max_index_step)
 
     # ------------------------------------------------------------------------------------------
+    MAX_STATES = 12
+
     def _state(self, nb, C, L, T) -> _State:
+        """Device state + captured graphs per (batch bucket, latent shape, step count); least recently used
+        entries are dropped so a long run over many shapes keeps a bounded footprint."""
         key = (nb, C, L, T)
         if key not in self._states:
             self._states[key] = _State(self.dev, nb, C, L, T)
+            while len(self._states) > self.MAX_STATES:
+                self._states.pop(next(iter(self._states)))
+        else:
+            self._states[key] = self._states.pop(key)          # move to the MRU end
         return self._states[key]
 
     def _runner(self, st: _State, name, fn):
@@ -172,7 +190,7 @@ class LMDSampler:
         B=nb grad plan on the conditional text (second half of the text batch) and the zero-masked GLIGEN
         half (pipelines.py:381-384)."""
         eng = self.eng
-        pg = eng.plan(nb, L, grad=True, fuser=fuser, stop_key=gkeys[-1], save_keys=gkeys,
+        pg = eng.plan(nb, L, grad=True, fuser=fuser, stop_key=eng.last_key(gkeys), save_keys=gkeys,
                       text_batch_offset=nb, obj_batch_offset=0)
 
         def g_fwd():
@@ -184,8 +202,12 @@ class LMDSampler:
         name = ("guide", fuser, tuple(gkeys))
         return pg, self._runner(st, name + ("fwd",), g_fwd), self._runner(st, name + ("bwd",), g_bwd)
 
+    def _count(self, kind, fuser, nb):
+        k = (kind, bool(fuser), int(nb))
+        self.pass_counts[k] = self.pass_counts.get(k, 0) + 1
+
     def backward_guidance(self, states: List[Optional[GuidanceState]], energy: EnergyTables, plan_g, index: int,
-                          st: _State, fwd_run, bwd_run, trace: Optional[list] = None):
+                          st: _State, fwd_run, bwd_run, trace: Optional[list] = None, fuser: bool = False):
         """latent_backward_guidance (pipelines.py:16-82) for a batch of images on st.lat.  Each image keeps
         its own `while loss/scale > thr and it < max_iter` exit: an image that left the loop is masked out of
         the latent update (st.active) and its carried loss is not refreshed."""
@@ -201,11 +223,13 @@ class LMDSampler:
             fwd_run()                                               # grad-plan forward from st.lat
             loss_dev = energy.run(self.eng.dyn, grad_scale=self.grad_scale)
             bwd_run()                                               # backward + masked latent update
+            self._count("guide", fuser, nb)
             losses = loss_dev.tolist()                              # host sync, as pipelines.py:30
             for j, gs in enumerate(states):
                 if act[j]:
                     gs.loss = losses[j]
                     gs.iterations += 1
+                    gs.iterations_fuser_on += int(bool(fuser))
                     self.stats["guidance_iters"] += 1
             if trace is not None:
                 trace.append(dict(index=index, it=it, loss=losses[0], losses=losses,
@@ -236,7 +260,7 @@ class LMDSampler:
             eng.prepare_gligen(boxes=gligen[0], positive_embeddings=gligen[1], masks=gligen[2])
         st.lat.copy_(latents.to(dev, F32))
         if gs is not None:
-            self.backward_guidance([gs], gs.energy, pg, index, st, gf, gb, trace)
+            self.backward_guidance([gs], gs.energy, pg, index, st, gf, gb, trace, fuser=fuser)
         return st.lat.clone(), (gs.loss if gs is not None else None), gs
 
     # ------------------------------------------------------------------------------------------
@@ -252,7 +276,8 @@ class LMDSampler:
                 out.append(("main", f, nb, eng.plan(2 * nb, L, fuser=f, save_keys=plan_keys).forward))
             for nb in guide_batches:
                 st = self._state(nb, eng.cfg.in_channels, L, T)
-                pg = eng.plan(nb, L, grad=True, fuser=f, stop_key=keys[-1], save_keys=keys, text_batch_offset=nb)
+                pg = eng.plan(nb, L, grad=True, fuser=f, stop_key=eng.last_key(keys), save_keys=keys,
+                              text_batch_offset=nb)
 
                 def guide(pg=pg, st=st):
                     pg.forward(st.lat)
@@ -267,11 +292,31 @@ class LMDSampler:
         job = Job(latents, text_embeddings, gligen, guidance, frozen_mask, return_token_ca_only)
         return self.denoise_batch([job], num_inference_steps, use_gligen=gligen is not None, **shared)[0]
 
-    def denoise_batch(self, jobs: List[Job], num_inference_steps: int, *, guidance_scale: float = 7.5,
-                      use_gligen: bool = False, gligen_scheduled_sampling_beta: float = 0.3,
-                      frozen_steps: int = 0, saved_cross_attn_keys: Sequence[Tuple] = (),
-                      return_cond_ca_only: bool = False, save_all_latents: bool = True,
-                      trace: Optional[list] = None, fast_after_steps: Optional[int] = None, fast_rate: int = 2):
+    def denoise_batch(self, jobs: List[Job], num_inference_steps: int, **kw):
+        """Any number of independent images: guided and unguided jobs are chunked separately (at most
+        max_batch_guided / max_batch images per UNet call — the reference runs them one at a time, so any count
+        works there too), every chunk is padded to a bucket size with inert copies of its last job, and the
+        results come back in job order.  Arguments and per-job result as `_denoise_chunk`."""
+        out: List[Optional[dict]] = [None] * len(jobs)
+        for guided, cap in ((True, self.max_batch_guided), (False, self.max_batch)):
+            idx = [i for i, j in enumerate(jobs) if (j.guidance is not None) == guided]
+            for c0 in range(0, len(idx), cap):
+                part = idx[c0:c0 + cap]
+                chunk = [jobs[i] for i in part]
+                nb = next((b for b in self.BUCKETS if b >= len(chunk)), len(chunk))
+                last = chunk[-1]
+                pad = [Job(last.latents, last.text, last.gligen, None, last.frozen_mask, last.token)
+                       for _ in range(min(nb, cap) - len(chunk))]
+                res = self._denoise_chunk(chunk + pad, num_inference_steps, **kw)
+                for i, r in zip(part, res):
+                    out[i] = r
+        return out
+
+    def _denoise_chunk(self, jobs: List[Job], num_inference_steps: int, *, guidance_scale: float = 7.5,
+                       use_gligen: bool = False, gligen_scheduled_sampling_beta: float = 0.3,
+                       frozen_steps: int = 0, saved_cross_attn_keys: Sequence[Tuple] = (),
+                       return_cond_ca_only: bool = False, save_all_latents: bool = True,
+                       trace: Optional[list] = None, fast_after_steps: Optional[int] = None, fast_rate: int = 2):
         """Generic 50-step loop over a batch of independent images (one UNet call serves all of them:
         B = 2*len(jobs) for the CFG pass, len(jobs) for the guidance pass).
 
@@ -313,7 +358,10 @@ class LMDSampler:
                 gstates.append(None)
                 continue
             g = dict(j.guidance)
-            gkeys = [tuple(k) for k in (g.get("guidance_attn_keys") or DEFAULT_GUIDANCE_ATTN_KEYS)]
+            jk = [tuple(k) for k in (g.get("guidance_attn_keys") or DEFAULT_GUIDANCE_ATTN_KEYS)]
+            if gkeys is not None and jk != gkeys:
+                raise RuntimeError("jobs guided in one batch must share guidance_attn_keys")
+            gkeys = jk
             gstates.append(self.make_guidance(L, g.pop("bboxes"), g.pop("object_positions"), **g))
         guided = any(gs is not None for gs in gstates)
         energy = None
@@ -371,9 +419,10 @@ class LMDSampler:
             fuser_on = fuser_at(index)
             if guided and index < max_guided:
                 pg, gf, gb = runners_guide[fuser_on]
-                self.backward_guidance(gstates, energy, pg, index, st, gf, gb, trace)
+                self.backward_guidance(gstates, energy, pg, index, st, gf, gb, trace, fuser=fuser_on)
             runners_main[fuser_on]()
             self.stats["unet_main"] += 1
+            self._count("main", fuser_on, nb)
             if save_keys:
                 maps = plans_main[fuser_on].maps
                 for b, j in enumerate(jobs):                              # attention_processor.py:466-476
@@ -382,7 +431,8 @@ class LMDSampler:
                         saved[b][k][index].copy_(m[..., int(j.token):int(j.token) + 1] if j.token is not None else m)
         hist = st.hist[:Tr + 1].clone() if save_all_latents else None
         return [dict(latents=st.lat[b:b + 1].clone(), latents_all=hist[:, b:b + 1] if hist is not None else None,
-                     saved=saved[b], guidance_iters=gstates[b].iterations if gstates[b] is not None else 0)
+                     saved=saved[b], guidance_iters=gstates[b].iterations if gstates[b] is not None else 0,
+                     guidance_iters_fuser_on=gstates[b].iterations_fuser_on if gstates[b] is not None else 0)
                 for b in range(nb)]
 
     # ------------------------------------------------------------------------------------------
@@ -391,7 +441,9 @@ class LMDSampler:
         """pipelines.py:117-127: VAE decode -> uint8 HWC (the VAE is [ext] and stays PyTorch/MIOpen)."""
         if self.vae is None:
             raise RuntimeError("no VAE attached to the sampler")
-        image = self.vae.decode(latents / 0.18215)
-        image = (image / 2 + 0.5).clamp(0, 1)
-        image = image.detach().float().cpu().permute(0, 2, 3, 1).numpy()
-        return (image * 255).round().astype("uint8")
+        outs = []
+        for c0 in range(0, latents.shape[0], 8):                  # bounded activation footprint
+            image = self.vae.decode(latents[c0:c0 + 8] / 0.18215)
+            image = (image / 2 + 0.5).clamp(0, 1)
+            outs.append((image.detach().float().permute(0, 2, 3, 1) * 255).round().to(torch.uint8))
+        return torch.cat(outs).cpu().numpy()

@@ -20,6 +20,7 @@ attention_processor.py of the reference (and torch.autograd for pipelines.py:56)
     key (pipelines.py:46 TODO).
 """
 import math
+from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -70,20 +71,26 @@ class Plan:
         self.dbg: Dict[str, Act] = {}                 # named activations (debugging / tests)
         self.maps: Dict[Tuple, torch.Tensor] = {}     # key -> fp32 [B,H,HW,T] captured probabilities
         self.gmaps: Dict[Tuple, torch.Tensor] = {}    # key -> fp32 gradient of the map (grad plans)
-        self.latents_in = torch.zeros((B, eng.cfg.in_channels, L, L), device=eng.device, dtype=F32)
+        self._cursor = [0, 0]                         # (segment, byte offset) of the shared activation arena
+        self.arena_bytes = 0
+        self.latents_in = self._alloc((B, eng.cfg.in_channels, L, L))
         self.eps_out = None
         self.g_latents = None
         self._build()
 
     # --------------------------------------------------------------------------------------
     def _new(self, rows, C, dtype=F16):
-        # kernels see raw pointers only, so the plan itself must own every buffer it launches on
-        t = torch.empty((rows, C), device=self.eng.device, dtype=dtype)
-        self._buffers.append(t)
-        return t
+        return self._alloc((rows, C), dtype)
 
     def _alloc(self, shape, dtype=F32):
-        t = torch.empty(shape, device=self.eng.device, dtype=dtype)
+        """Every buffer of a plan is carved out of the engine's activation arena, starting at offset 0 of
+        segment 0 for EVERY plan: plans alias each other.  Only one plan is in flight at a time and nothing
+        a plan produces is read after another plan ran (maps / noise prediction / latent gradient are
+        consumed by the caller right after the launch sequence; grad plans keep their forward activations
+        until their own backward), so the resident footprint is the largest plan, not the sum of all
+        (batch, grad, fuser) variants — and addresses stay fixed, as captured hipGraphs need."""
+        t, self._cursor = self.eng.arena_take(self._cursor, shape, dtype)
+        self.arena_bytes += t.numel() * t.element_size()
         self._buffers.append(t)
         return t
 
@@ -109,7 +116,9 @@ class Plan:
         d = ops.gemm_desc(x.t, W, y.t, M, N, K, lda0=x.C, bias=b, res=res.t if res else None,
                           ldr=res.C if res else 0, alpha=alpha, epi=EPI_GEGLU if geglu else 0,
                           ldc=y.C)
-        fwd = lambda: ops.gemm_launch(d)
+        # q/k/v/out projections count towards the "attention path" of the benchmark's roofline report
+        tag = "attn_path" if any(t in name for t in (".attn1.", ".attn2.", ".fuser.attn.")) else None
+        fwd = lambda: ops.gemm_launch(d, tag)
         if not (self.grad and bwd):
             self._add(fwd)
             return y
@@ -314,9 +323,9 @@ class Plan:
             # the map is always captured whole (all images, all 77 columns) into a static buffer, so
             # the launch has no per-step arguments; callers slice what attention_processor.py:466-476
             # would have kept (token column / conditional half) when they copy it out.
-            probs = self.maps[key] = torch.zeros((B, heads, S, T), device=eng.device, dtype=F32)
+            probs = self.maps[key] = self._alloc((B, heads, S, T))
             if self.grad:
-                self.gmaps[key] = torch.zeros((B, heads, S, T), device=eng.device, dtype=F32)
+                self.gmaps[key] = self._alloc((B, heads, S, T))   # zeroed by the energy launch (EnergyTables.run)
         kt, vt = kv_t, kv_t[:, :, C:]
 
         def fwd():
@@ -451,7 +460,7 @@ class Plan:
                     H *= 2
         if not done:
             n = self.groupnorm(x, None, "conv_norm_out", H * H, cfg.norm_eps, True)
-            self.eps_out = torch.empty((B, cfg.out_channels, L, L), device=eng.device, dtype=F32)
+            self.eps_out = self._alloc((B, cfg.out_channels, L, L))
             eo = self.eps_out
             self._add(lambda: ops.conv_out(n.t, w.h["conv_out.w"], w.f["conv_out.b"], B, L, out=eo))
         if self.grad:
@@ -467,14 +476,14 @@ class Plan:
             op.acc = []
             for a in op.gouts:
                 if a.g is None:
-                    a.g = torch.zeros_like(a.t)
+                    a.g = self._alloc(tuple(a.t.shape), a.t.dtype)   # first writer overwrites (acc flags below)
                 op.acc.append(id(a) in seen)
                 seen.add(id(a))
         # every consumed activation now owns a .g, so the closures can bind output gradients
         for op in self.ops:
             if op.make_bwd is not None:
                 op.bwd = op.make_bwd(op.acc)
-        self.g_latents = torch.zeros_like(self.latents_in)
+        self.g_latents = self._alloc(tuple(self.latents_in.shape))
         self._bwd_ops = [op.bwd for op in reversed(self.ops) if op.bwd is not None]
 
     # --------------------------------------------------------------------------------------
@@ -499,8 +508,11 @@ class Plan:
 
 
 class UNetEngine:
+    ARENA_SEGMENT = 1 << 30      # bytes per arena segment (largest single plan buffer is ~0.2 GB)
+    MAX_PLANS = 48               # LRU bound on cached launch plans (their buffers alias one arena anyway)
+
     def __init__(self, cfg: UNetConfig, device="cuda", state_dict: Optional[Dict[str, torch.Tensor]] = None,
-                 text_len: int = 77, max_text_batch: int = 16):
+                 text_len: int = 77, max_text_batch: int = 32):
         self.cfg = cfg
         self.device = torch.device(device)
         self.blocks = unet_blocks(cfg)
@@ -521,8 +533,38 @@ class UNetEngine:
         self._ws = None
         self._ws_size = 0
         self._fuser_cat: Dict[Tuple, torch.Tensor] = {}
-        self._plans: Dict[Tuple, Plan] = {}
+        self._plans: "OrderedDict[Tuple, Plan]" = OrderedDict()
         self._objs = None
+        self._arena: List[torch.Tensor] = []      # uint8 segments shared by all plans (Plan._alloc)
+
+    # ---- activation arena -------------------------------------------------------------------
+    def arena_take(self, cursor, shape, dtype):
+        """Bump allocation of one plan buffer: `cursor` = [segment, byte offset] of the requesting plan.
+        Segments are only ever appended (never moved or freed while the engine lives), so buffers handed
+        out earlier — and the hipGraphs captured over them — stay valid when a larger plan arrives."""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        if nbytes > self.ARENA_SEGMENT:
+            raise RuntimeError(f"plan buffer of {nbytes} bytes exceeds the arena segment size")
+        seg, off = cursor
+        off = (off + 255) & ~255
+        if off + nbytes > self.ARENA_SEGMENT:
+            seg, off = seg + 1, 0
+        while len(self._arena) <= seg:
+            self._arena.append(torch.empty(self.ARENA_SEGMENT, device=self.device, dtype=torch.uint8))
+        t = self._arena[seg][off:off + nbytes].view(dtype).view(tuple(int(d) for d in shape))
+        return t, [seg, off + nbytes]
+
+    def arena_bytes(self) -> int:
+        return len(self._arena) * self.ARENA_SEGMENT
+
+    def poison_arena(self):
+        """Debug/test aid: overwrite every plan buffer with NaN bit patterns — a plan that relied on data
+        surviving another plan's run (or on build-time zeros) shows up as NaNs."""
+        for seg in self._arena:
+            seg.fill_(0xFF)
 
     # ---- shared scratch ---------------------------------------------------------------------
     def workspace(self, n_floats: int = 0) -> torch.Tensor:
@@ -567,7 +609,9 @@ class UNetEngine:
         """to_k / to_v of all cross-attention layers for this prompt (time-invariant: computed once per
         run instead of once per UNet call; attention_processor.py:345-346,433-434)."""
         Bt, T, Cx = ehs.shape
-        assert Bt <= self.max_text_batch and T == self.text_len
+        if Bt > self.max_text_batch or T != self.text_len:
+            raise RuntimeError(f"text batch {Bt}x{T} exceeds the engine's text K/V buffers "
+                               f"({self.max_text_batch}x{self.text_len}); chunk the jobs (LMDSampler.max_batch)")
         x = ehs.to(self.device, F16).reshape(Bt * T, Cx).contiguous()
         for b in self.blocks:
             for a in b.attns:
@@ -610,8 +654,23 @@ class UNetEngine:
              text_batch_offset=0, obj_batch_offset=0) -> Plan:
         key = (B, L, grad, fuser, tuple(stop_key) if stop_key else None, tuple(map(tuple, save_keys)),
                text_batch_offset, obj_batch_offset)
+        if B + text_batch_offset > self.max_text_batch:
+            raise RuntimeError(f"plan batch {B} (+{text_batch_offset}) exceeds max_text_batch={self.max_text_batch}")
         if key not in self._plans:
             self._plans[key] = Plan(self, B, L, grad=grad, fuser=fuser, stop_key=stop_key,
                                     save_keys=save_keys, text_batch_offset=text_batch_offset,
                                     obj_batch_offset=obj_batch_offset)
+            while len(self._plans) > self.MAX_PLANS:
+                self._plans.popitem(last=False)       # a dropped plan's graphs stay valid: the arena never moves
+        self._plans.move_to_end(key)
         return self._plans[key]
+
+    def attn_key_order(self) -> List[Tuple]:
+        """Attention keys in UNet execution order (down, mid, up)."""
+        return [a.key for b in self.blocks for a in b.attns]
+
+    def last_key(self, keys) -> Tuple:
+        """The key of `keys` that executes last — where a guidance forward may stop (pipelines.py:46 TODO),
+        whatever order the caller listed them in."""
+        order = self.attn_key_order()
+        return max((tuple(k) for k in keys), key=order.index)

@@ -69,3 +69,45 @@ def test_per_item_results_do_not_depend_on_partition():
         for i, gb in ldist.shard(layouts, r, 2):
             lay = CachedLayout.synthetic(cfg, gb, index=i)
             assert torch.equal(lay.overall_cond, single[i].overall_cond) and lay.bg_seed == single[i].bg_seed
+
+
+def test_bench_self_spawns_ranks_and_balances_the_prompt_set():
+    """`python bench.py --gpus 2` with no rendezvous in the environment must start 2 ranks itself
+    (torch.distributed.run), broadcast the weight arenas, partition the lmd_v0.1 prompt set by cost and
+    report from rank 0 — exercised on CPU (gloo) through --cpu-dryrun."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cpu-dryrun", "--workload",
+                          "lmd_v0.1", "--prompts", "40"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == r["rccl_ranks"] == 2 and r["images"] == 40
+    assert r["weight_broadcast_s"] > 0 and r["weights_identical"]
+    a, b = r["per_rank_cost"]
+    assert abs(a - b) <= 1.0                                  # cost = layouts + boxes, LPT-balanced
+
+
+def test_cost_partition_is_complete_balanced_and_deterministic():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cache = bench.load_cache()
+    sel = bench.select_prompts(cache, 100)
+    assert len(sel) == len(set(sel)) == 100
+    n_boxes = [len(cache[i]["gen_boxes"]) for i in sel]
+    assert min(n_boxes) == 0 and max(n_boxes) == 5             # all four prompt categories are present
+    costs = [n + 1 for n in n_boxes]
+    for world in (1, 2, 4, 8):
+        parts = bench.partition_by_cost(costs, world)
+        assert sorted(i for p in parts for i in p) == list(range(100))
+        loads = [sum(costs[i] for i in p) for p in parts]
+        assert max(loads) - min(loads) <= max(costs)
+        assert parts == bench.partition_by_cost(costs, world)
+    # per-image work of the default 2-box LMD+ image with all 65 iterations: SURVEY.md 8(d) "<= 359.8 TF"
+    assert abs(bench.algorithmic_tflop(2, 50, 0.4, 55, 10) - 359.8) < 0.2

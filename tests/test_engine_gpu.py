@@ -346,3 +346,86 @@ def test_layout_without_boxes(dev):
     assert both[1]["guidance_iters"] == 0 and both[0]["guidance_iters"] == alone["guidance_iters"] == 2
     assert relerr(both[0]["latents"], alone["latents"]) < 3e-2
     assert relerr(both[1]["latents"], out["latents"]) < 3e-2
+
+
+def test_plans_alias_one_arena_and_do_not_depend_on_stale_data(dev):
+    """All launch plans carve their buffers out of ONE arena (footprint = largest plan, not the sum of the
+    (batch, grad, fuser) variants).  Poisoning the arena with NaN patterns before every plan run must not
+    change a guided denoising loop: no plan may rely on build-time zeros or on another plan's leftovers."""
+    g = np.load(os.path.join(GOLD, "loops_tiny_gligen.npz"))
+    eng = engine("tiny_gligen", dev)
+    ehs = torch.from_numpy(g["ehs"])
+    gl = prepare_gligen_condition(BBOXES, torch.from_numpy(g["phrase_emb"]), dev)
+    guid = dict(bboxes=BBOXES, object_positions=OBJ_POS, loss_scale=5, loss_threshold=0.0, max_iter=[2, 1],
+                max_index_step=3, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+    kw = dict(gligen=gl, gligen_scheduled_sampling_beta=0.5, guidance=guid, frozen_steps=2,
+              frozen_mask=torch.from_numpy(g["frozen_mask"]), saved_cross_attn_keys=[OBJ_KEY, *KEYS],
+              return_cond_ca_only=True, return_token_ca_only=7)
+    sm = LMDSampler(eng, DDIMScheduler(), use_graphs=False)
+    ref = sm.denoise(torch.from_numpy(g["lat_all_in"]), ehs, 4, **kw)
+    before = eng.arena_bytes()
+    # poison before every launch sequence of every plan
+    from lgd_amd import unet as U
+    fwd0, bwd0 = U.Plan.forward, U.Plan.backward
+    try:
+        def fwd(self, latents=None):
+            keep = self.latents_in.clone() if latents is None else None
+            self.eng.poison_arena()
+            if keep is not None:
+                self.latents_in.copy_(keep)
+            return fwd0(self, latents)
+        U.Plan.forward = fwd
+        out = sm.denoise(torch.from_numpy(g["lat_all_in"]), ehs, 4, **kw)
+    finally:
+        U.Plan.forward, U.Plan.backward = fwd0, bwd0
+    torch.cuda.synchronize()
+    assert eng.arena_bytes() == before                         # same plans, no growth
+    assert torch.isfinite(out["latents_all"]).all()
+    assert torch.equal(out["latents_all"], ref["latents_all"])
+    assert torch.equal(out["saved"][("up", 1, 1, 0)], ref["saved"][("up", 1, 1, 0)])
+    # many plan variants later the arena is still the size of the largest one
+    big = max(p.arena_bytes for p in eng._plans.values())
+    assert eng.arena_bytes() <= ((big + eng.ARENA_SEGMENT - 1) // eng.ARENA_SEGMENT + 1) * eng.ARENA_SEGMENT
+
+
+def test_many_boxes_are_chunked_and_padded_to_buckets(dev):
+    """A layout with more boxes than fit one UNet call (the reference runs boxes one at a time, so any count up to
+    GLIGEN's 30 works there): the per-box stage is chunked (max_batch) and padded to bucket sizes; results of
+    a box do not depend on the chunking.  Also 3 layouts x 3 boxes (9 > 8 images)."""
+    from lgd_amd.pipeline import CachedLayout, lmd_plus_generate, lmd_plus_generate_batch
+    cfg = weights.CONFIGS["tiny_gligen"]
+    eng = engine("tiny_gligen", dev)
+    names = ["a apple", "a bear", "a cat", "a dog", "a eel", "a fox", "a goat", "a hen", "a ibis", "a jay"]
+    boxes10 = [(n, [16 + 40 * (i % 5), 30 + 200 * (i // 5), 90, 120]) for i, n in enumerate(names)]
+    lay10 = CachedLayout.synthetic(cfg, boxes10, 21)
+    kw = dict(num_inference_steps=4, height=8 * L, width=8 * L, decode=False, overall_loss_threshold=0.0,
+              overall_max_index_step=2, overall_max_iter=[1])
+    sm8 = LMDSampler(eng, DDIMScheduler(), max_batch=8)
+    sm3 = LMDSampler(eng, DDIMScheduler(), max_batch=3)
+    a = lmd_plus_generate(sm8, lay10, **kw)
+    b = lmd_plus_generate(sm3, lay10, **kw)
+    assert torch.isfinite(a["latents"]).all() and a["guidance_iters"] == 2
+    assert relerr(a["composed"], b["composed"]) < 3e-2 and relerr(a["latents"], b["latents"]) < 3e-2
+    lays = [CachedLayout.synthetic(cfg, boxes10[3 * i:3 * i + 3], 30 + i) for i in range(3)]
+    both = lmd_plus_generate_batch(sm8, lays, **kw)
+    for lay, rb in zip(lays, both):
+        rs = lmd_plus_generate(sm8, lay, **kw)
+        assert relerr(rb["latents"], rs["latents"]) < 3e-2 and rb["guidance_iters"] == rs["guidance_iters"] == 2
+    with pytest.raises(RuntimeError):
+        eng.prepare_text(torch.zeros(eng.max_text_batch + 1, 77, cfg.cross_attention_dim))
+
+
+def test_guidance_keys_in_any_order(dev):
+    """The reference accepts guidance_attn_keys in any order; the guidance forward must still run up to the
+    key that EXECUTES last (not the one listed last)."""
+    g = np.load(os.path.join(GOLD, "guidance_tiny.npz"))
+    sm = LMDSampler(engine("tiny", dev), DDIMScheduler())
+    res = []
+    for keys in (KEYS, [KEYS[3], KEYS[0], KEYS[2], KEYS[1]]):
+        guid = dict(bboxes=BBOXES, object_positions=OBJ_POS, loss_scale=5, loss_threshold=0.0, max_iter=1,
+                    max_index_step=10, guidance_attn_keys=keys, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+        tr = []
+        sm.guidance_only(torch.from_numpy(g["latents_in"]), torch.from_numpy(g["cond"]), 10, 1, guid, trace=tr)
+        res.append(tr[0])
+    assert abs(res[0]["loss"] - res[1]["loss"]) < 1e-4 * abs(res[0]["loss"])
+    assert cosine(res[0]["grad"], res[1]["grad"]) > 0.9999
