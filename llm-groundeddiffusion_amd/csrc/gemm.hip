@@ -558,6 +558,246 @@ __global__ __launch_bounds__(128 * WM) void gemm_dma_kernel(const GemmArgs ga) {
   gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off);
 }
 
+// Counted vector-memory wait (the immediate must be a literal).
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+  }
+}
+
+// Main-loop variant 3: 8 waves (WM x WN), one workgroup per CU, 256-row class tiles, THREE LDS stages.
+//   The 4-wave loop above is bound by the CU's vector-memory path (a 128x160 tile needs 58 B/clk/CU of
+//   global->LDS traffic at full MFMA rate, the path delivers ~64) and drains the DMA queue at every K tile
+//   (vmcnt(0) + barrier).  Here a 256x160 tile needs 42 B/clk/CU (256x128: 48), the DMA of K tile kt+2 is
+//   issued while tile kt is multiplied and is only waited for (counted vmcnt, own share) one full K tile
+//   later, so a DMA has a whole K tile (~2.5k cycles) of flight time and nothing in the loop ever waits for
+//   vmcnt(0); the barrier is a bare s_barrier (a __syncthreads() would drain the LDS-DMA queue).
+//   Per K tile and wave:   issue DMA(kt+2) | ds_read frags(kt, k-half 1) | MFMA k-half 0 |
+//                          vmcnt(own share of kt+2 may stay in flight), lgkmcnt(0), s_barrier |
+//                          ds_read frags(kt+1, k-half 0) | MFMA k-half 1
+//   i.e. fragment reads always run one k-half ahead of the MFMAs that consume them (two register sets).
+//   LDS image and source-side swizzle are those of gemm_dma_kernel (128-B rows, conflict-free ds_read_b128).
+//   Hazards: stage (kt+2)%3 held tile kt-1, whose last fragment reads were waited for (lgkmcnt(0)) before the
+//   barrier of iteration kt-1 by every wave; tile kt+1 is read only after the barrier of iteration kt, in
+//   front of which every wave waited for its own share of that tile's DMAs.
+template <int MI, int NI, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs ga) {
+  constexpr int NW = WM * WN;
+  constexpr int NT = 64 * NW;
+  constexpr int BM = WM * 16 * MI;
+  constexpr int BN = WN * 16 * NI;
+  constexpr int GA = BM / 8, GB = BN / 8;   // 8-row groups (one DMA wave-instruction each)
+  constexpr int A_IT = (GA + NW - 1) / NW, B_IT = (GB + NW - 1) / NW;
+  constexpr int STAGE = (BM + BN) * BK;     // halfs per stage
+  constexpr int NS = 3;
+  static_assert(NS * STAGE * 2 <= 160 * 1024, "LDS");
+
+  extern __shared__ __attribute__((aligned(1024))) half_t smem[];
+
+  const LgdGemmDesc& d = ga.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid - wm * WN;
+
+  const int n_tiles_n = (d.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = bid / n_tiles_n;
+  const int tile_n = bid - tile_m * n_tiles_n;
+  const int zz = blockIdx.z;
+  const int batch = zz / d.splits;
+  const int split = zz - batch * d.splits;
+  const int b_o = batch / d.nb_i, b_i = batch - b_o * d.nb_i;
+  const long a_off = b_o * d.a_bs_o + b_i * d.a_bs_i;
+  const long w_off = b_o * d.w_bs_o + b_i * d.w_bs_i;
+  const long c_off = b_o * d.c_bs_o + b_i * d.c_bs_i;
+  const long r_off = b_o * d.r_bs_o + b_i * d.r_bs_i;
+
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int k_beg = split * ga.k_per_split;
+  int k_end = k_beg + ga.k_per_split;
+  if (k_end > d.K) k_end = d.K;
+  const int nk = (k_end - k_beg) / BK;
+
+  const half_t* A0 = reinterpret_cast<const half_t*>(d.a0) + a_off;
+  const half_t* A1 = d.a1 ? reinterpret_cast<const half_t*>(d.a1) + a_off : nullptr;
+  const half_t* W = reinterpret_cast<const half_t*>(d.w) + w_off;
+  const half_t* zero = reinterpret_cast<const half_t*>(g_zero_line);
+
+  // ---- staging: wave w fills the 8-row groups w, w+NW, ... of A and of B; lane -> (row in group, 16-B slot).
+  // With NW = 8 the swizzle term (row>>1)&7 of row = 8*(i*NW + w) + lrow does not depend on i, so a lane
+  // fetches the same logical K segment in every group it fills (as in gemm_dma_kernel).
+  static_assert(NW % 2 == 0, "kseg must not depend on the pass index");
+  const int lrow = lane >> 3;
+  const int kseg = (lane & 7) ^ ((((wid & 1) << 2) + (lrow >> 1)) & 7);
+  const int cin = ga.cin;
+  const bool conv = d.taps == 9;
+  int n_dma = 0;  // DMA wave-instructions this wave issues per K tile
+  int a_iy0[A_IT], a_ix0[A_IT];
+  long a_row[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int grp = i * NW + wid;
+    int m = m0 + grp * 8 + lrow;
+    if (m >= d.M) m = d.M - 1;  // rows past M are computed on valid data and never stored
+    if (grp < GA) ++n_dma;
+    if (conv) {
+      int hw = d.hout * d.wout;
+      int b = m / hw;
+      int rem = m - b * hw;
+      int oy = rem / d.wout;
+      int ox = rem - oy * d.wout;
+      a_iy0[i] = oy * d.stride - 1;
+      a_ix0[i] = ox * d.stride - 1;
+      a_row[i] = (long)b * d.hin * d.win;
+    } else {
+      a_iy0[i] = 0; a_ix0[i] = 0;
+      a_row[i] = m;
+    }
+  }
+  const half_t* w_row[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int grp = i * NW + wid;
+    int n = n0 + grp * 8 + lrow;
+    if (n >= d.N) n = d.N - 1;
+    if (grp < GB) ++n_dma;
+    w_row[i] = W + (long)n * d.ldw + k_beg + kseg * 8;
+  }
+  const int k_first = k_beg + kseg * 8;
+  int tap = conv ? k_first / cin : 0;
+  int ch = k_first - tap * cin;
+
+  const half_t* a_ptr[A_IT];
+  bool a_ok[A_IT];
+  bool rederive = true;
+  auto issue_tile = [&](int stage) {
+    half_t* As = smem + stage * STAGE;
+    half_t* Bs = As + BM * BK;
+    if (rederive) {
+      int ky = 0, kx = 0;
+      if (conv) { ky = tap / 3; kx = tap - ky * 3; }
+      const bool src1 = ch >= d.c0;
+      const half_t* src = src1 ? A1 : A0;
+      const long ld = src1 ? d.lda1 : d.lda0;
+      const int cc = src1 ? ch - d.c0 : ch;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        bool ok = true;
+        long row = a_row[i];
+        if (conv) {
+          int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+          if (d.ups) {
+            ok = iy >= 0 && ix >= 0 && iy < 2 * d.hin && ix < 2 * d.win;
+            if (d.ups == 2) ok = ok && !((iy | ix) & 1);
+            iy >>= 1; ix >>= 1;
+          } else {
+            ok = iy >= 0 && ix >= 0 && iy < d.hin && ix < d.win;
+          }
+          row += (long)iy * d.win + ix;
+        }
+        a_ok[i] = ok;
+        a_ptr[i] = src + row * ld + cc;
+      }
+      rederive = false;
+    }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int grp = i * NW + wid;
+      if (grp < GA) {
+        const half_t* p = a_ok[i] ? a_ptr[i] : zero;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)(As + grp * 8 * BK), 16, 0, 0);
+      }
+      a_ptr[i] += BK;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int grp = i * NW + wid;
+      if (grp < GB)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)w_row[i], (lds_ptr_t)(Bs + grp * 8 * BK), 16, 0, 0);
+      w_row[i] += BK;
+    }
+    const int ch_prev = ch;
+    ch += BK;
+    if (ch_prev < d.c0 && ch >= d.c0) rederive = true;
+    if (ch >= cin) {
+      rederive = true;
+      do { ch -= cin; ++tap; } while (ch >= cin);
+    }
+  };
+
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fg = lane >> 4;
+  const int fsw = (frow >> 1) & 7;
+  const int a_base = (wm * 16 * MI + frow) * BK;
+  const int b_base = BM * BK + (wn * 16 * NI + frow) * BK;
+  const int slot0 = ((0 * 4 + fg) ^ fsw) * 8, slot1 = ((1 * 4 + fg) ^ fsw) * 8;
+
+  auto read_frags = [&](const half_t* st, int slot, half8_t (&af)[MI], half8_t (&bf)[NI]) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      af[mi] = *reinterpret_cast<const half8_t*>(st + a_base + mi * 16 * BK + slot);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      bf[ni] = *reinterpret_cast<const half8_t*>(st + b_base + ni * 16 * BK + slot);
+  };
+  auto mma = [&](half8_t (&af)[MI], half8_t (&bf)[NI]) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+  };
+
+  half8_t af0[MI], bf0[NI], af1[MI], bf1[NI];
+  if (nk > 0) {
+    issue_tile(0);
+    if (nk > 1) { issue_tile(1); wait_vmcnt(n_dma); } else wait_vmcnt(0);
+    __builtin_amdgcn_s_barrier();
+    read_frags(smem, slot0, af0, bf0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int s_cur = kt % NS;
+      const half_t* st = smem + s_cur * STAGE;
+      const bool more2 = kt + 2 < nk;
+      if (more2) issue_tile((kt + 2) % NS);
+      read_frags(st, slot1, af1, bf1);
+      mma(af0, bf0);
+      // tile kt+1: own DMAs landed (the ones of tile kt+2 may stay in flight); own LDS reads retired
+      if (more2) wait_vmcnt(n_dma); else wait_vmcnt(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) read_frags(smem + ((kt + 1) % NS) * STAGE, slot0, af0, bf0);
+      mma(af1, bf1);
+    }
+  }
+
+  gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off);
+}
+
 // Sums the split-K partials and applies the epilogue. One thread per 4 output channels.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs ga) {
   const LgdGemmDesc& d = ga.d;
@@ -611,6 +851,23 @@ int launch_gemm(const GemmArgs& ga, hipStream_t st, bool dma) {
   return lgd_check_launch();
 }
 
+template <int MI, int NI, int WM, int WN>
+int launch_gemm_pipe(const GemmArgs& ga, hipStream_t st) {
+  constexpr int BM = WM * 16 * MI, BN = WN * 16 * NI;
+  constexpr int SMEM = 3 * (BM + BN) * BK * 2;
+  const LgdGemmDesc& d = ga.d;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<MI, NI, WM, WN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set = true;
+  }
+  long tiles = (long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+  dim3 grid((unsigned)tiles, 1, (unsigned)(d.nb_o * d.nb_i * d.splits));
+  hipLaunchKernelGGL((gemm_pipe_kernel<MI, NI, WM, WN>), grid, dim3(64 * WM * WN), SMEM, st, ga);
+  return lgd_check_launch();
+}
+
 }  // namespace
 
 extern "C" int lgd_abi_version(void) { return LGD_ABI_VERSION; }
@@ -657,6 +914,30 @@ extern "C" int lgd_gemm_f16(const LgdGemmDesc* desc, void* stream) {
     else if (wgs(128, 128) >= 384 && d.N % 128 == 0) tile = 17;
     else if (wgs(64, 128) >= 256 && d.N % 128 == 0) tile = 19;
     else tile = 20;
+  }
+  // tile codes 33.. = 8-wave three-stage pipelined main loop (K % 64 == 0 only)
+  if (tile > 32) {
+    if (d.K % BK) return LGD_ERR_ARG;
+    int rc;
+    switch (tile) {
+      case 33: rc = geglu ? LGD_ERR_ARG : launch_gemm_pipe<4, 5, 4, 2>(ga, st); break;  // 256x160
+      case 34: rc = launch_gemm_pipe<4, 4, 4, 2>(ga, st); break;                         // 256x128
+      case 35: rc = launch_gemm_pipe<4, 2, 4, 2>(ga, st); break;                         // 256x64
+      case 37: rc = geglu ? LGD_ERR_ARG : launch_gemm_pipe<2, 5, 4, 2>(ga, st); break;  // 128x160
+      case 38: rc = launch_gemm_pipe<2, 4, 4, 2>(ga, st); break;                         // 128x128
+      default: return LGD_ERR_ARG;
+    }
+    if (rc) return rc;
+    if (d.splits > 1) {
+      int n_out = geglu ? d.N / 2 : d.N;
+      long total = (long)d.M * (n_out / 4);
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      dim3 grid(blocks, 1, d.nb_o * d.nb_i);
+      hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, st, ga);
+      rc = lgd_check_launch();
+    }
+    return rc;
   }
   // tile codes 1..7 = register-staged main loop; 16 + code = LDS-DMA main loop (17..23, and the 8-wave 25/26)
   bool dma = tile > 16;
