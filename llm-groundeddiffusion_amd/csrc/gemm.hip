@@ -24,6 +24,8 @@
 //     M = B*HW is 128..512 and the weight stream must be spread over all 256 CUs.
 #include "common.h"
 #include "../../include/lgd_hip.h"
+#include <utility>
+#include <stdlib.h>
 
 namespace {
 
@@ -558,51 +560,95 @@ __global__ __launch_bounds__(128 * WM) void gemm_dma_kernel(const GemmArgs ga) {
   gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off);
 }
 
-// Counted vector-memory wait (the immediate must be a literal).
-__device__ __forceinline__ void wait_vmcnt(int n) {
-  switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-  }
+// ---- pieces of the pipelined main loop that must not be left to the compiler's own wait insertion --------
+// LDS fragment reads and every wait are inline asm: hipcc's s_waitcnt pass is conservative across the loop
+// back edge (it emits lgkmcnt(0) behind freshly issued prefetch reads, serialising them with the MFMAs they
+// were meant to overlap) and treats a pending LDS-DMA as a hazard for every LDS read it can see.
+template <int OFF>
+__device__ __forceinline__ void lds_read128(half8_t& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int BASE, int STRIDE, int N, int... I>
+__device__ __forceinline__ void lds_read_frags(half8_t (&f)[N], unsigned addr, std::integer_sequence<int, I...>) {
+  (lds_read128<BASE + I * STRIDE>(f[I], addr), ...);
+}
+// Wait for this wave's LDS reads (and, with VM >= 0, until at most VM vector-memory operations are in flight).
+// The fragments are named read-write so that no MFMA consuming them can be scheduled above the wait.
+template <int VM, int NA, int NB>
+__device__ __forceinline__ void wait_frags(half8_t (&a)[NA], half8_t (&b)[NB]) {
+  static_assert(NA <= 8 && NB <= 10, "operand count");
+  if constexpr (VM >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+  if constexpr (NA == 4 && NB == 5)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]),
+                 "+v"(b[2]), "+v"(b[3]), "+v"(b[4]));
+  else if constexpr (NA == 4 && NB == 4)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]),
+                 "+v"(b[2]), "+v"(b[3]));
+  else if constexpr (NA == 4 && NB == 2)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]));
+  else if constexpr (NA == 2 && NB == 5)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+                 "+v"(b[4]));
+  else if constexpr (NA == 2 && NB == 4)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+  else if constexpr (NA == 2 && NB == 2)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+  else if constexpr (NA == 1 && NB == 5)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]));
+  else if constexpr (NA == 1 && NB == 4)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+  else if constexpr (NA == 1 && NB == 2)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(b[0]), "+v"(b[1]));
+  else
+    static_assert(NA == 0, "add the operand list for this tile");
 }
 
 // Main-loop variant 3: 8 waves (WM x WN), one workgroup per CU, 256-row class tiles, THREE LDS stages.
 //   The 4-wave loop above is bound by the CU's vector-memory path (a 128x160 tile needs 58 B/clk/CU of
 //   global->LDS traffic at full MFMA rate, the path delivers ~64) and drains the DMA queue at every K tile
 //   (vmcnt(0) + barrier).  Here a 256x160 tile needs 42 B/clk/CU (256x128: 48), the DMA of K tile kt+2 is
-//   issued while tile kt is multiplied and is only waited for (counted vmcnt, own share) one full K tile
-//   later, so a DMA has a whole K tile (~2.5k cycles) of flight time and nothing in the loop ever waits for
-//   vmcnt(0); the barrier is a bare s_barrier (a __syncthreads() would drain the LDS-DMA queue).
-//   Per K tile and wave:   issue DMA(kt+2) | ds_read frags(kt, k-half 1) | MFMA k-half 0 |
-//                          vmcnt(own share of kt+2 may stay in flight), lgkmcnt(0), s_barrier |
-//                          ds_read frags(kt+1, k-half 0) | MFMA k-half 1
-//   i.e. fragment reads always run one k-half ahead of the MFMAs that consume them (two register sets).
+//   issued while tile kt is multiplied and is only waited for (counted vmcnt) one full K tile later, so a
+//   DMA has a whole K tile (~2.5k cycles) of flight time and nothing in the loop ever waits for vmcnt(0);
+//   the barrier is a bare s_barrier (a __syncthreads() would drain the LDS-DMA queue).
+//   Per K tile and wave (fragment reads run one k-half ahead of the MFMAs that consume them):
+//       wait: frags(kt, half 0) landed          | read frags(kt, half 1)
+//       MFMA half 0, the T DMA instructions of tile kt+2 interleaved between MFMA groups
+//       wait: vmcnt(T) = tile kt+1 landed (own share), lgkmcnt(0)   | s_barrier
+//       read frags(kt+1, half 0)                | MFMA half 1
+//   Every wave issues the same number T of DMA instructions per tile (a 160-row B tile = 20 row groups over 8
+//   waves: two whole groups each plus one half-masked instruction), and tiles past the end of K are "loaded"
+//   from the zero line, so the loop body has no tail case and vmcnt(T) always means "tile kt+1 landed".
 //   LDS image and source-side swizzle are those of gemm_dma_kernel (128-B rows, conflict-free ds_read_b128).
 //   Hazards: stage (kt+2)%3 held tile kt-1, whose last fragment reads were waited for (lgkmcnt(0)) before the
 //   barrier of iteration kt-1 by every wave; tile kt+1 is read only after the barrier of iteration kt, in
 //   front of which every wave waited for its own share of that tile's DMAs.
-template <int MI, int NI, int WM, int WN>
+//   Requires cin % 64 == 0 and c0 % 64 == 0 (a K tile never straddles a tap or a source; true for every
+//   UNet contraction), checked by the launcher.
+// ABL (tools only; results are wrong by design): 1 = no DMA in the loop, 2 = no fragment reads in the loop,
+// 4 = no MFMA, 8 = no barrier — the cost of each ingredient by removal.
+// CM ("chunk-major"): 3x3 stride-1 single-source convolutions walk K as (channel chunk, tap) instead of the
+// weight layout's (tap, channel): the nine taps of one 64-channel chunk touch the same 6 x 66 pixel halo of
+// the input, 1/5..1/20 of the map's bytes, so the re-reads hit the XCD's L2 instead of falling out of it
+// between taps (the weight rows are simply visited in a different order; partial sums are order-free).
+template <int MI, int NI, int WM, int WN, int NS, bool CM, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs ga) {
   constexpr int NW = WM * WN;
-  constexpr int NT = 64 * NW;
+  static_assert(NW == 8, "eight waves");
   constexpr int BM = WM * 16 * MI;
   constexpr int BN = WN * 16 * NI;
-  constexpr int GA = BM / 8, GB = BN / 8;   // 8-row groups (one DMA wave-instruction each)
-  constexpr int A_IT = (GA + NW - 1) / NW, B_IT = (GB + NW - 1) / NW;
-  constexpr int STAGE = (BM + BN) * BK;     // halfs per stage
-  constexpr int NS = 3;
-  static_assert(NS * STAGE * 2 <= 160 * 1024, "LDS");
+  constexpr int GA = BM / 8, GB = BN / 8;            // 8-row groups (one DMA wave-instruction each)
+  static_assert(GA % NW == 0, "A rows");
+  static_assert(GB % NW == 0 || GB % NW == NW / 2, "B rows: whole groups per wave plus at most a half group");
+  constexpr int A_IT = GA / NW, B_FULL = GB / NW;
+  constexpr bool B_HALF = (GB % NW) != 0;
+  constexpr int B_IT = B_FULL + (B_HALF ? 1 : 0);
+  constexpr int T_DMA = A_IT + B_IT;                         // DMA instructions per wave per K tile
+  constexpr int T1 = (T_DMA + 1) / 2, T2 = T_DMA - T1;       // issued beside k-half 0 / k-half 1
+  constexpr int STAGE = (BM + BN) * BK;                      // halfs per stage
+  constexpr int STAGE_B = STAGE * 2;                         // bytes
+  static_assert(NS >= 3 && NS * STAGE_B <= 160 * 1024, "LDS");
+  constexpr int D = NS - 1;                                  // prefetch distance in K tiles
+  constexpr int NMMA = MI * NI;                              // MFMAs per k-half
 
   extern __shared__ __attribute__((aligned(1024))) half_t smem[];
 
@@ -642,105 +688,140 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
   const half_t* W = reinterpret_cast<const half_t*>(d.w) + w_off;
   const half_t* zero = reinterpret_cast<const half_t*>(g_zero_line);
 
-  // ---- staging: wave w fills the 8-row groups w, w+NW, ... of A and of B; lane -> (row in group, 16-B slot).
-  // With NW = 8 the swizzle term (row>>1)&7 of row = 8*(i*NW + w) + lrow does not depend on i, so a lane
-  // fetches the same logical K segment in every group it fills (as in gemm_dma_kernel).
-  static_assert(NW % 2 == 0, "kseg must not depend on the pass index");
+  // ---- staging: wave w fills the 8-row groups w, w+8, ... of A and of B; lane -> (row in group, 16-B slot).
+  // The swizzle term (row>>1)&7 of row = 8*(8i + w) + lrow does not depend on i, so a lane fetches the same
+  // logical K segment in every group it fills (as in gemm_dma_kernel).
   const int lrow = lane >> 3;
   const int kseg = (lane & 7) ^ ((((wid & 1) << 2) + (lrow >> 1)) & 7);
   const int cin = ga.cin;
   const bool conv = d.taps == 9;
-  int n_dma = 0;  // DMA wave-instructions this wave issues per K tile
-  int a_iy0[A_IT], a_ix0[A_IT];
-  long a_row[A_IT];
+  // K position of the next tile to issue.  Tap-major: (tap0, ch0) follow the weight layout.  Chunk-major:
+  // tile t of the split's range is (chunk = t / 9, tap = t % 9).
+  int tap0, ch0;
+  if (CM) { const int t = k_beg / BK; ch0 = (t / 9) * BK; tap0 = t - (t / 9) * 9; }
+  else { tap0 = conv ? k_beg / cin : 0; ch0 = k_beg - tap0 * cin; }
+  int kt_issue = 0;
+
+  int a_iy0[A_IT], a_ix0[A_IT];   // tap-major conv: top-left input coordinate of the 3x3 window
+  long a_row[A_IT];               // tap-major: first row of the image (conv) / row index (plain)
+  const half_t* a_cen[A_IT];      // chunk-major: pointer to the window's centre pixel, this lane's segment
+  int a_mask[A_IT];               // chunk-major: bit `tap` set = that tap's pixel lies inside the image
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const int grp = i * NW + wid;
-    int m = m0 + grp * 8 + lrow;
+    int m = m0 + (i * NW + wid) * 8 + lrow;
     if (m >= d.M) m = d.M - 1;  // rows past M are computed on valid data and never stored
-    if (grp < GA) ++n_dma;
+    a_iy0[i] = 0; a_ix0[i] = 0; a_row[i] = m; a_cen[i] = nullptr; a_mask[i] = 0;
     if (conv) {
       int hw = d.hout * d.wout;
       int b = m / hw;
       int rem = m - b * hw;
       int oy = rem / d.wout;
       int ox = rem - oy * d.wout;
-      a_iy0[i] = oy * d.stride - 1;
-      a_ix0[i] = ox * d.stride - 1;
-      a_row[i] = (long)b * d.hin * d.win;
-    } else {
-      a_iy0[i] = 0; a_ix0[i] = 0;
-      a_row[i] = m;
+      if (CM) {
+        a_cen[i] = A0 + ((long)b * d.hin * d.win + (long)oy * d.win + ox) * d.lda0 + kseg * 8;
+        int msk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+          if (iy >= 0 && ix >= 0 && iy < d.hin && ix < d.win) msk |= 1 << t;
+        }
+        a_mask[i] = msk;
+      } else {
+        a_iy0[i] = oy * d.stride - 1;
+        a_ix0[i] = ox * d.stride - 1;
+        a_row[i] = (long)b * d.hin * d.win;
+      }
     }
   }
+  // the half-masked instruction: waves 2g and 2g+1 fill rows 0-3 / 4-7 of group 8*B_FULL + g
+  const int b_grp_last = B_FULL * NW + (wid >> 1);
+  const bool b_half_on = (lane >> 5) == (wid & 1);
   const half_t* w_row[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
-    const int grp = i * NW + wid;
+    const bool last = B_HALF && i == B_FULL;
+    const int grp = last ? b_grp_last : i * NW + wid;
+    // the half group's index has its own parity, hence its own swizzle term
+    const int ks = last ? ((lane & 7) ^ ((((b_grp_last & 1) << 2) + (lrow >> 1)) & 7)) : kseg;
     int n = n0 + grp * 8 + lrow;
     if (n >= d.N) n = d.N - 1;
-    if (grp < GB) ++n_dma;
-    w_row[i] = W + (long)n * d.ldw + k_beg + kseg * 8;
+    w_row[i] = W + (long)n * d.ldw + (CM ? tap0 * cin + ch0 : k_beg) + ks * 8;
   }
-  const int k_first = k_beg + kseg * 8;
-  int tap = conv ? k_first / cin : 0;
-  int ch = k_first - tap * cin;
 
   const half_t* a_ptr[A_IT];
   bool a_ok[A_IT];
-  bool rederive = true;
-  auto issue_tile = [&](int stage) {
-    half_t* As = smem + stage * STAGE;
-    half_t* Bs = As + BM * BK;
-    if (rederive) {
-      int ky = 0, kx = 0;
-      if (conv) { ky = tap / 3; kx = tap - ky * 3; }
-      const bool src1 = ch >= d.c0;
-      const half_t* src = src1 ? A1 : A0;
-      const long ld = src1 ? d.lda1 : d.lda0;
-      const int cc = src1 ? ch - d.c0 : ch;
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) {
-        bool ok = true;
-        long row = a_row[i];
-        if (conv) {
-          int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-          if (d.ups) {
-            ok = iy >= 0 && ix >= 0 && iy < 2 * d.hin && ix < 2 * d.win;
-            if (d.ups == 2) ok = ok && !((iy | ix) & 1);
-            iy >>= 1; ix >>= 1;
-          } else {
-            ok = iy >= 0 && ix >= 0 && iy < d.hin && ix < d.win;
-          }
-          row += (long)iy * d.win + ix;
-        }
-        a_ok[i] = ok;
-        a_ptr[i] = src + row * ld + cc;
-      }
-      rederive = false;
-    }
+  // tap-major: (re)derive the A source pointers of the tile about to be issued — at tap / source changes only
+  auto derive = [&]() {
+    int ky = 0, kx = 0;
+    if (conv) { ky = tap0 / 3; kx = tap0 - ky * 3; }
+    const bool src1 = ch0 >= d.c0;
+    const half_t* src = src1 ? A1 : A0;
+    const long ld = src1 ? d.lda1 : d.lda0;
+    const int cc = (src1 ? ch0 - d.c0 : ch0) + kseg * 8;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const int grp = i * NW + wid;
-      if (grp < GA) {
-        const half_t* p = a_ok[i] ? a_ptr[i] : zero;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)(As + grp * 8 * BK), 16, 0, 0);
+      bool ok = true;
+      long row = a_row[i];
+      if (conv) {
+        int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+        if (d.ups) {
+          ok = iy >= 0 && ix >= 0 && iy < 2 * d.hin && ix < 2 * d.win;
+          if (d.ups == 2) ok = ok && !((iy | ix) & 1);
+          iy >>= 1; ix >>= 1;
+        } else {
+          ok = iy >= 0 && ix >= 0 && iy < d.hin && ix < d.win;
+        }
+        row += (long)iy * d.win + ix;
       }
-      a_ptr[i] += BK;
+      a_ok[i] = ok;
+      a_ptr[i] = src + row * ld + cc;
     }
+  };
+  // chunk-major: offset (halfs) from a window's centre pixel to the tile's tap and channel chunk (uniform)
+  long cm_off = 0;
+  auto cm_offset = [&]() {
+    const int ky = tap0 / 3, kx = tap0 - ky * 3;
+    cm_off = ((long)(ky - 1) * d.win + (kx - 1)) * d.lda0 + ch0;
+  };
+  // One DMA instruction of the tile being issued (j = 0..T_DMA-1), into stage offset `so` (halfs).
+  auto issue_one = [&](int j, int so, bool live) {
+    half_t* As = smem + so;
+    half_t* Bs = As + BM * BK;
+    if (j < A_IT) {
+      const half_t* p;
+      if (CM) p = (((a_mask[j] >> tap0) & 1) && live) ? a_cen[j] + cm_off : zero;
+      else p = (a_ok[j] && live) ? a_ptr[j] : zero;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)(As + (j * NW + wid) * 8 * BK), 16, 0, 0);
+    } else {
+      const int i = j - A_IT;
+      const half_t* p = live ? w_row[i] : zero;
+      if (B_HALF && i == B_FULL) {
+        if (b_half_on)
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)(Bs + b_grp_last * 8 * BK), 16, 0, 0);
+      } else {
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)(Bs + (i * NW + wid) * 8 * BK), 16, 0, 0);
+      }
+    }
+  };
+  // after a tile has been issued: advance the K walk and the source pointers (uniform control flow)
+  auto advance = [&]() {
+    ++kt_issue;
+    if (CM) {
+      int wstep = cin;
+      if (++tap0 == 9) { tap0 = 0; ch0 += BK; wstep = BK - 8 * cin; }
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const int grp = i * NW + wid;
-      if (grp < GB)
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)w_row[i], (lds_ptr_t)(Bs + grp * 8 * BK), 16, 0, 0);
-      w_row[i] += BK;
-    }
-    const int ch_prev = ch;
-    ch += BK;
-    if (ch_prev < d.c0 && ch >= d.c0) rederive = true;
-    if (ch >= cin) {
-      rederive = true;
-      do { ch -= cin; ++tap; } while (ch >= cin);
+      for (int i = 0; i < B_IT; ++i) w_row[i] += wstep;
+      cm_offset();
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) w_row[i] += BK;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) a_ptr[i] += BK;
+      const int prev = ch0;
+      ch0 += BK;
+      bool red = prev < d.c0 && ch0 >= d.c0;
+      if (ch0 >= cin) { ch0 -= cin; ++tap0; red = true; }
+      if (red && kt_issue < nk) derive();
     }
   };
 
@@ -753,46 +834,82 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
   const int frow = lane & 15;
   const int fg = lane >> 4;
   const int fsw = (frow >> 1) & 7;
-  const int a_base = (wm * 16 * MI + frow) * BK;
-  const int b_base = BM * BK + (wn * 16 * NI + frow) * BK;
-  const int slot0 = ((0 * 4 + fg) ^ fsw) * 8, slot1 = ((1 * 4 + fg) ^ fsw) * 8;
-
-  auto read_frags = [&](const half_t* st, int slot, half8_t (&af)[MI], half8_t (&bf)[NI]) {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-      af[mi] = *reinterpret_cast<const half8_t*>(st + a_base + mi * 16 * BK + slot);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-      bf[ni] = *reinterpret_cast<const half8_t*>(st + b_base + ni * 16 * BK + slot);
-  };
-  auto mma = [&](half8_t (&af)[MI], half8_t (&bf)[NI]) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-  };
+  // byte addresses (LDS) of this lane's fragment rows, k-half 0 / 1, relative to a stage
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const unsigned a_b0 = lds0 + ((wm * 16 * MI + frow) * BK + ((0 * 4 + fg) ^ fsw) * 8) * 2;
+  const unsigned a_b1 = lds0 + ((wm * 16 * MI + frow) * BK + ((1 * 4 + fg) ^ fsw) * 8) * 2;
+  constexpr int B_OFF = BM * BK * 2;       // bytes from the stage base to the B rows
+  const unsigned b_b0 = a_b0 - (wm * 16 * MI) * BK * 2 + B_OFF + (wn * 16 * NI) * BK * 2;
+  const unsigned b_b1 = a_b1 - (wm * 16 * MI) * BK * 2 + B_OFF + (wn * 16 * NI) * BK * 2;
+  using seqA = std::make_integer_sequence<int, MI>;
+  using seqB = std::make_integer_sequence<int, NI>;
+  constexpr int FSTR = 16 * BK * 2;        // bytes between consecutive 16-row fragments
 
   half8_t af0[MI], bf0[NI], af1[MI], bf1[NI];
+  // MFMAs g0..g1-1 of a k-half (linear index = ni*MI + mi)
+  auto mma_range = [&](half8_t (&af)[MI], half8_t (&bf)[NI], int g0, int g1) {
+#pragma unroll
+    for (int g = 0; g < NMMA; ++g)
+      if (g >= g0 && g < g1) {
+        const int ni = g / MI, mi = g % MI;
+        if constexpr (ABL & 4) {
+          asm volatile("" : "+v"(acc[ni][mi]) : "v"(bf[ni]), "v"(af[mi]));
+        } else {
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+      }
+  };
+  // `cnt` DMA instructions starting at j0, each followed by its share of the k-half's MFMAs
+  auto dma_and_mma = [&](int j0, int cnt, unsigned so_b, bool live, half8_t (&af)[MI], half8_t (&bf)[NI]) {
+#pragma unroll
+    for (int j = 0; j < T_DMA; ++j)
+      if (j < cnt) {
+        if constexpr (!(ABL & 1)) issue_one(j0 + j, (int)(so_b >> 1), live);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_range(af, bf, (NMMA * j) / cnt, (NMMA * (j + 1)) / cnt);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    if (cnt == 0) mma_range(af, bf, 0, NMMA);
+  };
+
   if (nk > 0) {
-    issue_tile(0);
-    if (nk > 1) { issue_tile(1); wait_vmcnt(n_dma); } else wait_vmcnt(0);
-    __builtin_amdgcn_s_barrier();
-    read_frags(smem, slot0, af0, bf0);
-    for (int kt = 0; kt < nk; ++kt) {
-      const int s_cur = kt % NS;
-      const half_t* st = smem + s_cur * STAGE;
-      const bool more2 = kt + 2 < nk;
-      if (more2) issue_tile((kt + 2) % NS);
-      read_frags(st, slot1, af1, bf1);
-      mma(af0, bf0);
-      // tile kt+1: own DMAs landed (the ones of tile kt+2 may stay in flight); own LDS reads retired
-      if (more2) wait_vmcnt(n_dma); else wait_vmcnt(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (kt + 1 < nk) read_frags(smem + ((kt + 1) % NS) * STAGE, slot0, af0, bf0);
-      mma(af1, bf1);
+    // ---- prologue: tiles 0..D-1 in flight, tile 0 landed, its first fragments requested
+    if (CM) cm_offset(); else derive();
+#pragma unroll
+    for (int t = 0; t < D; ++t) {
+#pragma unroll
+      for (int j = 0; j < T_DMA; ++j) issue_one(j, t * STAGE, t < nk);
+      advance();
     }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * T_DMA) : "memory");
+    __builtin_amdgcn_s_barrier();
+    lds_read_frags<0, FSTR>(af0, a_b0, seqA{});
+    lds_read_frags<0, FSTR>(bf0, b_b0, seqB{});
+    // byte offsets of the stages of tile kt, tile kt+1 and of the tile being issued (kt+D)
+    unsigned so_cur = 0, so_nxt = STAGE_B, so_iss = D * STAGE_B;
+    auto next_stage = [](unsigned x) { x += STAGE_B; return x == NS * STAGE_B ? 0u : x; };
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool live = kt + D < nk;
+      wait_frags<-1>(af0, bf0);                                  // frags(kt, half 0)
+      if constexpr (!(ABL & 2)) {
+        lds_read_frags<0, FSTR>(af1, a_b1 + so_cur, seqA{});     // frags(kt, half 1)
+        lds_read_frags<0, FSTR>(bf1, b_b1 + so_cur, seqB{});
+      }
+      dma_and_mma(0, T1, so_iss, live, af0, bf0);                // first part of tile kt+D beside k-half 0
+      // tile kt+1 landed (own share: tiles kt+2..kt+D-1 and the T1 instructions just issued may be in flight);
+      // own reads retired
+      wait_frags<(D - 2) * T_DMA + T1>(af1, bf1);
+      if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
+      if constexpr (!(ABL & 2)) {
+        lds_read_frags<0, FSTR>(af0, a_b0 + so_nxt, seqA{});     // frags(kt+1, half 0)
+        lds_read_frags<0, FSTR>(bf0, b_b0 + so_nxt, seqB{});
+      }
+      dma_and_mma(T1, T2, so_iss, live, af1, bf1);               // rest of tile kt+D beside k-half 1
+      advance();
+      so_cur = so_nxt; so_nxt = next_stage(so_nxt); so_iss = next_stage(so_iss);
+    }
+    // the reads of the (non-existent) tile nk and the zero-line DMAs behind the last real tiles
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
 
   gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off);
@@ -851,21 +968,53 @@ int launch_gemm(const GemmArgs& ga, hipStream_t st, bool dma) {
   return lgd_check_launch();
 }
 
-template <int MI, int NI, int WM, int WN>
-int launch_gemm_pipe(const GemmArgs& ga, hipStream_t st) {
+template <int MI, int NI, int WM, int WN, int NS, bool CM>
+int launch_gemm_pipe_cm(const GemmArgs& ga, hipStream_t st) {
   constexpr int BM = WM * 16 * MI, BN = WN * 16 * NI;
-  constexpr int SMEM = 3 * (BM + BN) * BK * 2;
+  constexpr int SMEM = NS * (BM + BN) * BK * 2;
   const LgdGemmDesc& d = ga.d;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<MI, NI, WM, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set = true;
   }
   long tiles = (long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
   dim3 grid((unsigned)tiles, 1, (unsigned)(d.nb_o * d.nb_i * d.splits));
-  hipLaunchKernelGGL((gemm_pipe_kernel<MI, NI, WM, WN>), grid, dim3(64 * WM * WN), SMEM, st, ga);
+#ifdef LGD_GEMM_ABLATION
+  static int abl = -1;
+  if (abl < 0) { const char* e = getenv("LGD_GEMM_ABL"); abl = e ? atoi(e) : 0; }
+  if (abl) {
+    auto go = [&](auto kern) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+      hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), SMEM, st, ga);
+    };
+    switch (abl) {
+      case 1: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, 1>); break;
+      case 2: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, 2>); break;
+      case 3: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, 3>); break;
+      case 4: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, 4>); break;
+      case 6: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, 6>); break;
+      case 8: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, 8>); break;
+      case 11: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, 11>); break;
+      default: break;
+    }
+    return lgd_check_launch();
+  }
+#endif
+  hipLaunchKernelGGL((gemm_pipe_kernel<MI, NI, WM, WN, NS, CM>), grid, dim3(64 * WM * WN), SMEM, st, ga);
   return lgd_check_launch();
+}
+
+// chunk-major K order for plain 3x3 convolutions (stride 1, no upsampling fold, one source); LGD_GEMM_NO_CM=1
+// in the environment keeps the weight layout's tap-major order (A/B timing of the two walks).
+template <int MI, int NI, int WM, int WN, int NS>
+int launch_gemm_pipe(const GemmArgs& ga, hipStream_t st) {
+  const LgdGemmDesc& d = ga.d;
+  static int no_cm = -1;
+  if (no_cm < 0) { const char* e = getenv("LGD_GEMM_NO_CM"); no_cm = (e && e[0] == '1') ? 1 : 0; }
+  const bool cm = d.taps == 9 && d.stride == 1 && d.ups == 0 && d.c1 == 0 && !no_cm;
+  return cm ? launch_gemm_pipe_cm<MI, NI, WM, WN, NS, true>(ga, st) : launch_gemm_pipe_cm<MI, NI, WM, WN, NS, false>(ga, st);
 }
 
 }  // namespace
@@ -917,14 +1066,18 @@ extern "C" int lgd_gemm_f16(const LgdGemmDesc* desc, void* stream) {
   }
   // tile codes 33.. = 8-wave three-stage pipelined main loop (K % 64 == 0 only)
   if (tile > 32) {
-    if (d.K % BK) return LGD_ERR_ARG;
+    if ((d.K % BK) || (ga.cin % BK) || (d.c0 % BK)) return LGD_ERR_ARG;
     int rc;
     switch (tile) {
-      case 33: rc = geglu ? LGD_ERR_ARG : launch_gemm_pipe<4, 5, 4, 2>(ga, st); break;  // 256x160
-      case 34: rc = launch_gemm_pipe<4, 4, 4, 2>(ga, st); break;                         // 256x128
-      case 35: rc = launch_gemm_pipe<4, 2, 4, 2>(ga, st); break;                         // 256x64
-      case 37: rc = geglu ? LGD_ERR_ARG : launch_gemm_pipe<2, 5, 4, 2>(ga, st); break;  // 128x160
-      case 38: rc = launch_gemm_pipe<2, 4, 4, 2>(ga, st); break;                         // 128x128
+      case 33: rc = geglu ? LGD_ERR_ARG : launch_gemm_pipe<4, 5, 4, 2, 3>(ga, st); break;  // 256x160, 3 stages
+      case 34: rc = launch_gemm_pipe<4, 4, 4, 2, 3>(ga, st); break;                         // 256x128, 3
+      case 35: rc = launch_gemm_pipe<4, 2, 4, 2, 4>(ga, st); break;                         // 256x64,  4
+      case 37: rc = geglu ? LGD_ERR_ARG : launch_gemm_pipe<2, 5, 4, 2, 4>(ga, st); break;  // 128x160, 4
+      case 38: rc = launch_gemm_pipe<2, 4, 4, 2, 4>(ga, st); break;                         // 128x128, 4
+      case 39: rc = launch_gemm_pipe<2, 2, 4, 2, 5>(ga, st); break;                         // 128x64,  5
+      case 40: rc = geglu ? LGD_ERR_ARG : launch_gemm_pipe<1, 5, 4, 2, 5>(ga, st); break;  // 64x160,  5
+      case 41: rc = launch_gemm_pipe<1, 4, 4, 2, 5>(ga, st); break;                         // 64x128,  5
+      case 42: rc = launch_gemm_pipe<1, 2, 4, 2, 6>(ga, st); break;                         // 64x64,   6
       default: return LGD_ERR_ARG;
     }
     if (rc) return rc;

@@ -96,7 +96,12 @@ def gemm_desc(a0, w, c, M, N, K, *, a1=None, lda0=None, lda1=0, c0=None, c1=0, t
 
 _TILE_DIMS = {1: (4, 4), 2: (4, 2), 3: (2, 4), 4: (2, 2), 5: (1, 4), 6: (4, 5), 7: (2, 5)}
 TILE_NAMES = {t: f"gemm_kernel<{mi},{ni}> {32 * mi}x{32 * ni}" for t, (mi, ni) in _TILE_DIMS.items()}
-TILE_NAMES.update({16 + t: f"gemm_dma_kernel<{mi},{ni}> {32 * mi}x{32 * ni}" for t, (mi, ni) in _TILE_DIMS.items()})
+TILE_NAMES.update({16 + t: f"gemm_dma_kernel<{mi},{ni},2> {32 * mi}x{32 * ni}" for t, (mi, ni) in _TILE_DIMS.items()})
+TILE_NAMES.update({25: "gemm_dma_kernel<4,10,4> 256x320", 26: "gemm_dma_kernel<4,4,4> 256x128"})
+# 8-wave pipelined main loop: code -> (MI, NI, stages); tile = 64*MI x 32*NI
+_PIPE_DIMS = {33: (4, 5, 3), 34: (4, 4, 3), 35: (4, 2, 4), 37: (2, 5, 4), 38: (2, 4, 4), 39: (2, 2, 5), 40: (1, 5, 5),
+              41: (1, 4, 5), 42: (1, 2, 6)}
+TILE_NAMES.update({t: f"gemm_pipe_kernel<{mi},{ni},4,2,{ns}> {64 * mi}x{32 * ni}" for t, (mi, ni, ns) in _PIPE_DIMS.items()})
 
 
 def choose_tile(M, N, batches=1, geglu=False, K=64):

@@ -9,7 +9,8 @@ from lgd_amd import ops
 
 TABLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llm-groundeddiffusion_amd",
                      "tuning_gfx950.json")
-LEGAL = set(range(1, 11)) | {16 + t for t in range(1, 11)} - {8, 24}
+PIPE = {33: 160, 34: 128, 35: 64, 37: 160, 38: 128, 39: 64, 40: 160, 41: 128, 42: 64}      # code -> tile width
+LEGAL = (set(range(1, 11)) | {16 + t for t in range(1, 11)} | set(PIPE)) - {8, 24}
 TILE_BN = {1: 128, 2: 64, 3: 128, 4: 64, 5: 128, 6: 160, 7: 160, 9: 320, 10: 128}
 
 
@@ -24,8 +25,10 @@ def test_table_entries_are_legal():
         assert e["tile"] in LEGAL, (key, e)
         assert K == taps * (c0 + c1)
         assert 1 <= e["splits"] <= 16 and (e["splits"] == 1 or K // 64 >= e["splits"])
-        if geglu:
-            assert (e["tile"] & 15) not in (6, 7, 9), (key, e)            # 160/320-wide tiles cannot pair value|gate rows
+        if geglu:                                                          # 160/320-wide tiles cannot pair value|gate rows
+            assert PIPE.get(e["tile"], 0) != 160 and (e["tile"] in PIPE or (e["tile"] & 15) not in (6, 7, 9)), (key, e)
+        if e["tile"] in PIPE:
+            assert K % 64 == 0 and (c0 + c1) % 64 == 0 and c0 % 64 == 0, (key, e)
         assert e["us"] > 0 and e["tflops"] > 0
 
 

@@ -1,6 +1,7 @@
 """GPU-box tool: enumerates every GEMM / implicit-conv launch shape of the engine's plans (SD1.4+GLIGEN,
-64x64 latents: main B=2 fuser on/off, guidance B=1 fwd+bwd), times each (tile, split-K) candidate with
-HIP events and writes the winners to llm-groundeddiffusion_amd/tuning_gfx950.json.
+64x64 latents: main passes of 1/2/4/8 images with the fuser on/off, guidance passes of 1/2/4 images fwd+bwd),
+VERIFIES each (tile, split-K) candidate against a trusted tile's output, times the ones that pass with HIP events
+and writes the winners to llm-groundeddiffusion_amd/tuning_gfx950.json.
 
     python tools/tune_gemm.py [config] [out.json]
 """
@@ -23,7 +24,7 @@ L = cfg.sample_size if cfg_name.startswith("tiny") else 64
 
 shapes = {}
 orig = ops.gemm_launch
-def rec(d):
+def rec(d, tag=None):
     key = ops.shape_key(d)
     shapes.setdefault(key, dict(M=d.M, N=d.N, K=d.K, taps=d.taps, c0=d.c0, c1=d.c1, hin=d.hin, win=d.win,
                                 hout=d.hout, wout=d.wout, stride=d.stride, ups=d.ups, epi=d.epi,
@@ -33,7 +34,7 @@ def rec(d):
 ops.gemm_launch = rec
 sm = LMDSampler(eng, use_graphs=False)
 eng.prepare_timesteps([500]); eng.set_step(0)
-batches = [int(x) for x in os.environ.get("LGD_TUNE_BATCHES", "1,4,8").split(",")]
+batches = [int(x) for x in os.environ.get("LGD_TUNE_BATCHES", "1,2,4,8").split(",")]
 for kind, fz, nb, fn in sm.profile_passes(L, 50, cfg.use_gated_attention, main_batches=batches,
                                           guide_batches=[b for b in batches if b <= 4]):
     fn()
@@ -41,27 +42,62 @@ torch.cuda.synchronize()
 ops.gemm_launch = orig
 print(f"{len(shapes)} distinct GEMM shapes")
 
-def bench(sh, tile, splits, reps=8):
+TILE_DIMS = {17: (128, 128), 18: (128, 64), 19: (64, 128), 20: (64, 64), 21: (32, 128), 22: (128, 160), 23: (64, 160),
+             33: (256, 160), 34: (256, 128), 35: (256, 64), 37: (128, 160), 38: (128, 128)}
+NO_GEGLU = {22, 23, 33, 37}                      # odd fragment counts cannot pair value | gate column blocks
+VERIFY_TOL = 2e-3                                # fp16 outputs, different summation orders
+rejected = []
+
+
+def make_problem(sh):
     M, N, K = sh["M"], sh["N"], sh["K"]
     c0, c1, taps = sh["c0"], sh["c1"], sh["taps"]
     rows_in = M if taps == 1 else max(1, (M // max(sh["hout"] * sh["wout"], 1))) * sh["hin"] * sh["win"]
-    a0 = torch.randn(rows_in, c0, device=dev).half()
-    a1 = torch.randn(rows_in, c1, device=dev).half() if c1 else None
-    w = (torch.randn(N, K, device=dev) * K ** -0.5).half()
+    g = torch.Generator(device="cpu").manual_seed(M * 31 + N * 7 + K)
+    a0 = torch.randn(rows_in, c0, generator=g).to(dev).half()
+    a1 = torch.randn(rows_in, c1, generator=g).to(dev).half() if c1 else None
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev).half()
     geglu = bool(sh["epi"] & 1)
     n_out = N // 2 if geglu else N
-    c = torch.empty(M, n_out, device=dev, dtype=torch.float16)
-    bias = torch.zeros(N, device=dev) if sh["has_bias"] else None
-    res = torch.zeros(M, n_out, device=dev, dtype=torch.float16) if sh["has_res"] else None
+    bias = torch.randn(N, generator=g).to(dev) if sh["has_bias"] else None
+    res = torch.randn(M, n_out, generator=g).to(dev).half() if sh["has_res"] else None
+    return dict(a0=a0, a1=a1, w=w, bias=bias, res=res, n_out=n_out)
+
+
+def make_desc(sh, pb, c, tile, splits):
+    M, N, K = sh["M"], sh["N"], sh["K"]
     ws = torch.empty(splits * M * N, device=dev) if splits > 1 else None
-    d = ops.gemm_desc(a0, w, c, M, N, K, a1=a1, c0=c0, c1=c1, lda0=c0, lda1=c1, taps=taps, hin=sh["hin"],
-                      win=sh["win"], hout=sh["hout"], wout=sh["wout"], stride=sh["stride"], ups=sh["ups"],
-                      bias=bias, res=res, ldr=n_out, epi=sh["epi"] & 1, ldc=n_out, splits=splits, ws=ws, tile=tile)
+    d = ops.gemm_desc(pb["a0"], pb["w"], c, M, N, K, a1=pb["a1"], c0=sh["c0"], c1=sh["c1"], lda0=sh["c0"],
+                      lda1=sh["c1"], taps=sh["taps"], hin=sh["hin"], win=sh["win"], hout=sh["hout"], wout=sh["wout"],
+                      stride=sh["stride"], ups=sh["ups"], bias=pb["bias"], res=pb["res"], ldr=pb["n_out"],
+                      epi=sh["epi"] & 1, ldc=pb["n_out"], splits=splits, ws=ws, tile=tile)
+    d._keep = ws
+    return d
+
+
+def reference(sh, pb):
+    """Trusted output for this problem: the register-staged 64x128 main loop without split-K (tile code 3), which
+    tests/test_ops_gpu.py checks against fp32 torch for every gather / epilogue variant."""
+    c = torch.empty(sh["M"], pb["n_out"], device=dev, dtype=torch.float16)
+    orig(make_desc(sh, pb, c, 3, 1))
+    torch.cuda.synchronize()
+    return c.float()
+
+
+def bench(sh, pb, ref, tile, splits, reps=8):
+    """Launches a candidate, VERIFIES its output against the trusted reference, then times it (us) —
+    a candidate that computes something else is never recorded."""
+    c = torch.zeros(sh["M"], pb["n_out"], device=dev, dtype=torch.float16)
+    d = make_desc(sh, pb, c, tile, splits)
     try:
         orig(d)
     except RuntimeError:
         return None
     torch.cuda.synchronize()
+    err = float((c.float() - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+    if not (err < VERIFY_TOL):
+        rejected.append((ops.shape_key(d), tile, splits, err))
+        return None
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -77,12 +113,13 @@ for key, sh in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"
         continue
     M, N, K = sh["M"], sh["N"], sh["K"]
     geglu = bool(sh["epi"] & 1)
+    pipe_ok = K % 64 == 0 and (sh["c0"] + sh["c1"]) % 64 == 0 and sh["c0"] % 64 == 0
     cands = []
-    for tile in (17, 18, 19, 20, 21, 22, 23):   # LDS-DMA main loop (falls back to register staging if K % 64)
-        if geglu and tile in (22, 23):
+    for tile, (bm, bn) in TILE_DIMS.items():
+        if geglu and tile in NO_GEGLU:
             continue
-        bm, bn = {17: (128, 128), 18: (128, 64), 19: (64, 128), 20: (64, 64), 21: (32, 128), 22: (128, 160),
-                  23: (64, 160)}[tile]
+        if tile > 32 and (not pipe_ok or M < bm):
+            continue
         wgs = -(-M // bm) * -(-N // bn)
         for sp in (1, 2, 3, 4, 6, 8, 12, 16):
             if sp > 1 and (K // 64 < 4 * sp or wgs * sp > 2048 or sp * M * N > (1 << 26)):
@@ -90,11 +127,13 @@ for key, sh in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"
             if wgs * sp < 48 and sp < 16 and K // 64 >= 8 * sp:
                 continue   # hopelessly under-filled, a larger split exists
             cands.append((tile, sp))
+    pb = make_problem(sh)
+    ref = reference(sh, pb)
     best = None
     from lgd_amd.unet import choose_splits
-    base = bench(sh, ops.choose_tile(M, N, choose_splits(M, N, K), geglu, K), choose_splits(M, N, K)) or 0.0
+    base = bench(sh, pb, ref, ops.choose_tile(M, N, choose_splits(M, N, K), geglu, K), choose_splits(M, N, K)) or 0.0
     for tile, sp in cands:
-        t = bench(sh, tile, sp)
+        t = bench(sh, pb, ref, tile, sp)
         if t is not None and (best is None or t < best[0]):
             best = (t, tile, sp)
     fl = 2.0 * M * N * K
@@ -102,7 +141,9 @@ for key, sh in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"
                       base_us=round(base, 2), count=sh["count"])
     tot_old += base * sh["count"]; tot_new += best[0] * sh["count"]
     print(f"{key:60s} n={sh['count']:3d} base {base:7.1f}us -> tile {best[1]} split {best[2]:2d} {best[0]:7.1f}us "
-          f"{fl / best[0] / 1e6:6.1f} TF/s")
+          f"{fl / best[0] / 1e6:6.1f} TF/s", flush=True)
 print(f"sum over passes: {tot_old/1e3:.2f} ms -> {tot_new/1e3:.2f} ms")
+for r in rejected:
+    print("REJECTED (wrong output):", r)
 json.dump(table, open(out_path, "w"), indent=0, sort_keys=True)
 print("wrote", out_path)
