@@ -39,6 +39,7 @@ HBM_PEAK = 8.0e12
 # analytic 2*MAC TFLOP of one UNet call (sd14_gligen, 64x64 latents)
 TF_MAIN_ON, TF_MAIN_OFF = 2.2736, 1.6065            # CFG forward B=2, GLIGEN fuser on / off
 TF_GUIDE_ON, TF_GUIDE_OFF = 0.5872 + 0.6885, 0.4086 + 0.4585   # guidance fwd (to up.1.2) + dgrad to the latents
+TF_SD21_MAIN, TF_SD21_GUIDE = 4.2982, 1.0579 + 1.311           # SD2.1 at 96x96 latents (BASELINE config 3)
 
 
 def load_cache():
@@ -69,7 +70,7 @@ def select_prompts(rows, n):
     return [(i * len(rows)) // n for i in range(n)]
 
 
-def cpu_baseline(cfg, n_boxes, n_steps, beta, iters_on, iters_off):
+def cpu_baseline(cfg, generations, n_steps, beta, iters_on, iters_off):
     """The CPU oracle (oracle/restate.py: fp32 restatement of the reference path, pinned against the
     reference's own code) timed on this box's host cores on a bounded sample (~20-30 s): one CFG UNet call with
     the GLIGEN fuser on, one with it off, one guidance iteration (fwd+bwd); extrapolated to a full LMD+ image
@@ -112,11 +113,11 @@ def cpu_baseline(cfg, n_boxes, n_steps, beta, iters_on, iters_off):
                                            masks=gl["masks"][:1]) if gl else None)
     t_g = time.time() - t0
     n_on = int(beta * n_steps) if gl is not None else 0
-    per_image = (n_boxes + 1) * (n_on * t_on + (n_steps - n_on) * t_off) + (iters_on + iters_off) * t_g
+    per_image = generations * (n_on * t_on + (n_steps - n_on) * t_off) + (iters_on + iters_off) * t_g
     return dict(value=1.0 / per_image, unit="images/s", cores=cores, kind="port",
                 sample=(f"oracle/restate.py fp32 on {cores} host threads, measured: 1 CFG UNet call (B=2) fuser on "
                         f"{t_on:.2f}s, fuser off {t_off:.2f}s, 1 guidance iteration (fwd+bwd, early exit, fuser on) "
-                        f"{t_g:.2f}s; extrapolated to one {n_boxes:.2f}-box LMD+ image = (N+1)({n_on} on + "
+                        f"{t_g:.2f}s; extrapolated to one image = {generations:.2f} generation(s) x ({n_on} on + "
                         f"{n_steps - n_on} off) UNet calls + {iters_on + iters_off:.1f} guidance iterations (VAE excluded)"))
 
 
@@ -142,10 +143,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="batch4", choices=["batch4", "lmd_v0.1"])
+    ap.add_argument("--workload", default="batch4", choices=["batch4", "lmd_v0.1", "backward_guidance"])
     ap.add_argument("--layouts", type=int, default=4, help="batch4: cached layouts per rank per step")
     ap.add_argument("--prompts", type=int, default=100, help="lmd_v0.1: prompts of the cache (whole job)")
-    ap.add_argument("--config", default="sd14_gligen")
+    ap.add_argument("--config", default=None, help="default: sd14_gligen (sd21 for --workload backward_guidance)")
     ap.add_argument("--num-inference-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
@@ -156,6 +157,8 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn(args.gpus))
+    if args.config is None:
+        args.config = "sd21" if args.workload == "backward_guidance" else "sd14_gligen"
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -173,7 +176,7 @@ def main():
     beta = 0.4                                                      # lmd_plus.py:208-209
 
     # ---- this rank's share of the work (global prompt index preserved: seeds derive from it) -----------------
-    if args.workload == "batch4":
+    if args.workload in ("batch4", "backward_guidance"):
         pool = [i for i, r in enumerate(cache) if len(r["gen_boxes"]) == 2]
         mine = [pool[(rank * args.layouts + i) % len(pool)] for i in range(args.layouts)]
         seeds = [rank * args.layouts + i for i in range(args.layouts)]
@@ -210,7 +213,7 @@ def main():
         return
 
     from lgd_amd import ops
-    from lgd_amd.pipeline import lmd_plus_generate_batch
+    from lgd_amd.pipeline import backward_guidance_generate_batch, lmd_plus_generate_batch
     from lgd_amd.sampler import LMDSampler
     from lgd_amd.scheduler import DDIMScheduler
     from lgd_amd.unet import UNetEngine
@@ -225,8 +228,15 @@ def main():
     vae = None if args.no_decode else make_hip_vae(dev)
     sm = LMDSampler(eng, DDIMScheduler(prediction_type=cfg.prediction_type), vae=vae)
 
+    side = 8 * cfg.sample_size
+
     def one_step():
-        return lmd_plus_generate_batch(sm, lays, num_inference_steps=T, decode=not args.no_decode) if lays else []
+        if not lays:
+            return []
+        if args.workload == "backward_guidance":       # generation/backward_guidance.py:46-49 defaults
+            return backward_guidance_generate_batch(sm, lays, num_inference_steps=T, height=side, width=side,
+                                                    decode=not args.no_decode)
+        return lmd_plus_generate_batch(sm, lays, num_inference_steps=T, decode=not args.no_decode)
 
     for _ in range(args.warmup):
         one_step()
@@ -315,16 +325,24 @@ def main():
                             all_kernels={k: dict(ms_per_image=round(v["ms"], 1), launches_per_image=round(v["n"]),
                                                  tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1))
                                          for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])})
-    tf = algorithmic_tflop(mean_boxes, T, beta, iters_on, iters_off) if args.config == "sd14_gligen" else None
-    what = (f"{args.layouts} cached 2-box layouts/GPU/step" if args.workload == "batch4" else
+    tf = None
+    if args.config == "sd14_gligen" and args.workload != "backward_guidance":
+        tf = algorithmic_tflop(mean_boxes, T, beta, iters_on, iters_off)
+    elif args.config == "sd21" and args.workload == "backward_guidance":
+        tf = T * TF_SD21_MAIN + (iters_on + iters_off) * TF_SD21_GUIDE
+    what = (f"{args.layouts} cached 2-box layouts/GPU/step" if args.workload != "lmd_v0.1" else
             f"{n_total} layouts of the lmd_v0.1 cache (0-5 boxes, mean {mean_boxes:.2f}) cost-balanced over {world} rank(s)")
-    res = dict(metric="images/sec (50-step SD1.5 512^2, LMD+ guidance)", value=round(n_images / dt, 4),
+    method = {"backward_guidance": "layout-guidance baseline (generation/backward_guidance.py), "}.get(args.workload, "LMD+ stage 2, ")
+    arch = {"sd14_gligen": "SD1.4+GLIGEN architecture", "sd21": "SD2.1-768 architecture, v-prediction"}.get(args.config, args.config)
+    metric = ("images/sec (50-step SD1.5 512^2, LMD+ guidance)" if args.workload != "backward_guidance" else
+              f"images/sec (50-step SD2.1 {side}^2, backward guidance)")
+    res = dict(metric=metric, value=round(n_images / dt, 4),
                unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=round(dt * 1e3 / args.steps, 1), higher_is_better=True,
                scaling="weak" if args.workload == "batch4" else "strong",
                vs_baseline=None, dtype="fp16", data="synthetic",
-               config=dict(workload=f"LMD+ stage 2, {what} (lmd_v0.1 cache), {T} DDIM steps, 512x512, {args.config} "
-                                    f"(SD1.4+GLIGEN architecture, seeded random weights), VAE decodes "
+               config=dict(workload=f"{method}{what} (lmd_v0.1 cache), {T} DDIM steps, {side}x{side}, {args.config} "
+                                    f"({arch}, seeded random weights), VAE decodes "
                                     f"{'excluded' if args.no_decode else 'included'}",
                            layouts_per_gpu=(args.layouts if args.workload == "batch4" else round(n_total / world, 2)),
                            num_inference_steps=T, parallelism=f"dp{world}", rccl_ranks=world,
@@ -338,7 +356,8 @@ def main():
         res["config"]["whole_path_frac_of_mfma_peak"] = round(tf * 1e12 * (n_images / dt) / world / MFMA_PEAK_F16, 4)
     if world == 1 and not args.no_cpu_baseline:
         try:
-            res["cpu_baseline"] = cpu_baseline(cfg, mean_boxes, T, beta, iters_on, iters_off)
+            gens = 1.0 if args.workload == "backward_guidance" else mean_boxes + 1
+            res["cpu_baseline"] = cpu_baseline(cfg, gens, T, beta, iters_on, iters_off)
         except Exception as e:  # the baseline is reported, never gating
             res["cpu_baseline"] = dict(value=None, unit="images/s", cores=os.cpu_count(), kind="port",
                                        sample=f"failed: {e}")

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LGD_ABI_VERSION 1
+#define LGD_ABI_VERSION 2
 int lgd_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -204,7 +204,10 @@ int lgd_select_row_f32(const float* table, const int32_t* idx, float* out, int n
  * all (key, object, token, head) items: utils/guidance.py:91-148 (max-based fg/bg top-k box loss),
  * :150-242 (reference-attention L1 transfer), :244-286 (compute_ca_lossv3), times loss_scale
  * (pipelines.py:48).
- *   items: int32 [n_items][8] = {map_id, kind(0 topk, 1 ref), token, mask_id, k_fg, k_bg, ref_id, image}
+ *   items: int32 [n_items][8] = {map_id, kind(0 topk, 1 ref), token, mask_id, k_fg, k_bg, ref_id, image},
+ *          sorted so that the items of one (map, image, token) column are adjacent;
+ *   groups: int32 [n_groups][2] = {first item, item count} of each column — one workgroup per (group, head)
+ *          sums the column's map gradients in a fixed order and stores them once (no atomics)
  *   coefs: fp32  [n_items][4] = {fg_coef, bg_coef, ref_coef, 0} (all normalisations folded in)
  *   maps:  device array of n_maps pointers to fp32 [n_samples][H][HW][T]; gmaps likewise (pre-zeroed)
  *          or NULL; loss: fp32 [n_samples] (one value per image of the batch)
@@ -217,8 +220,9 @@ int lgd_select_row_f32(const float* table, const int32_t* idx, float* out, int n
  * ------------------------------------------------------------------------------------------- */
 int lgd_ca_energy_f32(const float* const* maps, float* const* gmaps, const int32_t* map_hw,
                       const int32_t* items, const float* coefs, const float* masks, const float* refs,
-                      int64_t refs_step_stride, const int32_t* dyn, int n_items, int n_samples, int H,
-                      int T, int max_hw, float grad_scale, float* partial, float* loss, void* stream);
+                      int64_t refs_step_stride, const int32_t* dyn, const int32_t* groups, int n_groups,
+                      int n_items, int n_samples, int H, int T, int max_hw, float grad_scale, float* partial,
+                      float* loss, void* stream);
 
 #ifdef __cplusplus
 }

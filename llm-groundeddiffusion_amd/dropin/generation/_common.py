@@ -12,32 +12,41 @@ DEFAULT_SO_NEGATIVE_PROMPT = "artifacts, blurry, smooth texture, bad quality, di
 DEFAULT_OVERALL_NEGATIVE_PROMPT = "artifacts, blurry, smooth texture, bad quality, distortions, unrealistic, distorted image, bad proportions, duplicate"
 
 
-def convert_spec(spec, height, width, include_counts=True, verbose=False):
-    """utils/parse.py:311-367.  Uses the reference's own parser (inflect pluralisation) when it is
-    importable through `utils.__path__`; otherwise a minimal pluraliser (only the overall prompt TEXT
-    differs — boxes, grouping and ordering are identical)."""
+def _pluraliser():
+    """The reference pluralises repeated object names with the third-party `inflect` package
+    (utils/parse.py:7,11,343-346).  It is only needed for specs that repeat a name; without it such a spec is an
+    error here rather than a silently different overall prompt (different text -> different tokens)."""
     try:
-        from utils import parse
-        return parse.convert_spec(spec, height, width, include_counts=include_counts, verbose=verbose)
-    except Exception:
-        pass
-    prompt, gen_boxes, bg_prompt = spec['prompt'], spec['gen_boxes'], spec['bg_prompt']
-    gen_boxes = sorted(gen_boxes, key=lambda gb: gb[0])
-    gen_boxes = [(name, convert_box(box, height=height, width=width)) for name, box in gen_boxes]
+        import inflect
+    except ImportError as e:
+        raise RuntimeError("this spec repeats an object name; the overall prompt then needs the `inflect` package "
+                           "(as the reference does) to pluralise it") from e
+    return inflect.engine()
+
+
+def convert_spec(spec, height, width, include_counts=True, verbose=False):
+    """Spec -> (per-box (prompt, phrase, word, box) list, overall prompt, [(phrase, word, boxes)]) with the
+    conventions of utils/parse.py:311-367: boxes sorted by object name (so that the per-box order equals the
+    flattened overall order), one overall phrase per distinct name, repeated names counted and pluralised."""
+    prompt, bg_prompt = spec['prompt'], spec['bg_prompt']
+    named = sorted(((name, convert_box(box, height=height, width=width)) for name, box in spec['gen_boxes']),
+                   key=lambda nb: nb[0])
     so = [((f"{bg_prompt} with {name}" if bg_prompt else f"{name}"), name, name.split(" ")[-1], box)
-          for name, box in gen_boxes]
-    names = [n for n, _ in gen_boxes]
-    uniq, counts = np.unique(names, return_counts=True)
+          for name, box in named]
     overall = []
-    for u, c in zip(uniq, counts):
-        bboxes = [box for name, box in gen_boxes if name == u]
-        phrase = u
-        if c > 1:
-            base = u.replace("an ", "").replace("a ", "")
-            phrase = (f"{c} " if include_counts else "") + base + "s"
-        overall.append((phrase, phrase.split(' ')[-1], bboxes))
-    objects_str = ", ".join(p for p, _, _ in overall)
-    overall_prompt = (f"{bg_prompt} with {objects_str}" if bg_prompt else objects_str) if objects_str else bg_prompt
+    for name in sorted({n for n, _ in named}):                           # np.unique order
+        boxes = [box for n, box in named if n == name]
+        phrase = name
+        if len(boxes) > 1:
+            p = _pluraliser()
+            phrase = p.plural_noun(name.replace("an ", "").replace("a ", ""))
+            if include_counts:
+                phrase = p.number_to_words(len(boxes)) + " " + phrase
+        overall.append((phrase, phrase.split(' ')[-1], boxes))
+    listed = ", ".join(ph for ph, _, _ in overall)
+    overall_prompt = ((f"{bg_prompt} with {listed}" if bg_prompt else listed) if listed else bg_prompt)
+    if verbose:
+        print("so_prompt_phrase_word_box_list:", so, "overall_prompt:", overall_prompt)
     return so, overall_prompt, overall
 
 

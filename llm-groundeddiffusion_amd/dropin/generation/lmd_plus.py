@@ -22,16 +22,14 @@ def run(spec, bg_seed=1, overall_prompt_override="", fg_seed_start=20, frozen_st
         use_autocast=True, verbose=False):
     """Argument names and defaults of generation/lmd_plus.py:193-228.  `use_autocast` is accepted for
     compatibility: the HIP path always computes fp16 with fp32 accumulation."""
-    if max_index_step != 0:
-        raise NotImplementedError("per-box attention guidance in LMD+ (max_index_step>0) is disabled in the reference "
-                                  "by default and not wired on the HIP path")
     sm = models.model_dict.sampler
     lay = build_layout(spec, bg_seed, fg_seed_start, so_negative_prompt, overall_negative_prompt, height, width,
                        overall_prompt_override, verbose)
     print("Key generation settings:", spec, bg_seed, fg_seed_start, frozen_step_ratio,
           so_gligen_scheduled_sampling_beta, overall_gligen_scheduled_sampling_beta, overall_max_index_step)
     out = lmd_plus_generate(sm, lay, num_inference_steps=num_inference_steps, frozen_step_ratio=frozen_step_ratio,
-                            guidance_scale=guidance_scale,
+                            guidance_scale=guidance_scale, loss_scale=loss_scale, loss_threshold=loss_threshold,
+                            max_iter=max_iter, max_index_step=max_index_step,
                             so_gligen_scheduled_sampling_beta=so_gligen_scheduled_sampling_beta,
                             overall_gligen_scheduled_sampling_beta=overall_gligen_scheduled_sampling_beta,
                             overall_loss_scale=overall_loss_scale, overall_loss_threshold=overall_loss_threshold,

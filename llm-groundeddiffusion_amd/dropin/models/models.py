@@ -1,5 +1,7 @@
 """models/models.py of the reference: process-global model handles (`sd_key`, `sd_version`,
-`model_dict`), prompt encoding and the loader.  `model_dict.unet` is the HIP engine wrapped in the
+`model_dict`), prompt encoding and the loader.  `encode_prompts` / `process_input_embeddings` are boundary glue
+whose behaviour the callers prescribe (tokenise, pad to 77, encode uncond + cond, concatenate): they follow
+models/models.py:63-109 closely by necessity.  `model_dict.unet` is the HIP engine wrapped in the
 reference's UNet2DConditionModel call surface."""
 import torch
 
@@ -23,11 +25,21 @@ class _EasyDict(dict):
 
 
 def build_model_dict(cfg, state_dict, vae=None, tokenizer=None, text_encoder=None, device="cuda",
-                     dtype=torch.float16):
-    """model_dict contract of models/models.py:55: vae, tokenizer, text_encoder, unet, scheduler, dtype."""
+                     dtype=torch.float16, scheduler_config=None):
+    """model_dict contract of models/models.py:55: vae, tokenizer, text_encoder, unet, scheduler, dtype.
+    scheduler_config: the checkpoint's own scheduler_config.json fields (models/models.py:49 reads them through
+    DDIMScheduler.from_pretrained); only what the DDIM eta=0 path uses is honoured, anything else must match."""
     eng = UNetEngine(cfg, device, state_dict)
     unet = UNet2DConditionModel(eng)
-    sched = DDIMScheduler(prediction_type=cfg.prediction_type)
+    sc = dict(scheduler_config or {})
+    for k, want in (("beta_schedule", "scaled_linear"), ("clip_sample", False), ("set_alpha_to_one", False)):
+        if k in sc and sc[k] != want:
+            raise RuntimeError(f"scheduler_config.{k}={sc[k]!r} is not supported on the HIP path (expects {want!r})")
+    if "prediction_type" in sc and sc["prediction_type"] != cfg.prediction_type:
+        raise RuntimeError("scheduler prediction_type disagrees with the UNet config")
+    sched = DDIMScheduler(num_train_timesteps=sc.get("num_train_timesteps", 1000),
+                          beta_start=sc.get("beta_start", 0.00085), beta_end=sc.get("beta_end", 0.012),
+                          steps_offset=sc.get("steps_offset", 1), prediction_type=cfg.prediction_type)
     md = _EasyDict(vae=vae, tokenizer=tokenizer, text_encoder=text_encoder, unet=unet, scheduler=sched, dtype=dtype)
     md["sampler"] = LMDSampler(eng, sched, vae=vae)
     return md
@@ -46,7 +58,7 @@ def load_sd(key="runwayml/stable-diffusion-v1-5", use_fp16=False, load_inverse_s
     """models/models.py:16-62.  Needs the Hugging Face checkpoint (diffusers + network/cache); the UNet
     state dict is repacked into the HIP engine's arenas, CLIP / VAE stay Hugging Face modules."""
     try:
-        from diffusers import AutoencoderKL, UNet2DConditionModel as HFUNet
+        from diffusers import AutoencoderKL, DDIMScheduler as HFDDIM, UNet2DConditionModel as HFUNet
         from transformers import CLIPTextModel, CLIPTokenizer
     except ImportError as e:
         raise RuntimeError("load_sd needs `diffusers` and HF checkpoints; use load_synthetic() offline") from e
@@ -55,9 +67,11 @@ def load_sd(key="runwayml/stable-diffusion-v1-5", use_fp16=False, load_inverse_s
     hf = HFUNet.from_pretrained(key, subfolder="unet")
     c = hf.config
     heads = c.attention_head_dim if isinstance(c.attention_head_dim, (list, tuple)) else (c.attention_head_dim,) * 4
+    sched_cfg = dict(HFDDIM.from_pretrained(key, subfolder="scheduler").config)      # models/models.py:49
     cfg = _weights.UNetConfig(name=key, block_out_channels=tuple(c.block_out_channels), cross_attention_dim=c.cross_attention_dim,
                               attention_head_dim=tuple(heads), use_linear_projection=getattr(c, "use_linear_projection", False),
-                              use_gated_attention="gligen" in key, sample_size=c.sample_size)
+                              use_gated_attention="gligen" in key, sample_size=c.sample_size,
+                              prediction_type=sched_cfg.get("prediction_type", "epsilon"))
     vae = AutoencoderKL.from_pretrained(key, subfolder="vae").to(torch_device)
     tok = CLIPTokenizer.from_pretrained(key, subfolder="tokenizer")
     te = CLIPTextModel.from_pretrained(key, subfolder="text_encoder").to(torch_device)
@@ -66,7 +80,7 @@ def load_sd(key="runwayml/stable-diffusion-v1-5", use_fp16=False, load_inverse_s
         def decode(self, z):
             return vae.decode(z.to(vae.dtype)).sample
     return build_model_dict(cfg, {k: v.float() for k, v in hf.state_dict().items()}, vae=_HFVae(), tokenizer=tok,
-                            text_encoder=te)
+                            text_encoder=te, scheduler_config=sched_cfg)
 
 
 def encode_prompts(tokenizer, text_encoder, prompts, negative_prompt="", return_full_only=False,

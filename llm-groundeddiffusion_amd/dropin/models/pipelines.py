@@ -51,6 +51,24 @@ def _ref_maps_from_saved(sm, ref, bboxes, keys, L, T):
     return out
 
 
+def _fast_args(dynamic_num_inference_steps, fast_after_steps, fast_rate):
+    """pipelines.py:151-152,217-218,358-359,439-440: the fast tail needs the step count to follow the schedule."""
+    if fast_after_steps is None:
+        return {}
+    if not dynamic_num_inference_steps:
+        raise RuntimeError("fast_after_steps without dynamic_num_inference_steps takes DDIM steps of the wrong size "
+                           "(the reference only ever passes both)")
+    return dict(fast_after_steps=int(fast_after_steps), fast_rate=int(fast_rate))
+
+
+def _keys_to_save(sm, return_saved, keys):
+    """return_saved_cross_attn with saved_cross_attn_keys=None keeps every layer (attention_processor.py:479:
+    `save_keys is None or ...`)."""
+    if not return_saved:
+        return []
+    return [tuple(k) for k in keys] if keys is not None else sm.eng.attn_key_order()
+
+
 def _saved_list(saved, T):
     """{key: [T,Bp,H,HW,Tp]} -> list over steps of {key: (Bp,H,HW,Tp)} (the reference's saved_attns)."""
     return [{k: v[s] for k, v in saved.items()} for s in range(T)]
@@ -146,8 +164,8 @@ def generate_semantic_guidance(model_dict, latents, input_embeddings, num_infere
                                save_all_latents=False, dynamic_num_inference_steps=False, fast_after_steps=None,
                                fast_rate=2, use_boxdiff=False):
     """pipelines.py:129-247 -> (latents, images[, saved_attns][, pil][, latents_all])."""
-    if use_boxdiff or return_cross_attn or fast_after_steps is not None:
-        raise NotImplementedError("use_boxdiff / return_cross_attn / fast schedule are outside the HIP path")
+    if use_boxdiff or return_cross_attn:
+        raise NotImplementedError("use_boxdiff / return_cross_attn are outside the HIP path")
     sm = _sampler(model_dict)
     text_embeddings, _, _ = input_embeddings
     T, L = num_inference_steps, latents.shape[-1]
@@ -158,8 +176,10 @@ def generate_semantic_guidance(model_dict, latents, input_embeddings, num_infere
         g["ref_maps"] = _ref_maps_from_saved(sm, ref, bboxes, keys, L, T)
         guid = g
     r = sm.denoise(latents, text_embeddings, T, guidance_scale=guidance_scale, guidance=guid,
-                   saved_cross_attn_keys=saved_cross_attn_keys or [] if return_saved_cross_attn else [],
-                   return_cond_ca_only=return_cond_ca_only, return_token_ca_only=return_token_ca_only)
+                   saved_cross_attn_keys=_keys_to_save(sm, return_saved_cross_attn, saved_cross_attn_keys),
+                   return_cond_ca_only=return_cond_ca_only, return_token_ca_only=return_token_ca_only,
+                   **_fast_args(dynamic_num_inference_steps, fast_after_steps, fast_rate))
+    T = r["latents_all"].shape[0] - 1 if r["latents_all"] is not None else T       # steps actually run
     return _finish(sm, model_dict, r, T, ret_saved=return_saved_cross_attn, return_box_vis=return_box_vis, bboxes=bboxes,
                    phrases=phrases, save_all_latents=save_all_latents, offload=offload_latents_to_cpu)
 
@@ -174,8 +194,8 @@ def generate_gligen(model_dict, latents, input_embeddings, num_inference_steps, 
                     show_progress=True, save_all_latents=False, batched_condition=False,
                     dynamic_num_inference_steps=False, fast_after_steps=None, fast_rate=2):
     """pipelines.py:323-473 -> (latents, images[, saved_attns][, pil][, latents_all])."""
-    if batched_condition or num_images_per_prompt != 1 or fast_after_steps is not None:
-        raise NotImplementedError("batched_condition / num_images_per_prompt>1 / fast schedule are outside the HIP path")
+    if batched_condition or num_images_per_prompt != 1:
+        raise NotImplementedError("batched_condition / num_images_per_prompt>1 are outside the HIP path")
     sm = _sampler(model_dict)
     text_embeddings, _, _ = process_input_embeddings(input_embeddings)
     T, L = num_inference_steps, latents.shape[-1]
@@ -190,8 +210,10 @@ def generate_gligen(model_dict, latents, input_embeddings, num_inference_steps, 
     r = sm.denoise(latents, text_embeddings, T, guidance_scale=guidance_scale, gligen=(boxes, emb, masks),
                    gligen_scheduled_sampling_beta=gligen_scheduled_sampling_beta, guidance=guid,
                    frozen_steps=frozen_steps if frozen_mask is not None else 0, frozen_mask=frozen_mask,
-                   saved_cross_attn_keys=(saved_cross_attn_keys or []) if return_saved_cross_attn else [],
-                   return_cond_ca_only=return_cond_ca_only, return_token_ca_only=return_token_ca_only)
+                   saved_cross_attn_keys=_keys_to_save(sm, return_saved_cross_attn, saved_cross_attn_keys),
+                   return_cond_ca_only=return_cond_ca_only, return_token_ca_only=return_token_ca_only,
+                   **_fast_args(dynamic_num_inference_steps, fast_after_steps, fast_rate))
+    T = r["latents_all"].shape[0] - 1 if r["latents_all"] is not None else T       # steps actually run
     gligen_enable_fuser(model_dict.unet, False)           # pipelines.py:459-460
     return _finish(sm, model_dict, r, T, ret_saved=return_saved_cross_attn, return_box_vis=return_box_vis, bboxes=bboxes,
                    phrases=phrases, save_all_latents=save_all_latents, offload=offload_latents_to_cpu)

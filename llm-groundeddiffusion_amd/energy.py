@@ -91,6 +91,19 @@ class EnergyTables:
     def _finalize(self):
         items, coefs, masks = self._host
         device, heads = self.device, self.heads
+        # Items that write the same gradient column (map, image, token) are made adjacent and handled by one
+        # workgroup per head in this fixed order: the sum of their contributions is reproducible bit for bit.
+        order = sorted(range(len(items)), key=lambda i: (items[i][0], items[i][7], items[i][2], i))
+        items, coefs = [items[i] for i in order], [coefs[i] for i in order]
+        groups = []
+        for i, it in enumerate(items):
+            col = (it[0], it[7], it[2])
+            if groups and groups[-1][2] == col:
+                groups[-1][1] += 1
+            else:
+                groups.append([i, 1, col])
+        self.n_groups = len(groups)
+        self.groups = torch.tensor([g[:2] for g in groups] or [[0, 0]], dtype=torch.int32, device=device)
         self.n_items = len(items)
         self.items = torch.tensor(items if items else [[0] * 8], dtype=torch.int32, device=device)
         self.coefs = torch.tensor(coefs if coefs else [[0.0] * 4], dtype=F32, device=device)
@@ -158,6 +171,6 @@ class EnergyTables:
                 gmaps[k].zero_()
         stride = self.refs[0].numel() if self.refs is not None else 0
         ops.ca_energy(mp, gp if with_grad else None, self.map_hw, self.items, self.coefs, self.masks,
-                      self.refs, stride, dyn, self.n_items, self.heads, self.T, self.max_hw, self.partial,
-                      self.loss, grad_scale=grad_scale, n_samples=self.n_samples)
+                      self.refs, stride, dyn, self.groups, self.n_groups, self.n_items, self.heads, self.T,
+                      self.max_hw, self.partial, self.loss, grad_scale=grad_scale, n_samples=self.n_samples)
         return self.loss

@@ -445,8 +445,8 @@ def select_row(table, idx, out):
     _call("lgd_select_row_f32", _p(table), _p(idx), _p(out), out.numel(), _stream())
 
 
-def ca_energy(map_ptrs, gmap_ptrs, map_hw, items, coefs, masks, refs, refs_step_stride, dyn, n_items,
-              H, T, max_hw, partial, loss, grad_scale=1.0, n_samples=1):
+def ca_energy(map_ptrs, gmap_ptrs, map_hw, items, coefs, masks, refs, refs_step_stride, dyn, groups, n_groups,
+              n_items, H, T, max_hw, partial, loss, grad_scale=1.0, n_samples=1):
     _call("lgd_ca_energy_f32", _p(map_ptrs), _p(gmap_ptrs), _p(map_hw), _p(items), _p(coefs),
-          _p(masks), _p(refs), int(refs_step_stride), _p(dyn), n_items, n_samples, H, T, max_hw,
-          float(grad_scale), _p(partial), _p(loss), _stream())
+          _p(masks), _p(refs), int(refs_step_stride), _p(dyn), _p(groups), n_groups, n_items, n_samples, H, T,
+          max_hw, float(grad_scale), _p(partial), _p(loss), _stream())

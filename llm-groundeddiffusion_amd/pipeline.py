@@ -138,7 +138,8 @@ def lmd_plus_generate(sampler: LMDSampler, lay: CachedLayout, **kw):
 
 
 def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, num_inference_steps=50,
-                            frozen_step_ratio=0.5, guidance_scale=7.5, so_gligen_scheduled_sampling_beta=0.4,
+                            frozen_step_ratio=0.5, guidance_scale=7.5, loss_scale=5, loss_threshold=5.0,
+                            max_iter=None, max_index_step=0, so_gligen_scheduled_sampling_beta=0.4,
                             overall_gligen_scheduled_sampling_beta=0.4, overall_loss_scale=5,
                             overall_loss_threshold=5.0, overall_max_iter=None, overall_max_index_step=30,
                             overall_fg_top_p=0.2, overall_bg_top_p=0.2, overall_fg_weight=1.0,
@@ -146,8 +147,9 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
                             use_ref_ca=True, height=512, width=512, decode=True, guidance_attn_keys=None,
                             use_fast_schedule=False, so_center_box=False, so_horizontal_center_only=True,
                             align_with_overall_bboxes=False, horizontal_shift_only=True):
-    """LMD+ (generation/lmd_plus.py:193-520, default arguments; per-box guidance is off there:
-    max_index_step=0, :203) for a batch of independent layouts: the per-box generations of ALL layouts run
+    """LMD+ (generation/lmd_plus.py:193-520; per-box attention guidance is off by default there,
+    max_index_step=0, :203 — with max_index_step > 0 every per-box GLIGEN generation is guided on its own box with
+    the energy's default weights, lmd_plus.py:320-328) for a batch of independent layouts: the per-box generations of ALL layouts run
     as one batched denoising call (B = 2 x total boxes), then the overall generations of all layouts as
     another (B = 2 x layouts; guidance pass B = layouts with a per-image loop exit).  Results per layout
     are independent of how layouts are batched (images only share kernel launches)."""
@@ -170,9 +172,15 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
     if use_ref_ca or frozen_steps > 0:
         for li, lay in enumerate(lays):
             for i, box in enumerate(so_boxes[li]):
+                guid = None
+                if max_index_step > 0:                       # lmd_plus.py:320-328 (semantic_guidance_kwargs)
+                    guid = dict(bboxes=[list(box)], object_positions=[lay.so_object_positions[i]],
+                                loss_scale=loss_scale, loss_threshold=loss_threshold,
+                                max_iter=max_iter or DEFAULT_MAX_ITER, max_index_step=max_index_step,
+                                guidance_attn_keys=keys)
                 jobs.append(Job(prep[li][0][i], torch.cat([lay.so_uncond, lay.so_cond[i:i + 1]]),
                                 gligen=prepare_gligen_condition([list(box)], lay.phrase_embeddings[i:i + 1], dev),
-                                token=lay.so_word_token_index[i]))
+                                guidance=guid, token=lay.so_word_token_index[i]))
                 owner.append((li, i))
     res_a = sampler.denoise_batch(jobs, T, guidance_scale=guidance_scale, use_gligen=True,
                                   gligen_scheduled_sampling_beta=so_gligen_scheduled_sampling_beta,
@@ -217,7 +225,9 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
     return [dict(image=images[li], latents=res_b[li]["latents"], so_images=per_lay[li]["so_images"],
                  guidance_iters=res_b[li]["guidance_iters"],
                  guidance_iters_fuser_on=res_b[li]["guidance_iters_fuser_on"], composed=comps[li][0],
-                 fg_idx=comps[li][1])
+                 fg_idx=comps[li][1],
+                 so_latents_all=per_lay[li]["latents_all"],
+                 so_guidance_iters=[r["guidance_iters"] for (lj, _), r in zip(owner, res_a) if lj == li])
             for li in range(len(lays))]
 
 
@@ -278,11 +288,12 @@ def lmd_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, num_inf
         if decode:
             d["so_images"].append(imgs[n:n + 1])
     # ---- alignment (latents.py:107-118), composition, stage B
-    jobs_b = []
+    jobs_b, comps = [], []
     for li, lay in enumerate(lays):
         d = per_lay[li]
         _align_stage_a(d, lay, keys, align_with_overall_bboxes, horizontal_shift_only)
         composed, fg_idx = compose_latents(d["latents_all"], d["masks"], comp_steps, prep[li][1].to(dev))
+        comps.append((composed, fg_idx))
         overall_bboxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
         flat = [i for grp in lay.overall_groups for i in grp]
         guid = None
@@ -301,29 +312,37 @@ def lmd_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, num_inf
                                   save_all_latents=False)
     images = sampler.decode(torch.cat([r["latents"] for r in res_b])) if decode else [None] * len(lays)
     return [dict(image=images[li], latents=res_b[li]["latents"], so_images=per_lay[li]["so_images"],
-                 guidance_iters=res_b[li]["guidance_iters"],
+                 guidance_iters=res_b[li]["guidance_iters"], composed=comps[li][0], fg_idx=comps[li][1],
                  so_guidance_iters=[r["guidance_iters"] for (lj, _), r in zip(owner, res_a) if lj == li])
             for li in range(len(lays))]
 
 
-def backward_guidance_generate(sampler: LMDSampler, lay: CachedLayout, *, num_inference_steps=50,
-                               guidance_scale=7.5, loss_scale=30, loss_threshold=0.2, max_iter=5,
-                               max_index_step=10, height=512, width=512, decode=True,
-                               guidance_attn_keys=None, **energy_kw):
-    """Layout-guidance baseline (generation/backward_guidance.py:46-49,99-120): one
-    generate_semantic_guidance call on seeded noise, no per-box stage (BASELINE config 3)."""
+def backward_guidance_generate(sampler: LMDSampler, lay: CachedLayout, **kw):
+    """Layout-guidance baseline for one layout (generation/backward_guidance.py:46-49,99-120)."""
+    return backward_guidance_generate_batch(sampler, [lay], **kw)[0]
+
+
+def backward_guidance_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, num_inference_steps=50,
+                                     guidance_scale=7.5, loss_scale=30, loss_threshold=0.2, max_iter=5,
+                                     max_index_step=10, height=512, width=512, decode=True,
+                                     guidance_attn_keys=None, **energy_kw):
+    """Layout-guidance baseline (generation/backward_guidance.py:46-49,99-120; BASELINE config 3 runs it on
+    SD2.1-768): one generate_semantic_guidance call per layout on seeded noise, no per-box stage.  The layouts of
+    a batch share UNet calls; each keeps its own guidance loop exit."""
     L = height // 8
     C = sampler.eng.cfg.in_channels
-    lat = torch.randn((1, C, L, L), generator=torch.manual_seed(lay.bg_seed), dtype=F32)
-    overall_bboxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
-    guid = None
-    if overall_bboxes:
-        guid = dict(bboxes=overall_bboxes, object_positions=lay.overall_object_positions, loss_scale=loss_scale,
-                    loss_threshold=loss_threshold, max_iter=max_iter, max_index_step=max_index_step,
-                    guidance_attn_keys=[tuple(k) for k in (guidance_attn_keys or DEFAULT_GUIDANCE_ATTN_KEYS)],
-                    **energy_kw)
-    text = torch.cat([lay.overall_uncond, lay.overall_cond])
-    r = sampler.denoise(lat, text, num_inference_steps, guidance_scale=guidance_scale, guidance=guid,
-                        save_all_latents=False)
-    image = sampler.decode(r["latents"])[0] if decode else None
-    return dict(image=image, latents=r["latents"], guidance_iters=r["guidance_iters"])
+    keys = [tuple(k) for k in (guidance_attn_keys or DEFAULT_GUIDANCE_ATTN_KEYS)]
+    jobs = []
+    for lay in lays:
+        lat = torch.randn((1, C, L, L), generator=torch.manual_seed(lay.bg_seed), dtype=F32)
+        overall_bboxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
+        guid = None
+        if overall_bboxes:
+            guid = dict(bboxes=overall_bboxes, object_positions=lay.overall_object_positions, loss_scale=loss_scale,
+                        loss_threshold=loss_threshold, max_iter=max_iter, max_index_step=max_index_step,
+                        guidance_attn_keys=keys, **energy_kw)
+        jobs.append(Job(lat, torch.cat([lay.overall_uncond, lay.overall_cond]), guidance=guid))
+    res = sampler.denoise_batch(jobs, num_inference_steps, guidance_scale=guidance_scale, save_all_latents=False)
+    images = sampler.decode(torch.cat([r["latents"] for r in res])) if decode else [None] * len(lays)
+    return [dict(image=images[i], latents=r["latents"], guidance_iters=r["guidance_iters"],
+                 guidance_iters_fuser_on=0) for i, r in enumerate(res)]

@@ -1,0 +1,159 @@
+"""ORACLE TEST INFRASTRUCTURE (build container only) — orchestration goldens.
+
+Runs the reference's OWN, unmodified plugins `generation/lmd_plus.run` (lmd_plus.py:193-520) and
+`generation/lmd.run` (lmd.py:215-551) on CPU through oracle/ref_harness.py, with
+  * the reference UNet (tiny configs, seeded synthetic weights, fp32),
+  * the whitespace fake tokenizer / table text encoder of tests/fake_text.py (no CLIP vocabulary here),
+  * SAM replaced by the box mask (`utils.proportion_to_mask`), as SURVEY.md 8(d) prescribes for benchmarks,
+  * recorder wrappers (no behaviour change) around latents.compose_latents_with_alignment,
+    pipelines.generate_gligen / generate_partial_frozen and guidance.get_phrase_indices,
+and writes tests/golden/run_lmd_plus_tiny.npz / run_lmd_tiny.npz: composed latents, foreground indices, the
+final latents of the overall generation, per-box histories, and every get_phrase_indices call (prompt, phrases,
+words -> positions), which also pins row G4 against the reference with the same fake tokenizer.
+
+    python oracle/make_golden_runs.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ref_harness as H  # noqa: E402
+from fake_text import FakeTextEncoder, FakeTokenizer  # noqa: E402
+
+SPEC = dict(prompt="A realistic image of a white deer and a gray bear in an empty factory scene",
+            gen_boxes=[("a white deer", [37, 88, 91, 117]), ("a gray bear", [157, 96, 94, 108])],
+            bg_prompt="A realistic image of an empty factory scene", extra_neg_prompt="")
+# a phrase that occurs twice (two boxes, pluralised overall phrase) and one absent from the prompt ("| phrase" suffix)
+SPEC3 = dict(prompt="A photo of two apples on a table",
+             gen_boxes=[("an apple", [20, 120, 80, 80]), ("an apple", [140, 110, 90, 90]), ("a wooden spoon", [60, 30, 120, 40])],
+             bg_prompt="A photo of a table", extra_neg_prompt="cartoon")
+
+
+def build(cfg_name):
+    H.setup()
+    import lgd_amd  # noqa: F401
+    from lgd_amd import weights
+    import models
+    cfg = weights.CONFIGS[cfg_name]
+    md = H.build_model_dict(cfg)
+    md.tokenizer, md.text_encoder = FakeTokenizer(), FakeTextEncoder(cfg.cross_attention_dim, "cpu")
+    models.model_dict = md
+    models.models.model_dict = md
+    return cfg, md
+
+
+def record_phrase_calls(guidance, log):
+    orig = guidance.get_phrase_indices
+
+    def wrapped(tokenizer, prompt, phrases, *a, **k):
+        out = orig(tokenizer, prompt, phrases, *a, **k)
+        log.append(dict(prompt=prompt, phrases=list(phrases), words=list(k.get("words") or []),
+                        add_suffix=bool(k.get("add_suffix_if_not_found", False)),
+                        out=json.loads(json.dumps(out, default=lambda o: o.tolist() if hasattr(o, "tolist") else o))))
+        return out
+    guidance.get_phrase_indices = wrapped
+    return orig
+
+
+def run_lmd_plus():
+    cfg, md = build("tiny_gligen")
+    import generation.lmd_plus as g
+    from utils import utils as ref_utils
+    g.height = g.width = 256
+    g.H = g.W = 32
+    rec = dict(phrase_calls=[], gligen_calls=[], compose=[])
+    g.sam.sam_refine_box = lambda sam_input_image, box, model_dict, verbose, H, W, **kw: (
+        ref_utils.proportion_to_mask(box, H, W, return_np=True).astype(bool), 1.0)
+    o_phr = record_phrase_calls(g.guidance, rec["phrase_calls"])
+    o_gl, o_comp = g.pipelines.generate_gligen, g.latents.compose_latents_with_alignment
+
+    def gl(*a, **k):
+        out = o_gl(*a, **k)
+        rec["gligen_calls"].append(dict(latents_in=a[1].detach().clone(), out_latents=out[0].detach().clone(),
+                                        latents_all=out[-1].detach().clone() if k.get("save_all_latents") else None))
+        return out
+
+    def comp(*a, **k):
+        out = o_comp(*a, **k)
+        rec["compose"].append((out[0].detach().clone(), out[1].detach().clone()))
+        return out
+    g.pipelines.generate_gligen, g.latents.compose_latents_with_alignment = gl, comp
+    outs = {}
+    for tag, spec, kw in (("a", SPEC, dict(bg_seed=3, fg_seed_start=3 + 123456789)),
+                          ("b", SPEC3, dict(bg_seed=11, fg_seed_start=77, use_fast_schedule=True))):
+        for v in rec.values():
+            v.clear()
+        r = g.run(spec, num_inference_steps=8, frozen_step_ratio=0.5, overall_max_index_step=3,
+                  overall_max_iter=[2, 1, 1], overall_loss_threshold=0.0, use_autocast=False, **kw)
+        n = len(spec["gen_boxes"])
+        assert len(rec["gligen_calls"]) == n + 1 and len(rec["compose"]) == 1
+        outs[f"{tag}_composed"] = rec["compose"][0][0].numpy()
+        outs[f"{tag}_fg_idx"] = rec["compose"][0][1].numpy()
+        outs[f"{tag}_final_latents"] = rec["gligen_calls"][-1]["out_latents"].numpy()
+        for i in range(n):
+            outs[f"{tag}_so{i}_latents_all"] = rec["gligen_calls"][i]["latents_all"].numpy()
+        outs[f"{tag}_phrase_calls"] = np.array(json.dumps(rec["phrase_calls"]))
+        outs[f"{tag}_image_shape"] = np.array(r.image.shape)
+    g.pipelines.generate_gligen, g.latents.compose_latents_with_alignment = o_gl, o_comp
+    g.guidance.get_phrase_indices = o_phr
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "run_lmd_plus_tiny.npz"), **outs)
+    print("wrote run_lmd_plus_tiny.npz", {k: getattr(v, "shape", None) for k, v in outs.items()})
+
+
+def run_lmd():
+    cfg, md = build("tiny")
+    import generation.lmd as g
+    from utils import utils as ref_utils
+    g.height = g.width = 256
+    g.H = g.W = 32
+    rec = dict(phrase_calls=[], compose=[], final=[])
+    g.sam.sam_refine_attn = lambda sam_input_image, token_attn_np, model_dict, height, width, H, W, **kw: (
+        None, 1.0)
+    # lmd.py refines with the attention map; the box is not passed to sam_refine_attn, so the stand-in is installed
+    # one level up, where the box is known
+    o_so = g.generate_single_object_with_box
+
+    def so(prompt, box, *a, **k):
+        g.sam.sam_refine_attn = lambda *aa, **kk: (ref_utils.proportion_to_mask(box, g.H, g.W, return_np=True).astype(bool), 1.0)
+        return o_so(prompt, box, *a, **k)
+    g.generate_single_object_with_box = so
+    o_phr = record_phrase_calls(g.guidance, rec["phrase_calls"])
+    o_comp, o_pf = g.latents.compose_latents_with_alignment, g.pipelines.generate_partial_frozen
+
+    def comp(*a, **k):
+        out = o_comp(*a, **k)
+        rec["compose"].append((out[0].detach().clone(), out[1].detach().clone()))
+        return out
+
+    def pf(*a, **k):
+        out = o_pf(*a, **k)
+        rec["final"].append(out[0].detach().clone())
+        return out
+    g.latents.compose_latents_with_alignment, g.pipelines.generate_partial_frozen = comp, pf
+    r = g.run(SPEC, bg_seed=3, fg_seed_start=99, num_inference_steps=12, max_index_step=2, max_iter=[1],
+              loss_threshold=0.0, overall_max_index_step=3, overall_max_iter=[2, 1, 1], overall_loss_threshold=0.0,
+              so_center_box=False, align_with_overall_bboxes=False, use_autocast=False)
+    outs = dict(composed=rec["compose"][0][0].numpy(), fg_idx=rec["compose"][0][1].numpy(),
+                final_latents=rec["final"][0].numpy(), phrase_calls=np.array(json.dumps(rec["phrase_calls"])),
+                image_shape=np.array(r.image.shape))
+    g.latents.compose_latents_with_alignment, g.pipelines.generate_partial_frozen = o_comp, o_pf
+    g.guidance.get_phrase_indices = o_phr
+    g.generate_single_object_with_box = o_so
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "run_lmd_tiny.npz"), **outs)
+    print("wrote run_lmd_tiny.npz", {k: getattr(v, "shape", None) for k, v in outs.items()})
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "lmd_plus"):
+        run_lmd_plus()
+    if which in ("all", "lmd"):
+        run_lmd()

@@ -302,3 +302,38 @@ def test_fullsize_guidance_iteration_vs_oracle(dev):
     print(f"[full] guidance loss hip {l_hip:.4f} oracle {l_ref:.4f}; latent-gradient cosine {cos:.5f} "
           f"rel-L2 {rel_l2(a, b):.3e}")
     assert abs(l_hip - l_ref) / abs(l_ref) < 2e-2 and cos > 0.98
+
+
+def test_fullsize_sd21_forward_vs_oracle(dev):
+    """BASELINE config 3 at full width: SD2.1-768 topology (heads 5/10/20/20 of width 64, text width 1024, linear
+    proj_in/out) at 96x96 latents, B = 2 — noise prediction and the guidance maps (HW = 144 / 576) vs the oracle."""
+    import restate as R
+    cfg = weights.CONFIGS["sd21"]
+    sd = weights.synth_state_dict(cfg, 0)
+    eng = UNetEngine(cfg, dev, sd)
+    cd = dict(block_out_channels=cfg.block_out_channels, layers_per_block=cfg.layers_per_block,
+              attention_head_dim=cfg.attention_head_dim, norm_num_groups=cfg.norm_num_groups, norm_eps=cfg.norm_eps,
+              gligen_positive_len=cfg.gligen_positive_len)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    L = cfg.sample_size
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((2, 4, L, L), generator=g)
+    unc, cond = weights.synth_embeddings(cfg, 1, seed=1)
+    ehs = torch.cat([unc, cond])
+    plan = eng.plan(2, L, fuser=False, save_keys=KEYS)
+    eng.prepare_timesteps([501])
+    eng.set_step(0)
+    eng.prepare_text(ehs)
+    eps = plan.forward(x.to(dev)).cpu()
+    saved = {}
+    with torch.no_grad():
+        ref = R.unet_forward(sd, cd, x, 501, ehs, saved=saved, save_keys=KEYS)
+    e = relerr(eps, ref)
+    print(f"[sd21 full] eps relerr {e:.3e} rel-L2 {rel_l2(eps, ref):.3e}")
+    assert e < 2e-2
+    for k in KEYS:
+        em, el2 = relerr(plan.maps[k], saved[k]), rel_l2(plan.maps[k], saved[k])
+        print(f"[sd21 full] map {k} relerr {em:.3e} rel-L2 {el2:.3e}")
+        assert em < 3e-2 and el2 < 1.5e-2
+    del eng
+    torch.cuda.empty_cache()

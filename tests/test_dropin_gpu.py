@@ -22,58 +22,8 @@ def relerr(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
-class _Tok(dict):
-    def __getattr__(self, k):
-        return self[k]
-
-    def to(self, *_a, **_k):
-        return self
-
-
-class FakeTokenizer:
-    model_max_length = 77
-    eos_token = "<eos>"
-
-    def __init__(self):
-        self.vocab, self.rev = {"<bos>": 0, "<eos>": 1}, {0: "<bos>", 1: "<eos>"}
-
-    def _id(self, w):
-        if w not in self.vocab:
-            self.vocab[w] = len(self.vocab)
-            self.rev[self.vocab[w]] = w
-        return self.vocab[w]
-
-    def _convert_id_to_token(self, i):
-        return self.rev[int(i)]
-
-    def __call__(self, texts, padding="do_not_pad", max_length=77, truncation=False, return_tensors="pt"):
-        rows = [[0] + [self._id(w) for w in t.replace(",", " ,").split()][:75] + [1] for t in texts]
-        if padding == "max_length":
-            rows = [r + [1] * (max_length - len(r)) for r in rows]
-        elif padding is True:
-            m = max(len(r) for r in rows)
-            rows = [r + [1] * (m - len(r)) for r in rows]
-        if return_tensors == "np":
-            return _Tok(input_ids=[np.array(r) for r in rows])
-        return _Tok(input_ids=torch.tensor(rows))
-
-
-class FakeTextEncoder:
-    def __init__(self, cx):
-        self.cx = cx
-
-    def _emb(self, ids, dim):
-        g = torch.Generator().manual_seed(1234)
-        table = torch.randn(4096, dim, generator=g)
-        return table[ids.cpu() % 4096]
-
-    def __call__(self, input_ids=None, **kw):
-        class O(tuple):
-            pass
-        h = self._emb(input_ids, self.cx).to("cuda")
-        o = O((h,))
-        o.pooler_output = self._emb(input_ids, 768).mean(dim=1).to("cuda")
-        return o
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fake_text import FakeTextEncoder, FakeTokenizer  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -190,3 +140,83 @@ def test_pipelines_generate_partial_frozen_signature(dropin, dev):
                                                     (ehs, ehs[:1], ehs[1:]), 4, 2, bboxes=BBOXES, phrases=["a", "b"],
                                                     object_positions=OBJ_POS, semantic_guidance_kwargs=sg)
     assert images is None and relerr(lat, g["partial_frozen_out"]) < 5e-2
+
+
+SPEC = dict(prompt="A realistic image of a white deer and a gray bear in an empty factory scene",
+            gen_boxes=[("a white deer", [37, 88, 91, 117]), ("a gray bear", [157, 96, 94, 108])],
+            bg_prompt="A realistic image of an empty factory scene", extra_neg_prompt="")
+SPEC3 = dict(prompt="A photo of two apples on a table",
+             gen_boxes=[("an apple", [20, 120, 80, 80]), ("an apple", [140, 110, 90, 90]), ("a wooden spoon", [60, 30, 120, 40])],
+             bg_prompt="A photo of a table", extra_neg_prompt="cartoon")
+
+
+def test_lmd_plus_run_vs_reference_run_golden(dropin, dev):
+    """End-to-end orchestration: the reference's own generation/lmd_plus.run (CPU, fp32, SAM = box mask, fake
+    tokenizer / encoder; oracle/make_golden_runs.py) against the plugin on the HIP engine — per-box histories,
+    composed latents, foreground indices and the final latents of the guided overall generation.  Spec (b) has a
+    repeated phrase (two boxes under one pluralised overall phrase -> flattened box order, per-box reference maps),
+    a negative prompt prefix and the fast schedule."""
+    sys.modules.pop("inflect", None)
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "stubs"))       # `inflect` stand-in, as in the golden run
+    try:
+        import generation.lmd_plus as g
+        from generation._common import DEFAULT_OVERALL_NEGATIVE_PROMPT, DEFAULT_SO_NEGATIVE_PROMPT, build_layout
+        from lgd_amd.pipeline import lmd_plus_generate
+        gold = np.load(os.path.join(GOLD, "run_lmd_plus_tiny.npz"))
+        sm = dropin.model_dict.sampler
+        g.height = g.width = 256
+        for tag, spec, seeds, extra in (("a", SPEC, (3, 3 + 123456789), {}), ("b", SPEC3, (11, 77), dict(use_fast_schedule=True))):
+            lay = build_layout(spec, seeds[0], seeds[1], DEFAULT_SO_NEGATIVE_PROMPT, DEFAULT_OVERALL_NEGATIVE_PROMPT, 256, 256)
+            kw = dict(num_inference_steps=8, frozen_step_ratio=0.5, overall_max_index_step=3, overall_max_iter=[2, 1, 1],
+                      overall_loss_threshold=0.0, height=256, width=256, **extra)
+            out = lmd_plus_generate(sm, lay, **kw)
+            n = len(spec["gen_boxes"])
+            assert out["guidance_iters"] == 4 and torch.equal(out["fg_idx"].cpu(), torch.from_numpy(gold[f"{tag}_fg_idx"]))
+            for i in range(n):
+                e = relerr(out["so_latents_all"][i][:gold[f"{tag}_so{i}_latents_all"].shape[0]], gold[f"{tag}_so{i}_latents_all"])
+                assert e < 5e-2, (tag, i, e)
+            e_c, e_f = relerr(out["composed"], gold[f"{tag}_composed"]), relerr(out["latents"], gold[f"{tag}_final_latents"])
+            print(f"[run {tag}] composed relerr {e_c:.3e}, final latents relerr {e_f:.3e}")
+            assert out["composed"].shape == gold[f"{tag}_composed"].shape and e_c < 5e-2 and e_f < 5e-2
+            # the plugin entry point runs the same thing and only hands back the image
+            r = g.run(spec, bg_seed=seeds[0], fg_seed_start=seeds[1], num_inference_steps=8, frozen_step_ratio=0.5,
+                      overall_max_index_step=3, overall_max_iter=[2, 1, 1], overall_loss_threshold=0.0, **extra)
+            assert tuple(r.image.shape) == tuple(gold[f"{tag}_image_shape"]) and np.array_equal(r.image, out["image"])
+            assert len(r.so_img_list) == n
+        # per-box attention guidance inside LMD+ (off by default in the reference) is wired too
+        out = lmd_plus_generate(sm, build_layout(SPEC, 3, 99, DEFAULT_SO_NEGATIVE_PROMPT, DEFAULT_OVERALL_NEGATIVE_PROMPT, 256, 256),
+                                num_inference_steps=6, max_index_step=2, max_iter=[1], loss_threshold=0.0,
+                                overall_max_index_step=2, overall_max_iter=[1], overall_loss_threshold=0.0,
+                                height=256, width=256, decode=False)
+        assert out["so_guidance_iters"] == [2, 2] and out["guidance_iters"] == 2 and torch.isfinite(out["latents"]).all()
+    finally:
+        sys.path.remove(os.path.join(ROOT, "oracle", "stubs"))
+        sys.modules.pop("inflect", None)
+
+
+def test_lmd_run_vs_reference_run_golden(dev):
+    """Training-free LMD: the reference's own generation/lmd.run (guided per-box stage, partial-frozen overall stage)."""
+    sys.path.insert(0, os.path.join(ROOT, "llm-groundeddiffusion_amd", "dropin"))
+    import lgd_amd  # noqa: F401
+    from lgd_amd import weights
+    import models
+    keep = models.model_dict
+    try:
+        cfg = weights.CONFIGS["tiny"]
+        models.model_dict = models.build_model_dict(cfg, weights.synth_state_dict(cfg, 0), vae=None, tokenizer=FakeTokenizer(),
+                                                    text_encoder=FakeTextEncoder(cfg.cross_attention_dim))
+        from generation._common import DEFAULT_OVERALL_NEGATIVE_PROMPT, DEFAULT_SO_NEGATIVE_PROMPT, build_layout
+        from lgd_amd.pipeline import lmd_generate
+        gold = np.load(os.path.join(GOLD, "run_lmd_tiny.npz"))
+        lay = build_layout(SPEC, 3, 99, DEFAULT_SO_NEGATIVE_PROMPT, DEFAULT_OVERALL_NEGATIVE_PROMPT, 256, 256)
+        out = lmd_generate(models.model_dict.sampler, lay, num_inference_steps=12, frozen_step_ratio=0.5, max_index_step=2,
+                           max_iter=[1], loss_threshold=0.0, overall_max_index_step=3, overall_max_iter=[2, 1, 1],
+                           overall_loss_threshold=0.0, so_center_box=False, align_with_overall_bboxes=False,
+                           height=256, width=256, decode=False)
+        assert out["so_guidance_iters"] == [2, 2] and out["guidance_iters"] == 4
+        assert torch.equal(out["fg_idx"].cpu(), torch.from_numpy(gold["fg_idx"]))
+        e_c, e_f = relerr(out["composed"], gold["composed"]), relerr(out["latents"], gold["final_latents"])
+        print(f"[run lmd] composed relerr {e_c:.3e}, final latents relerr {e_f:.3e}")
+        assert e_c < 5e-2 and e_f < 5e-2
+    finally:
+        models.model_dict = keep
