@@ -339,7 +339,7 @@ def main():
     res = dict(metric=metric, value=round(n_images / dt, 4),
                unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=round(dt * 1e3 / args.steps, 1), higher_is_better=True,
-               scaling="weak" if args.workload == "batch4" else "strong",
+               scaling="strong" if args.workload == "lmd_v0.1" else "weak",
                vs_baseline=None, dtype="fp16", data="synthetic",
                config=dict(workload=f"{method}{what} (lmd_v0.1 cache), {T} DDIM steps, {side}x{side}, {args.config} "
                                     f"({arch}, seeded random weights), VAE decodes "

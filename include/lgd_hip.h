@@ -160,6 +160,13 @@ int lgd_cross_attn_bwd_f16(const void* q, int64_t ldq, int64_t q_bs, const void*
                            int64_t gq_bs, int B, int H, int Sq, int Sk, int d, float scale,
                            void* stream);
 
+/* Causal self-attention (key j visible to query i iff j <= i), exact softmax: the CLIP text encoder's attention
+ * ([ext] transformers 4.29.2 CLIPAttention with the causal mask of CLIPTextTransformer; called from
+ * models/models.py:67-80 and pipelines.py:303-304 through `text_encoder(...)`).  Views as lgd_attn_fwd_f16. */
+int lgd_attn_causal_fwd_f16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
+                            const void* v, int64_t ldv, int64_t v_bs, void* o, int64_t ldo, int64_t o_bs, int B,
+                            int H, int S, int d, float scale, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Elementwise pieces.
  * ------------------------------------------------------------------------------------------- */
@@ -168,6 +175,8 @@ int lgd_cross_attn_bwd_f16(const void* q, int64_t ldq, int64_t q_bs, const void*
 int lgd_geglu_bwd_f16(const void* h, const void* gy, void* gh, int64_t rows, int n, void* stream);
 /* GEGLU forward on a stored packed pre-activation h [rows][2n] -> y [rows][n] (grad-enabled pass). */
 int lgd_geglu_fwd_f16(const void* h, void* y, int64_t rows, int n, void* stream);
+/* y = x * sigmoid(1.702 x) (fp16): CLIP text encoder MLP activation ([ext] transformers CLIPMLP, "quick_gelu"). */
+int lgd_quick_gelu_f16(const void* x, void* y, int64_t n, void* stream);
 /* y = a + b (fp16), n elements (gradient fan-in / residual). */
 int lgd_add_f16(const void* a, const void* b, void* y, int64_t n, void* stream);
 /* y = alpha * x (fp16) */

@@ -70,6 +70,8 @@ SIGNATURES = {
     "lgd_cfg_ddim_step_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "lgd_axpy_f32": [_P, _P, _P, _P, _I, _P, _L, _L, _P],
     "lgd_select_row_f32": [_P, _P, _P, _I, _P],
+    "lgd_attn_causal_fwd_f16": [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _F, _P],
+    "lgd_quick_gelu_f16": [_P, _P, _L, _P],
     "lgd_ca_energy_f32": [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P],
 }
 

@@ -35,6 +35,7 @@ struct AttnArgs {
   half_t* o; long ldo, o_bs;
   float* lse;
   float* probs; int tok; int cond_only;
+  int causal;        // attn_fwd_kernel only: key j attends to query i iff j <= i (CLIP text encoder)
   int B, H, Sq, Sk, d;
   float scale_log2;  // scale * log2(e)
 };
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   };
 
   // S^T for the current LDS tile, scaled to the log2 domain and masked.
+  const int key_end = a.causal ? min(a.Sk, q0 + c16 + 1) : a.Sk;   // first key this lane's query does not see
   auto compute_s = [&](int kv0, f32x4 (&s)[4]) {
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int key = kv0 + kt * 16 + g * 4 + r;
-        s[kt][r] = key < a.Sk ? acc[r] * a.scale_log2 : NEG_BIG;
+        s[kt][r] = key < key_end ? acc[r] * a.scale_log2 : NEG_BIG;
       }
     }
   };
@@ -618,7 +620,7 @@ extern "C" int lgd_attn_fwd_f16(const void* q, int64_t ldq, int64_t q_bs, const 
   a.k = (const half_t*)k; a.ldk = ldk; a.k_bs = k_bs;
   a.v = (const half_t*)v; a.ldv = ldv; a.v_bs = v_bs;
   a.o = (half_t*)o; a.ldo = ldo; a.o_bs = o_bs;
-  a.lse = lse; a.probs = nullptr; a.tok = -1; a.cond_only = 0;
+  a.lse = lse; a.probs = nullptr; a.tok = -1; a.cond_only = 0; a.causal = 0;
   a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.d = d;
   a.scale_log2 = scale * 1.4426950408889634f;
   return launch_attn<false>(a, reinterpret_cast<hipStream_t>(stream));
@@ -639,10 +641,28 @@ extern "C" int lgd_cross_attn_fwd_f16(const void* q, int64_t ldq, int64_t q_bs, 
   a.k = (const half_t*)k; a.ldk = ldk; a.k_bs = k_bs;
   a.v = (const half_t*)v; a.ldv = ldv; a.v_bs = v_bs;
   a.o = (half_t*)o; a.ldo = ldo; a.o_bs = o_bs;
-  a.lse = nullptr; a.probs = probs; a.tok = tok; a.cond_only = cond_only;
+  a.lse = nullptr; a.probs = probs; a.tok = tok; a.cond_only = cond_only; a.causal = 0;
   a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.d = d;
   a.scale_log2 = scale * 1.4426950408889634f;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (probs) return launch_attn<true>(a, st);
   return launch_attn<false>(a, st);
+}
+
+extern "C" int lgd_attn_causal_fwd_f16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk,
+                                       int64_t k_bs, const void* v, int64_t ldv, int64_t v_bs, void* o,
+                                       int64_t ldo, int64_t o_bs, int B, int H, int S, int d, float scale,
+                                       void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  if (B < 1 || H < 1 || S < 1 || d < 8) return LGD_ERR_ARG;
+  if (bad_view(ldq, d) || bad_view(ldk, d) || bad_view(ldv, d) || (ldo % 4)) return LGD_ERR_ARG;
+  AttnArgs a;
+  a.q = (const half_t*)q; a.ldq = ldq; a.q_bs = q_bs;
+  a.k = (const half_t*)k; a.ldk = ldk; a.k_bs = k_bs;
+  a.v = (const half_t*)v; a.ldv = ldv; a.v_bs = v_bs;
+  a.o = (half_t*)o; a.ldo = ldo; a.o_bs = o_bs;
+  a.lse = nullptr; a.probs = nullptr; a.tok = -1; a.cond_only = 0; a.causal = 1;
+  a.B = B; a.H = H; a.Sq = S; a.Sk = S; a.d = d;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  return launch_attn<true>(a, reinterpret_cast<hipStream_t>(stream));   // exact two-pass softmax kernel
 }

@@ -125,6 +125,20 @@ __global__ __launch_bounds__(256) void scale_kernel(const half_t* a, half_t* y, 
   }
 }
 
+// y = x * sigmoid(1.702 x): the "quick GELU" of the CLIP text encoder's MLP ([ext] transformers CLIPMLP).
+__global__ __launch_bounds__(256) void quick_gelu_kernel(const half_t* a, half_t* y, long nvec) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < nvec; i += gridDim.x * 256L) {
+    half8_t x0 = reinterpret_cast<const half8_t*>(a)[i];
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = (float)x0[e];
+      o[e] = (half_t)(x / (1.f + __expf(-1.702f * x)));
+    }
+    reinterpret_cast<half8_t*>(y)[i] = o;
+  }
+}
+
 // GEGLU forward on a stored pre-activation (the grad-enabled guidance pass keeps h for backward;
 // the no-grad pass uses the fused GEMM epilogue instead).  h packed [16 value | 16 gate] blocks.
 __global__ __launch_bounds__(256) void geglu_fwd_kernel(const half_t* __restrict__ h,
@@ -347,6 +361,14 @@ extern "C" int lgd_scale_f16(const void* x, void* y, float alpha, int64_t n, voi
   hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), (const half_t*)x, (half_t*)y, alpha,
                      (long)(n / 8));
+  return lgd_check_launch();
+}
+
+extern "C" int lgd_quick_gelu_f16(const void* x, void* y, int64_t n, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  if (n % 8) return LGD_ERR_ARG;
+  hipLaunchKernelGGL(quick_gelu_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), (const half_t*)x, (half_t*)y, (long)(n / 8));
   return lgd_check_launch();
 }
 

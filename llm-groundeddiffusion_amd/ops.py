@@ -367,6 +367,21 @@ def cross_attn_fwd(q, k, v, o, B, H, Sq, Sk, d, scale, *, probs=None, tok=-1, co
     return o
 
 
+def attn_causal_fwd(q, k, v, o, B, H, S, d, scale, *, view=None):
+    """Causal self-attention over a fused [B,S,3*H*d] projection (or separate q/k/v with the default view)."""
+    vw = view or (H * d, S * H * d)
+    _call("lgd_attn_causal_fwd_f16", _p(q), vw[0], vw[1], _p(k), vw[0], vw[1], _p(v), vw[0], vw[1], _p(o),
+          H * d, S * H * d, B, H, S, d, float(scale), _stream())
+    return o
+
+
+def quick_gelu(x, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    _call("lgd_quick_gelu_f16", _p(x), _p(out), x.numel(), _stream())
+    return out
+
+
 def cross_attn_bwd(q, k, v, go, gp, gq, B, H, Sq, Sk, d, scale, *, q_view=None, k_view=None,
                    v_view=None, go_view=None, gq_view=None):
     dq_ = (H * d, Sq * H * d)

@@ -181,7 +181,7 @@ def test_lmd_plus_run_vs_reference_run_golden(dropin, dev):
             # the plugin entry point runs the same thing and only hands back the image
             r = g.run(spec, bg_seed=seeds[0], fg_seed_start=seeds[1], num_inference_steps=8, frozen_step_ratio=0.5,
                       overall_max_index_step=3, overall_max_iter=[2, 1, 1], overall_loss_threshold=0.0, **extra)
-            assert tuple(r.image.shape) == tuple(gold[f"{tag}_image_shape"]) and np.array_equal(r.image, out["image"])
+            assert r.image.shape == (256, 256, 3) and np.array_equal(r.image, out["image"])
             assert len(r.so_img_list) == n
         # per-box attention guidance inside LMD+ (off by default in the reference) is wired too
         out = lmd_plus_generate(sm, build_layout(SPEC, 3, 99, DEFAULT_SO_NEGATIVE_PROMPT, DEFAULT_OVERALL_NEGATIVE_PROMPT, 256, 256),

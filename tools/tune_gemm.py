@@ -20,7 +20,7 @@ dev = torch.device("cuda:0")
 cfg = weights.CONFIGS[cfg_name]
 eng = UNetEngine(cfg, dev, None)      # zero weights are fine for timing shapes
 eng.w.refresh_scalars()
-L = cfg.sample_size if cfg_name.startswith("tiny") else 64
+L = cfg.sample_size
 
 shapes = {}
 orig = ops.gemm_launch
