@@ -18,6 +18,7 @@
 // pass 2 normalised probabilities, which are written to the fp32 map and fed to the PV product.
 #include "common.h"
 #include "../../include/lgd_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -271,14 +272,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 //     is only raised when a row's tile max exceeds it by more than 2^8 (wave-uniform vote), the
 //     row sum is produced by the PV MFMA from a row of ones at V^T row d (ONES, needs d < DP).
 // NDT: 16-row tiles of V^T / O^T actually multiplied (d = 40 with the ones row needs 3, not DP/16 = 4).
-template <int DP, bool ONES, int QT, int NDT = DP / 16>
-__global__ __launch_bounds__(256) void attn_self_kernel(const AttnArgs a) {
+// NW: waves per workgroup (4 or 8).  With 8 waves the K / V^T tile of a key block is staged once for 8 x QT x 16
+// queries, so the per-wave share of the staging loads, the transposing LDS stores and the LDS footprint halves.
+template <int DP, bool ONES, int QT, int NDT = DP / 16, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void attn_self_kernel(const AttnArgs a) {
+  constexpr int NT = 64 * NW;
   constexpr int K_LD = DP + 16;
   constexpr int NDC = DP / 32;
   constexpr int KSEG = DP / 8;
-  constexpr int K_IT = (KV_T * KSEG + 255) / 256;
+  constexpr int K_IT = (KV_T * KSEG + NT - 1) / NT;
   constexpr int V_ITEMS = (KV_T / 2) * KSEG;
-  constexpr int V_IT = (V_ITEMS + 255) / 256;
+  constexpr int V_IT = (V_ITEMS + NT - 1) / NT;
   constexpr int STAGE = KV_T * K_LD + NDT * 16 * VT_LD;
 
   __shared__ __attribute__((aligned(16))) half_t smem[2 * STAGE];
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, c16 = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * (64 * QT) + wid * (16 * QT);
+  const int q0 = blockIdx.x * (16 * QT * NW) + wid * (16 * QT);
   const int d = a.d;
   const half_t* Qb = a.q + (long)b * a.q_bs + (long)h * d;
   const half_t* Kb = a.k + (long)b * a.k_bs + (long)h * d;
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const AttnArgs a) {
 
   // ---- one-time LDS fill: zeros everywhere (padding columns / rows must not hold NaN bit
   // patterns), ones at V^T row d of both stages.
-  for (int i = tid; i < 2 * STAGE / 8; i += 256)
+  for (int i = tid; i < 2 * STAGE / 8; i += NT)
     reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   if (ONES && tid < 2 * VT_LD) {
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const AttnArgs a) {
   bool k_use[K_IT];
 #pragma unroll
   for (int i = 0; i < K_IT; ++i) {
-    const int idx = tid + i * 256;
+    const int idx = tid + i * NT;
     const int row = idx / KSEG, seg = idx - row * KSEG;
     k_use[i] = (idx < KV_T * KSEG) && (seg * 8 < d);
     k_row[i] = row;
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const AttnArgs a) {
   bool v_use[V_IT];
 #pragma unroll
   for (int i = 0; i < V_IT; ++i) {
-    const int idx = tid + i * 256;
+    const int idx = tid + i * NT;
     const int pair = idx & 31, seg = idx >> 5;
     v_use[i] = (idx < V_ITEMS) && (seg * 8 < d);
     v_row[i] = pair * 2;
@@ -579,6 +583,18 @@ void launch_attn_dp(const AttnArgs& a, hipStream_t st) {
     const bool qt2 = (long)((a.Sq + 127) / 128) * a.H * a.B >= 1024 && DP <= 96;
     dim3 grid(qt2 ? (a.Sq + 127) / 128 : (a.Sq + 63) / 64, a.H, a.B);
     if constexpr (DP <= 96) {
+      // 8-wave workgroups (256 queries share each staged K / V^T tile) pay where the head is narrow: measured
+      // +15 % at d = 40 (S = 4096), +4 % at d = 80, -15 % at d = 64 (S = 9216).  LGD_ATTN_NW=4 / 8 overrides (tools).
+      static int nw_env = -1;
+      if (nw_env < 0) { const char* e = getenv("LGD_ATTN_NW"); nw_env = e ? atoi(e) : 0; }
+      const bool nw8 = nw_env ? nw_env == 8 : ((DP == 64 && a.d < 48) || DP == 96);
+      if (qt2 && nw8 && (long)((a.Sq + 255) / 256) * a.H * a.B >= 512) {
+        dim3 g8((a.Sq + 255) / 256, a.H, a.B);
+        if (DP == 64 && a.d < 48) hipLaunchKernelGGL((attn_self_kernel<DP, true, 2, DP == 64 ? 3 : DP / 16, 8>), g8, dim3(512), 0, st, a);
+        else if (a.d < DP) hipLaunchKernelGGL((attn_self_kernel<DP, true, 2, DP / 16, 8>), g8, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((attn_self_kernel<DP, false, 2, DP / 16, 8>), g8, dim3(512), 0, st, a);
+        return;
+      }
       if (qt2) {
         if (DP == 64 && a.d < 48) hipLaunchKernelGGL((attn_self_kernel<DP, true, 2, DP == 64 ? 3 : DP / 16>), grid, dim3(256), 0, st, a);
         else if (a.d < DP) hipLaunchKernelGGL((attn_self_kernel<DP, true, 2>), grid, dim3(256), 0, st, a);

@@ -3,6 +3,8 @@ sandbox): whitespace tokenizer with the Hugging Face call surface the reference 
 (models/models.py:63-89, models/pipelines.py:303-304, utils/guidance.py:10-89) and an embedding-table "encoder".
 Used on both sides of the orchestration goldens: by oracle/make_golden_runs.py (driving the reference's own
 generation/*.run on CPU) and by the GPU tests (driving the drop-in plugins)."""
+import zlib
+
 import numpy as np
 import torch
 
@@ -23,9 +25,14 @@ class FakeTokenizer:
         self.vocab, self.rev = {"<bos>": 0, "<eos>": 1}, {0: "<bos>", 1: "<eos>"}
 
     def _id(self, w):
+        """A word's id is a stable hash of the word (not its order of first appearance): the embeddings of a
+        prompt must not depend on which prompts were tokenised before it."""
         if w not in self.vocab:
-            self.vocab[w] = len(self.vocab)
-            self.rev[self.vocab[w]] = w
+            i = 2 + zlib.crc32(w.encode()) % 2000003
+            while i in self.rev and self.rev[i] != w:
+                i += 1
+            self.vocab[w] = i
+            self.rev[i] = w
         return self.vocab[w]
 
     def _convert_id_to_token(self, i):

@@ -1,36 +1,35 @@
-"""GPU-box tool: times the self-attention forward (and backward) kernels on the benchmark's shapes."""
+"""GPU-box tool: checks (vs fp32 torch, one head slice at a time) and times the self-attention forward kernel on the
+benchmark's shapes.  LGD_ATTN_NW=8 selects the 8-wave workgroup variant (A/B)."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import lgd_amd
 from lgd_amd import ops
 dev = torch.device("cuda:0")
-bwd = "--bwd" in sys.argv
-for (B, H, S, d) in [(8, 8, 4096, 40), (4, 8, 4096, 40), (8, 8, 1024, 80), (8, 8, 256, 160), (8, 8, 64, 160)]:
+print("LGD_ATTN_NW =", os.environ.get("LGD_ATTN_NW", "4"))
+for (B, H, S, Sk, d) in [(16, 8, 4096, 4096, 40), (8, 8, 4096, 4096, 40), (8, 8, 4096, 4126, 40), (16, 8, 1024, 1024, 80),
+                         (16, 8, 1024, 1054, 80), (8, 5, 9216, 9216, 64), (16, 8, 256, 256, 160)]:
     C = H * d
-    qkv = torch.randn(B, S, 3 * C, device=dev).half()
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(B, S, C, generator=g).to(dev).half()
+    k = torch.randn(B, Sk, C, generator=g).to(dev).half()
+    v = torch.randn(B, Sk, C, generator=g).to(dev).half()
     o = torch.empty(B, S, C, device=dev, dtype=torch.float16)
-    lse = torch.empty(B, H, S, device=dev)
-    view = (3 * C, S * 3 * C)
-    f = lambda: ops.attn_fwd(qkv, qkv[:, :, C:], qkv[:, :, 2 * C:], o, B, H, S, S, d, d ** -0.5, lse=lse,
-                             q_view=view, k_view=view, v_view=view)
+    f = lambda: ops.attn_fwd(q, k, v, o, B, H, S, Sk, d, d ** -0.5)
     f(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10): f()
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 100
-    print(f"fwd B{B} H{H} S{S} d{d}: {us:8.1f} us  {4.0 * B * H * S * S * d / us / 1e6:7.1f} TF/s (algorithmic)")
-    if bwd:
-        q, k, v = (torch.randn(B, S, C, device=dev).half() for _ in range(3))
-        go = torch.randn(B, S, C, device=dev).half()
-        ops.attn_fwd(q, k, v, o, B, H, S, S, d, d ** -0.5, lse=lse)
-        gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        delta = torch.empty(B, H, S, device=dev)
-        fb = lambda: ops.attn_bwd(q, k, v, o, go, lse, delta, gq, gk, gv, B, H, S, S, d, d ** -0.5)
-        fb(); torch.cuda.synchronize()
+    err = 0.0
+    for b, h in ((0, 0), (B - 1, H - 1)):
+        sl = slice(h * d, (h + 1) * d)
+        p = (q[b, :, sl].float() @ k[b, :, sl].float().t() * d ** -0.5).softmax(-1)
+        ref = p @ v[b, :, sl].float()
+        err = max(err, float((o[b, :, sl].float() - ref).abs().max() / ref.abs().max()))
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5): fb()
+        for _ in range(10): f()
         e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 200
-        print(f"bwd B{B} H{H} S{S} d{d}: {us:8.1f} us  {10.0 * B * H * S * S * d / us / 1e6:7.1f} TF/s (algorithmic)")
+        ts.append(e0.elapsed_time(e1) * 100)
+    us = sorted(ts)[2]
+    print(f"fwd B{B} H{H} S{S}x{Sk} d{d}: {us:8.1f} us  {4.0 * B * H * S * Sk * d / us / 1e6:7.1f} TF/s (algorithmic)  err {err:.1e}"
+          f"{'' if err < 4e-3 else ' WRONG'}", flush=True)
