@@ -35,6 +35,8 @@ which = os.environ.get("SHAPES", "conv")
 SHAPES = sum(ALL.values(), []) if which == "all" else sum((ALL[w] for w in which.split(",")), [])
 # TILES: comma list of tile codes, each optionally "tile:splits" (tile 0 = the tuning table's choice)
 splits = int(os.environ.get("SPLITS", "1"))
+if os.environ.get("FIRST"):
+    SHAPES = SHAPES[:int(os.environ["FIRST"])]
 tiles = [(int(x.split(":")[0]), int(x.split(":")[1]) if ":" in x else splits)
          for x in os.environ.get("TILES", "22,33").split(",")]
 rounds = int(os.environ.get("ROUNDS", "5"))
