@@ -429,3 +429,38 @@ def test_guidance_keys_in_any_order(dev):
         res.append(tr[0])
     assert abs(res[0]["loss"] - res[1]["loss"]) < 1e-4 * abs(res[0]["loss"])
     assert cosine(res[0]["grad"], res[1]["grad"]) > 0.9999
+
+
+def test_rccl_backend_collectives_single_rank(dev):
+    """The N > 1 path uses torch.distributed's "nccl" backend (= RCCL on ROCm) for the weight-arena broadcast and the
+    timing / counter reductions.  Only 1-GPU boxes exist in the build sessions, so the real backend is exercised here
+    with a world of one rank (rendezvous on 127.0.0.1, device tensors through RCCL); the world-size-2 logic is
+    covered with gloo on CPU (tests/test_dist_cpu.py)."""
+    import socket
+    import torch.distributed as dist
+    from lgd_amd import dist as ldist
+    from lgd_amd.weightstore import WeightStore
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    try:
+        ldist.init(backend="nccl")
+        assert dist.get_backend() == "nccl" and ldist.world() == 1
+        ws = WeightStore(weights.CONFIGS["tiny_gligen"], dev)
+        ws.load_state_dict(weights.synth_state_dict(weights.CONFIGS["tiny_gligen"], 0))
+        before = (float(ws.arena16.float().abs().sum()), float(ws.arena32.abs().sum()))
+        for arena in (ws.arena16, ws.arena32):                    # what broadcast_weights does per chunk
+            dist.broadcast(arena, src=0)
+        torch.cuda.synchronize()
+        assert (float(ws.arena16.float().abs().sum()), float(ws.arena32.abs().sum())) == before
+        assert ldist.max_over_ranks(1.25) == 1.25 and ldist.sum_over_ranks(3.0) == 3.0
+        assert ldist.gather_floats(7.5) == [7.5]
+        ldist.barrier()
+    finally:
+        ldist.shutdown()
+        for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE"):
+            os.environ.pop(k, None)

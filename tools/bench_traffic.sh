@@ -31,7 +31,7 @@ for k, v in j.items():
     e = out.setdefault(n, dict(read=0.0, write=0.0, launches=0))
     e["read"] += rd * ln; e["write"] += wr * ln; e["launches"] += ln
 res = dict(method="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over "
-                  "`bench.py --steps 1 --warmup 0 --num-inference-steps 2 --layouts 4 --no-decode` (the default run's batch "
+                  "'bench.py --steps 1 --warmup 0 --num-inference-steps 2 --layouts 4 --no-decode' (the default run's batch "
                   "shapes); FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE as reported; averages over "
                   "all launches of a kernel",
            kernels={n: dict(hbm_bytes_per_launch=round((e["read"] + e["write"]) / e["launches"]),
