@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LGD_ABI_VERSION 2
+#define LGD_ABI_VERSION 3
 int lgd_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -207,6 +207,30 @@ int lgd_axpy_f32(const float* g, float* x, const float* coef_table, const int32_
 /* copy row `*idx` (device int32) of a [T][n] fp32 table into out[n] — per-step time-embedding
  * bias of every resnet without changing any kernel argument (graph-replay friendly). */
 int lgd_select_row_f32(const float* table, const int32_t* idx, float* out, int n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SAM mask refinement (models/sam.py:25-55 -> [ext] transformers SamModel): pieces of the ViT image encoder and the
+ * mask decoder that are not GEMM / LayerNorm / attention calls above.
+ * ------------------------------------------------------------------------------------------- */
+#define LGD_ACT_GELU 1 /* exact (erf) GELU: SamMLPBlock of the image encoder, mask-decoder upscaling */
+#define LGD_ACT_RELU 2 /* SamMLPBlock / SamFeedForward of the mask decoder */
+/* y = act(x), fp16, n % 8 == 0. */
+int lgd_act_f16(const void* x, void* y, int64_t n, int mode, void* stream);
+/* Window partition + decomposed relative-position bias of SamVisionAttention, folded into the attention operands.
+ * qkv [B*Hs*Ws][3*NH*d] fp16 (fused projection, raster token order), qkv_bias fp32 [3*NH*d] (value of the zero-padded
+ * window positions), rel_h / rel_w fp32 [2*S-1][d] with S = window (window > 0: ceil(Hs/S) x ceil(Ws/S) windows,
+ * padded) or S = Hs = Ws (window == 0: global attention).  Writes qa / ka / va [B*nwin*S*S][NH*DA] fp16,
+ *   qa = [q | q.Rh[qy-j+S-1]/scale, j<S | q.Rw[qx-j+S-1]/scale, j<S | 0],  ka = [k | onehot(ky) | onehot(kx) | 0],
+ *   va = [v | 0],   DA >= d + 2*S, DA % 8 == 0,
+ * so that lgd_attn_fwd_f16(qa, ka, va, d = DA, scale) computes softmax(scale*q.k + rel_h + rel_w) v in columns 0..d-1
+ * of every head. */
+int lgd_sam_relpos_qkv_f16(const void* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, int B,
+                           int Hs, int Ws, int window, int NH, int d, int DA, float scale, void* qa, void* ka,
+                           void* va, void* stream);
+/* Inverse gather (SamVisionLayer.window_unpartition): oa [B*nwin*S*S][NH*DA] in window order -> out [B*Hs*Ws][NH*d]
+ * in raster order, padding positions and the DA-d extra columns dropped. */
+int lgd_sam_window_merge_f16(const void* oa, void* out, int B, int Hs, int Ws, int window, int NH, int d, int DA,
+                             void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Cross-attention energy of LMD / LMD+ and its gradient on the probability maps, one launch for

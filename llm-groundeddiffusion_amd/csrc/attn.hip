@@ -478,7 +478,9 @@ __global__ __launch_bounds__(64 * NW) void attn_self_kernel(const AttnArgs a) {
           const float m_abs = mxs[qt] + m_old;
           const float m_new = (float)(half_t)(t == 0 ? m_abs : fmaxf(m_old, m_abs));
           const float shift = m_new - m_old;
-          const float alpha = __builtin_amdgcn_exp2f(-shift);
+          // first tile: the accumulators are still zero and the shift is the absolute reference, which may be far
+          // below -128 (exp2 -> +inf, 0 * inf = NaN): nothing to rescale
+          const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-shift);
 #pragma unroll
           for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -616,6 +618,7 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
   else if (d <= 96) launch_attn_dp<96, SAVE_P>(a, st);
   else if (d <= 128) launch_attn_dp<128, SAVE_P>(a, st);
   else if (d <= 160) launch_attn_dp<160, SAVE_P>(a, st);
+  else if (d <= 192) launch_attn_dp<192, SAVE_P>(a, st);  // SAM global attention: 64 + 2 x 64 bias columns
   else return LGD_ERR_UNSUPPORTED;
   return lgd_check_launch();
 }

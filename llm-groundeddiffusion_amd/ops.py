@@ -382,6 +382,34 @@ def quick_gelu(x, out=None):
     return out
 
 
+ACT_GELU, ACT_RELU = 1, 2
+
+
+def act(x, mode, out=None):
+    """Exact GELU / ReLU on an fp16 tensor (SAM encoder and mask-decoder MLPs)."""
+    if out is None:
+        out = torch.empty_like(x)
+    _call("lgd_act_f16", _p(x), _p(out), x.numel(), int(mode), _stream())
+    return out
+
+
+def sam_relpos_qkv(qkv, qkv_bias, rel_h, rel_w, B, Hs, Ws, window, NH, d, DA, scale):
+    """Window partition + decomposed rel-pos bias folded into the attention operands (csrc/sam.hip).
+    Returns qa, ka, va [B*nwin*S*S, NH*DA] fp16."""
+    S = window or Hs
+    rows = B * (-(-Hs // S)) * (-(-Ws // S)) * S * S
+    qa, ka, va = (torch.empty((rows, NH * DA), device=qkv.device, dtype=F16) for _ in range(3))
+    _call("lgd_sam_relpos_qkv_f16", _p(qkv), _p(qkv_bias), _p(rel_h), _p(rel_w), B, Hs, Ws, window, NH, d, DA,
+          float(scale), _p(qa), _p(ka), _p(va), _stream())
+    return qa, ka, va
+
+
+def sam_window_merge(oa, B, Hs, Ws, window, NH, d, DA):
+    out = torch.empty((B * Hs * Ws, NH * d), device=oa.device, dtype=F16)
+    _call("lgd_sam_window_merge_f16", _p(oa), _p(out), B, Hs, Ws, window, NH, d, DA, _stream())
+    return out
+
+
 def cross_attn_bwd(q, k, v, go, gp, gq, B, H, Sq, Sk, d, scale, *, q_view=None, k_view=None,
                    v_view=None, go_view=None, gq_view=None):
     dq_ = (H * d, Sq * H * d)
