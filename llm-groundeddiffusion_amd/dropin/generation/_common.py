@@ -101,6 +101,17 @@ def build_layout(spec, bg_seed, fg_seed_start, so_negative_prompt, overall_negat
                         bg_seed=bg_seed, fg_seed_start=fg_seed_start)
 
 
+def sam_refiner(model_dict, height, width, **kw):
+    """The SAM mask refiner of the plugin when `model_dict` carries a SAM model (generate.py:126-127 merges
+    `sam.load_sam()` into it), else None = box masks."""
+    has = ("sam_model" in model_dict) if isinstance(model_dict, dict) else hasattr(model_dict, "sam_model")
+    if not has:
+        return None
+    from lgd_amd.sam_refine import SamRefiner
+    md = model_dict if isinstance(model_dict, dict) else vars(model_dict)
+    return SamRefiner(dict(sam_model=md["sam_model"], sam_processor=md["sam_processor"]), height=height, width=width, **kw)
+
+
 class EasyDict(dict):
     __getattr__ = dict.__getitem__
     __setattr__ = dict.__setitem__

@@ -2,7 +2,7 @@
 import models
 from lgd_amd.pipeline import DEFAULT_MAX_ITER, lmd_generate
 
-from ._common import DEFAULT_OVERALL_NEGATIVE_PROMPT, DEFAULT_SO_NEGATIVE_PROMPT, EasyDict, build_layout
+from ._common import DEFAULT_OVERALL_NEGATIVE_PROMPT, DEFAULT_SO_NEGATIVE_PROMPT, EasyDict, build_layout, sam_refiner
 
 version = "lmd"
 height = width = 512
@@ -20,12 +20,16 @@ def run(spec, bg_seed=1, overall_prompt_override="", fg_seed_start=20, frozen_st
         so_floor_padding=0.2, use_box_input=False, use_ref_ca=True, use_autocast=False, verbose=False):
     """Argument names and defaults of generation/lmd.py:215-256 (incl. so_center_box=True /
     align_with_overall_bboxes=True: per-box generations run on a centred box, histories, masks and
-    reference maps are shifted back onto the overall boxes before composition).  SAM-only arguments
-    (`mask_th_for_point`, `use_box_input`) are accepted and unused: masks are the box masks."""
+    reference maps are shifted back onto the overall boxes before composition).  When `models.model_dict` carries
+    a SAM model (generate.py:126-127 `model_dict.update(sam.load_sam())`) every per-box mask is SAM's refinement of the
+    object token's attention map (generation/lmd.py:124-149) with `mask_th_for_point` / `use_box_input`; otherwise the
+    masks are the box masks."""
     if num_inference_steps <= 10:
         # the reference crashes here too (attn_aggregation_step_start=10, generation/lmd.py:36,124-131)
         print("note: the reference's SAM point prompt aggregates maps from step 10 on; with <=10 steps it would fail")
     sm = models.model_dict.sampler
+    refiner = sam_refiner(models.model_dict, height, width, discourage_mask_below_coarse_iou=0.25,
+                          use_box_input=use_box_input, mask_th_for_point=mask_th_for_point, verbose=verbose)
     lay = build_layout(spec, bg_seed, fg_seed_start, so_negative_prompt, overall_negative_prompt, height, width,
                        overall_prompt_override, verbose)
     out = lmd_generate(sm, lay, num_inference_steps=num_inference_steps, frozen_step_ratio=frozen_step_ratio,
@@ -39,5 +43,6 @@ def run(spec, bg_seed=1, overall_prompt_override="", fg_seed_start=20, frozen_st
                        height=height, width=width, use_fast_schedule=use_fast_schedule,
                        so_center_box=so_center_box, so_horizontal_center_only=so_horizontal_center_only,
                        so_vertical_placement=so_vertical_placement, so_floor_padding=so_floor_padding,
-                       align_with_overall_bboxes=align_with_overall_bboxes, horizontal_shift_only=horizontal_shift_only)
+                       align_with_overall_bboxes=align_with_overall_bboxes, horizontal_shift_only=horizontal_shift_only,
+                       mask_refiner=refiner)
     return EasyDict(image=out["image"], so_img_list=out["so_images"])

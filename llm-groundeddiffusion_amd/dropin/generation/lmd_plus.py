@@ -4,7 +4,7 @@ generate.py imports this module after `models.model_dict` is set (generate.py:11
 import models
 from lgd_amd.pipeline import DEFAULT_MAX_ITER, lmd_plus_generate
 
-from ._common import DEFAULT_OVERALL_NEGATIVE_PROMPT, DEFAULT_SO_NEGATIVE_PROMPT, EasyDict, build_layout
+from ._common import DEFAULT_OVERALL_NEGATIVE_PROMPT, DEFAULT_SO_NEGATIVE_PROMPT, EasyDict, build_layout, sam_refiner
 
 version = "lmd_plus"
 height = width = 512
@@ -23,6 +23,7 @@ def run(spec, bg_seed=1, overall_prompt_override="", fg_seed_start=20, frozen_st
     """Argument names and defaults of generation/lmd_plus.py:193-228.  `use_autocast` is accepted for
     compatibility: the HIP path always computes fp16 with fp32 accumulation."""
     sm = models.model_dict.sampler
+    refiner = sam_refiner(models.model_dict, height, width, discourage_mask_below_coarse_iou=0.25, verbose=verbose)
     lay = build_layout(spec, bg_seed, fg_seed_start, so_negative_prompt, overall_negative_prompt, height, width,
                        overall_prompt_override, verbose)
     print("Key generation settings:", spec, bg_seed, fg_seed_start, frozen_step_ratio,
@@ -40,5 +41,5 @@ def run(spec, bg_seed=1, overall_prompt_override="", fg_seed_start=20, frozen_st
                             use_ref_ca=use_ref_ca, height=height, width=width, use_fast_schedule=use_fast_schedule,
                             so_center_box=so_center_box, so_horizontal_center_only=so_horizontal_center_only,
                             align_with_overall_bboxes=align_with_overall_bboxes,
-                            horizontal_shift_only=horizontal_shift_only)
+                            horizontal_shift_only=horizontal_shift_only, mask_refiner=refiner)
     return EasyDict(image=out["image"], so_img_list=out["so_images"])

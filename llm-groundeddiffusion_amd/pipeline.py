@@ -5,7 +5,8 @@ training-free LMD (generation/lmd.py:215-551) and the backward-guidance baseline
 "Cached layout" = everything stage 1 and the text encoder produce for a prompt, computed ahead of
 the hot path: boxes, CLIP hidden states of the per-box / overall / negative
 prompts, pooled phrase embeddings for GLIGEN, token positions of the phrases.  SAM mask refinement
-(models/sam.py, out of scope: §8f rank 2) is replaced by the box mask `proportion_to_mask`.
+(models/sam.py, §8f rank 2) runs when a `mask_refiner` (lgd_amd.sam_refine.SamRefiner over the HIP SAM model) is passed;
+without one — benchmarks, no SAM weights — the box mask `proportion_to_mask` stands in.
 """
 import math
 from dataclasses import dataclass, field
@@ -132,6 +133,30 @@ def _align_stage_a(d, lay, keys, align_with_overall_bboxes, horizontal_shift_onl
             saved[k] = m.flatten(3, 4)
 
 
+def _token_attn(saved, start):
+    """utils/attn.py:9-38 (get_token_attnv2 with input_ca_has_condition_only, one saved token): mean over heads and over
+    the steps from `start` on of the object token's map at OBJ_ATTN_KEY -> numpy [side, side]."""
+    m = saved[OBJ_ATTN_KEY][start:, 0, :, :, 0]
+    if m.shape[0] == 0:
+        raise RuntimeError(f"no saved attention at or after step {start}")
+    mean = m.float().mean(dim=(0, 1))
+    side = int(round(mean.numel() ** 0.5))
+    return mean.reshape(side, side).cpu().numpy()
+
+
+def _so_mask(refiner, kind, image, box, L, token_attn=None):
+    """Foreground mask of one single-object generation on the latent grid.  With a `mask_refiner`
+    (lgd_amd.sam_refine.SamRefiner) it is SAM's refinement of the decoded image, prompted by the layout box (LMD+,
+    generation/lmd_plus.py:122-130) or by the object token's attention map (LMD, generation/lmd.py:124-149); without one
+    it is the box itself — the stand-in SURVEY.md §8d prescribes for benchmarks without SAM weights."""
+    if refiner is None:
+        return proportion_to_mask(box, L, L).bool()
+    if image is None:
+        raise RuntimeError("mask refinement needs the decoded single-object images (decode=True)")
+    mask, _conf = refiner.box(image, box) if kind == "box" else refiner.attn(image, token_attn)
+    return torch.as_tensor(mask).bool()
+
+
 def lmd_plus_generate(sampler: LMDSampler, lay: CachedLayout, **kw):
     """LMD+ for one layout (generation/lmd_plus.py:193-520 with its default arguments)."""
     return lmd_plus_generate_batch(sampler, [lay], **kw)[0]
@@ -146,7 +171,7 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
                             overall_bg_weight=4.0, ref_ca_loss_weight=2.0, fg_blending_ratio=0.1,
                             use_ref_ca=True, height=512, width=512, decode=True, guidance_attn_keys=None,
                             use_fast_schedule=False, so_center_box=False, so_horizontal_center_only=True,
-                            align_with_overall_bboxes=False, horizontal_shift_only=True):
+                            align_with_overall_bboxes=False, horizontal_shift_only=True, mask_refiner=None):
     """LMD+ (generation/lmd_plus.py:193-520; per-box attention guidance is off by default there,
     max_index_step=0, :203 — with max_index_step > 0 every per-box GLIGEN generation is guided on its own box with
     the energy's default weights, lmd_plus.py:320-328) for a batch of independent layouts: the per-box generations of ALL layouts run
@@ -193,7 +218,7 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
         d = per_lay[li]
         d["latents_all"].append(r["latents_all"])
         d["saved"].append(r["saved"])
-        d["masks"].append(proportion_to_mask(so_boxes[li][i], L, L).bool())   # SAM stand-in
+        d["masks"].append(_so_mask(mask_refiner, "box", imgs[n] if decode else None, so_boxes[li][i], L))
         if decode:
             d["so_images"].append(imgs[n:n + 1])
     # ---- composition (lmd_plus.py:398-416) and stage B: overall generation with attention guidance
@@ -244,7 +269,8 @@ def lmd_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, num_inf
                        overall_bg_weight=4.0, ref_ca_loss_weight=2.0, fg_blending_ratio=0.01, use_ref_ca=True,
                        height=512, width=512, decode=True, guidance_attn_keys=None, use_fast_schedule=False,
                        so_center_box=False, so_horizontal_center_only=False, so_vertical_placement="floor_padding",
-                       so_floor_padding=0.2, align_with_overall_bboxes=False, horizontal_shift_only=False):
+                       so_floor_padding=0.2, align_with_overall_bboxes=False, horizontal_shift_only=False,
+                       mask_refiner=None, attn_aggregation_step_start=10):
     """Training-free LMD (generation/lmd.py:215-551) for a batch of independent layouts: per-box stage =
     generate_semantic_guidance WITH guidance (lmd.py:340-352), all boxes of all layouts in one batched
     denoising call (each image keeps its own guidance loop exit); overall stage = generate_partial_frozen
@@ -284,7 +310,8 @@ def lmd_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, num_inf
         d = per_lay[li]
         d["latents_all"].append(r["latents_all"])
         d["saved"].append(r["saved"])
-        d["masks"].append(proportion_to_mask(so_boxes[li][i], L, L).bool())   # SAM stand-in
+        d["masks"].append(_so_mask(mask_refiner, "attn", imgs[n] if decode else None, so_boxes[li][i], L,
+                                  token_attn=_token_attn(r["saved"], attn_aggregation_step_start) if mask_refiner else None))
         if decode:
             d["so_images"].append(imgs[n:n + 1])
     # ---- alignment (latents.py:107-118), composition, stage B

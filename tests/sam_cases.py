@@ -56,3 +56,47 @@ def inputs(cfg, B=1, P=2, seed=1, points=False):
     else:
         out["input_boxes"] = torch.cat([lo, hi], dim=-1)
     return out
+
+
+def refine_config(transformers):
+    """facebook/sam-vit-base geometry everywhere the processor and the decoder see it (1024^2 input, 64x64 tokens,
+    14x14 windows, 256-channel embeddings, default prompt encoder / mask decoder) with a 2-block, 64-wide vision tower
+    so that the reference's CPU run of it (oracle/make_golden_sam.py) takes seconds."""
+    v = transformers.SamVisionConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=2, global_attn_indexes=[1],
+                                     mlp_dim=128)
+    return transformers.SamConfig(vision_config=v)
+
+
+def build_refine_hf(transformers, seed=0):
+    """build_hf(refine_config) with the mask logits shifted down by a different constant per mask token: channel 0 of the
+    upscaled embedding is made the constant GELU(4) and every hyper-network emits a fixed negative weight for it.  With
+    plain random parameters the logits are sign-symmetric noise, every candidate covers the whole latent grid after the
+    reference's `interpolate(...).bool()`, and the selection rules would have nothing to select."""
+    model = build_hf(transformers, refine_config(transformers), seed)
+    md = model.mask_decoder
+    with torch.no_grad():
+        md.upscale_conv2.weight[:, 0].zero_()
+        md.upscale_conv2.bias[0] = 4.0
+        for i, mlp in enumerate(md.output_hypernetworks_mlps):
+            mlp.proj_out.weight[0].zero_()
+            mlp.proj_out.bias[0] = -0.25 * (0.2 + 0.15 * i)
+    return model
+
+
+def refine_inputs():
+    """Two synthetic 512x512 uint8 images (smooth blobs) with layout boxes (x0, y0, x1, y1 proportions) and a smooth
+    64x64 'cross-attention' map per box."""
+    import numpy as np
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(7)
+    low = torch.rand(2, 3, 16, 16, generator=g)
+    imgs = (F.interpolate(low, size=(512, 512), mode="bicubic", align_corners=False).clamp(0, 1) * 255).round().byte()
+    images = [im.permute(1, 2, 0).numpy() for im in imgs]
+    boxes = [[(0.10, 0.20, 0.55, 0.70), (0.50, 0.35, 0.95, 0.90)], [(0.25, 0.10, 0.80, 0.60), (0.05, 0.55, 0.45, 0.98)]]
+    attn = []
+    yy, xx = np.mgrid[0:64, 0:64] / 64.0
+    for per_image in boxes:
+        for (x0, y0, x1, y1) in per_image:
+            cx, cy, sx, sy = (x0 + x1) / 2, (y0 + y1) / 2, (x1 - x0) / 3, (y1 - y0) / 3
+            attn.append(np.exp(-((xx - cx) / sx) ** 2 - ((yy - cy) / sy) ** 2).astype(np.float32))
+    return images, boxes, attn

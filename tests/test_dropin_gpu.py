@@ -72,6 +72,57 @@ def test_plugin_run_contract(dropin):
     assert out.image.shape == (512, 512, 3) and out.image.dtype == np.uint8
 
 
+def test_plugins_refine_masks_with_sam_when_the_model_dict_carries_it(dropin, dev):
+    """generate.py:126-127 merges `sam.load_sam()` into models.model_dict; the plugins then refine every per-box mask with
+    SAM (generation/lmd_plus.py:122-130 box prompt, generation/lmd.py:124-149 attention-map point prompt).  Also checks the
+    hook itself: a refiner that returns the box mask reproduces the run without a refiner bit for bit."""
+    transformers = pytest.importorskip("transformers")
+    import sam_cases
+    from lgd_amd import sam_refine
+    from lgd_amd.hostprep import proportion_to_mask
+    from models import sam as dsam
+    import generation.lmd_plus as g
+    import generation.lmd as gl
+    spec = dict(prompt="A realistic image of a white deer and a gray bear in an empty factory scene",
+                gen_boxes=[("a white deer", [37, 88, 91, 117]), ("a gray bear", [157, 96, 94, 108])],
+                bg_prompt="A realistic image of an empty factory scene", extra_neg_prompt="")
+    g.height = g.width = gl.height = gl.width = 256
+    kw = dict(bg_seed=3, fg_seed_start=11, num_inference_steps=6, overall_max_index_step=3, overall_loss_threshold=0.0)
+    plain = g.run(spec, **kw)
+    calls = []
+    box_fn, attn_fn = sam_refine.SamRefiner.box, sam_refine.SamRefiner.attn
+
+    def rec_box(self, image, box):
+        m, c = box_fn(self, image, box)
+        calls.append(("box", image.shape, np.asarray(m).shape, np.asarray(m).dtype))
+        return m, c
+
+    def rec_attn(self, image, token_attn):
+        m, c = attn_fn(self, image, token_attn)
+        calls.append(("attn", image.shape, token_attn.shape, np.asarray(m).shape))
+        return m, c
+    md = dropin.model_dict
+    try:
+        sam_refine.SamRefiner.box, sam_refine.SamRefiner.attn = rec_box, rec_attn
+        md.update(dsam.wrap_sam(sam_cases.build_refine_hf(transformers), device=dev))
+        out = g.run(spec, **kw)
+        assert out.image.shape == (256, 256, 3)
+        assert calls == [("box", (256, 256, 3), (32, 32), np.dtype(bool))] * 2
+        calls.clear()
+        out = gl.run(spec, bg_seed=3, fg_seed_start=99, num_inference_steps=12, max_index_step=3, overall_max_index_step=3,
+                     so_center_box=False, align_with_overall_bboxes=False)
+        assert out.image.shape == (256, 256, 3)
+        assert calls == [("attn", (256, 256, 3), (8, 8), (32, 32))] * 2       # the map of ("down", 2, 1, 0): latent side / 4
+        # the hook alone: box masks through the refiner interface == no refiner
+        sam_refine.SamRefiner.box = lambda self, image, box: (proportion_to_mask(box, 32, 32, return_np=True).astype(bool), 1.0)
+        same = g.run(spec, **kw)
+        assert np.array_equal(same.image, plain.image)
+    finally:
+        sam_refine.SamRefiner.box, sam_refine.SamRefiner.attn = box_fn, attn_fn
+        md.pop("sam_model", None)
+        md.pop("sam_processor", None)
+
+
 def test_phrase_indices_and_energy_hook(dropin, dev):
     from utils import guidance
     tok = dropin.model_dict.tokenizer

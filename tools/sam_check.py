@@ -10,8 +10,9 @@ dev = torch.device("cuda:0")
 def relerr(a, b):
     a, b = a.float().cpu(), b.float().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
-for name, cfg, B, P in (("small", sam_cases.small_config(transformers), 2, 2), ("vit_base", transformers.SamConfig(), 1, 2)):
-    for points in (False, True):
+CASES = (("small", sam_cases.small_config(transformers), 2, 2), ("vit_base", transformers.SamConfig(), 1, 2))
+for name, cfg, B, P in [c for c in CASES if os.environ.get("ONLY", c[0]) == c[0]]:
+    for points in ((False,) if os.environ.get("ONLY") else (False, True)):
         hf = sam_cases.build_hf(transformers, cfg)
         inp = sam_cases.inputs(cfg, B=B, P=P, points=points)
         mine = lsam.HipSamModel(lsam.SamConfig.from_hf(cfg), hf.state_dict(), device=dev)
