@@ -630,7 +630,7 @@ __device__ __forceinline__ void wait_frags(half8_t (&a)[NA], half8_t (&b)[NB]) {
 // weight layout's (tap, channel): the nine taps of one 64-channel chunk touch the same 6 x 66 pixel halo of
 // the input, 1/5..1/20 of the map's bytes, so the re-reads hit the XCD's L2 instead of falling out of it
 // between taps (the weight rows are simply visited in a different order; partial sums are order-free).
-template <int MI, int NI, int WM, int WN, int NS, bool CM, int ABL = 0>
+template <int MI, int NI, int WM, int WN, int NS, bool CM, bool PERSIST = false, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs ga) {
   constexpr int NW = WM * WN;
   static_assert(NW == 8, "eight waves");
@@ -659,15 +659,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
   const int wm = wid / WN, wn = wid - wm * WN;
 
   const int n_tiles_n = (d.N + BN - 1) / BN;
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x;
-    const int q = nwg >> 3, r = nwg & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tile_m = bid / n_tiles_n;
-  const int tile_n = bid - tile_m * n_tiles_n;
+  // PERSISTENT TILE LOOP: the launcher may start fewer workgroups than output tiles; workgroup b then computes
+  // tiles b, b + gridDim.x, ... and keeps its DMA ring running across tile boundaries: the first D K tiles of the
+  // next output tile are fetched while the last K tiles of the current one are multiplied and its epilogue runs,
+  // so only the first tile of a workgroup pays the pipeline-fill latency.  (With gridDim.x == number of tiles this
+  // is the one-tile-per-workgroup kernel.)  Consecutive workgroup ids land on consecutive XCDs, and b + i*gridDim.x
+  // keeps b's XCD when gridDim.x % 8 == 0, so the XCD-contiguous tile remap below holds for every tile of a workgroup.
+  const int total_tiles = ((d.M + BM - 1) / BM) * n_tiles_n;
+  auto tile_origin = [&](int v, int& m0_, int& n0_) {
+    const int q = total_tiles >> 3, r = total_tiles & 7;
+    const int xcd = v & 7, idx = v >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tile_m = bid / n_tiles_n;
+    m0_ = tile_m * BM;
+    n0_ = (bid - tile_m * n_tiles_n) * BN;
+  };
   const int zz = blockIdx.z;
   const int batch = zz / d.splits;
   const int split = zz - batch * d.splits;
@@ -677,7 +683,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
   const long c_off = b_o * d.c_bs_o + b_i * d.c_bs_i;
   const long r_off = b_o * d.r_bs_o + b_i * d.r_bs_i;
 
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int k_beg = split * ga.k_per_split;
   int k_end = k_beg + ga.k_per_split;
   if (k_end > d.K) k_end = d.K;
@@ -697,15 +702,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
   const bool conv = d.taps == 9;
   // K position of the next tile to issue.  Tap-major: (tap0, ch0) follow the weight layout.  Chunk-major:
   // tile t of the split's range is (chunk = t / 9, tap = t % 9).
-  int tap0, ch0;
-  if (CM) { const int t = k_beg / BK; ch0 = (t / 9) * BK; tap0 = t - (t / 9) * 9; }
-  else { tap0 = conv ? k_beg / cin : 0; ch0 = k_beg - tap0 * cin; }
+  int tap0 = 0, ch0 = 0;
   int kt_issue = 0;
 
   int a_iy0[A_IT], a_ix0[A_IT];   // tap-major conv: top-left input coordinate of the 3x3 window
   long a_row[A_IT];               // tap-major: first row of the image (conv) / row index (plain)
   const half_t* a_cen[A_IT];      // chunk-major: pointer to the window's centre pixel, this lane's segment
   int a_mask[A_IT];               // chunk-major: bit `tap` set = that tap's pixel lies inside the image
+  // the half-masked instruction: waves 2g and 2g+1 fill rows 0-3 / 4-7 of group 8*B_FULL + g
+  const int b_grp_last = B_FULL * NW + (wid >> 1);
+  const bool b_half_on = (lane >> 5) == (wid & 1);
+  const half_t* w_row[B_IT];
+  // issue side of one output tile: K walk back to the start of the split's range, row pointers of the tile
+  auto setup_issue = [&](int m0, int n0) {
+  if (CM) { const int t = k_beg / BK; ch0 = (t / 9) * BK; tap0 = t - (t / 9) * 9; }
+  else { tap0 = conv ? k_beg / cin : 0; ch0 = k_beg - tap0 * cin; }
+  kt_issue = 0;
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     int m = m0 + (i * NW + wid) * 8 + lrow;
@@ -733,10 +745,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
       }
     }
   }
-  // the half-masked instruction: waves 2g and 2g+1 fill rows 0-3 / 4-7 of group 8*B_FULL + g
-  const int b_grp_last = B_FULL * NW + (wid >> 1);
-  const bool b_half_on = (lane >> 5) == (wid & 1);
-  const half_t* w_row[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
     const bool last = B_HALF && i == B_FULL;
@@ -747,6 +755,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
     if (n >= d.N) n = d.N - 1;
     w_row[i] = W + (long)n * d.ldw + (CM ? tap0 * cin + ch0 : k_beg) + ks * 8;
   }
+  };
 
   const half_t* a_ptr[A_IT];
   bool a_ok[A_IT];
@@ -872,47 +881,97 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
     if (cnt == 0) mma_range(af, bf, 0, NMMA);
   };
 
+  // the issue side runs D K tiles ahead of the MFMA side and crosses into the workgroup's next output tile on its
+  // own: `begin_k_tile` is called before each K tile is issued
+  int v_issue = blockIdx.x;
+  bool issue_dead = false;           // nothing left to fetch: the remaining ring slots are fed from the zero line
+  auto begin_k_tile = [&]() {
+    if constexpr (!PERSIST) {
+      issue_dead = kt_issue >= nk;     // one tile per workgroup: nothing behind the last K tile
+      return;
+    }
+    if (kt_issue >= nk && !issue_dead) {
+      v_issue += gridDim.x;
+      if (v_issue < total_tiles) {
+        int m0n, n0n;
+        tile_origin(v_issue, m0n, n0n);
+        setup_issue(m0n, n0n);
+        if (CM) cm_offset(); else derive();
+      } else {
+        issue_dead = true;
+      }
+    }
+  };
+
   if (nk > 0) {
-    // ---- prologue: tiles 0..D-1 in flight, tile 0 landed, its first fragments requested
+    int m0, n0;
+    tile_origin(blockIdx.x, m0, n0);
+    setup_issue(m0, n0);
+    // ---- prologue: K tiles 0..D-1 in flight, tile 0 landed, its first fragments requested
     if (CM) cm_offset(); else derive();
 #pragma unroll
     for (int t = 0; t < D; ++t) {
+      begin_k_tile();
 #pragma unroll
-      for (int j = 0; j < T_DMA; ++j) issue_one(j, t * STAGE, t < nk);
+      for (int j = 0; j < T_DMA; ++j) issue_one(j, t * STAGE, !issue_dead);
       advance();
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * T_DMA) : "memory");
     __builtin_amdgcn_s_barrier();
     lds_read_frags<0, FSTR>(af0, a_b0, seqA{});
     lds_read_frags<0, FSTR>(bf0, b_b0, seqB{});
-    // byte offsets of the stages of tile kt, tile kt+1 and of the tile being issued (kt+D)
+    // byte offsets of the stages of K tile kt, kt+1 and of the one being issued (kt+D); the ring keeps turning
+    // across output tiles
     unsigned so_cur = 0, so_nxt = STAGE_B, so_iss = D * STAGE_B;
     auto next_stage = [](unsigned x) { x += STAGE_B; return x == NS * STAGE_B ? 0u : x; };
-    for (int kt = 0; kt < nk; ++kt) {
-      const bool live = kt + D < nk;
-      wait_frags<-1>(af0, bf0);                                  // frags(kt, half 0)
-      if constexpr (!(ABL & 2)) {
-        lds_read_frags<0, FSTR>(af1, a_b1 + so_cur, seqA{});     // frags(kt, half 1)
-        lds_read_frags<0, FSTR>(bf1, b_b1 + so_cur, seqB{});
+    auto k_loop = [&]() {
+      for (int kt = 0; kt < nk; ++kt) {
+        begin_k_tile();
+        const bool live = !issue_dead;
+        wait_frags<-1>(af0, bf0);                                  // frags(kt, half 0)
+        if constexpr (!(ABL & 2)) {
+          lds_read_frags<0, FSTR>(af1, a_b1 + so_cur, seqA{});     // frags(kt, half 1)
+          lds_read_frags<0, FSTR>(bf1, b_b1 + so_cur, seqB{});
+        }
+        dma_and_mma(0, T1, so_iss, live, af0, bf0);                // first part of K tile kt+D beside k-half 0
+        // K tile kt+1 landed (own share: tiles kt+2..kt+D-1 and the T1 instructions just issued may be in
+        // flight; stores of a previous epilogue only make the count more conservative); own reads retired
+        wait_frags<(D - 2) * T_DMA + T1>(af1, bf1);
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
+        if constexpr (!(ABL & 2)) {
+          lds_read_frags<0, FSTR>(af0, a_b0 + so_nxt, seqA{});     // frags(kt+1, half 0) — of the next output tile
+          lds_read_frags<0, FSTR>(bf0, b_b0 + so_nxt, seqB{});     // after the last K tile
+        }
+        dma_and_mma(T1, T2, so_iss, live, af1, bf1);               // rest of K tile kt+D beside k-half 1
+        advance();
+        so_cur = so_nxt; so_nxt = next_stage(so_nxt); so_iss = next_stage(so_iss);
       }
-      dma_and_mma(0, T1, so_iss, live, af0, bf0);                // first part of tile kt+D beside k-half 0
-      // tile kt+1 landed (own share: tiles kt+2..kt+D-1 and the T1 instructions just issued may be in flight);
-      // own reads retired
-      wait_frags<(D - 2) * T_DMA + T1>(af1, bf1);
-      if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
-      if constexpr (!(ABL & 2)) {
-        lds_read_frags<0, FSTR>(af0, a_b0 + so_nxt, seqA{});     // frags(kt+1, half 0)
-        lds_read_frags<0, FSTR>(bf0, b_b0 + so_nxt, seqB{});
+    };
+    if constexpr (PERSIST) {
+      for (int v = blockIdx.x; v < total_tiles; v += gridDim.x) {
+        tile_origin(v, m0, n0);
+        k_loop();
+        // epilogue of this output tile; the next tile's first D K tiles are already on their way into the ring
+        gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-      dma_and_mma(T1, T2, so_iss, live, af1, bf1);               // rest of tile kt+D beside k-half 1
-      advance();
-      so_cur = so_nxt; so_nxt = next_stage(so_nxt); so_iss = next_stage(so_iss);
+      // the reads of the (non-existent) K tile behind the last one and the zero-line DMAs behind the last real tiles
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
+      k_loop();
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off);
     }
-    // the reads of the (non-existent) tile nk and the zero-line DMAs behind the last real tiles
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  } else {
+    for (int v = blockIdx.x; v < total_tiles; v += gridDim.x) {
+      int m0, n0;
+      tile_origin(v, m0, n0);
+      gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off);
+    }
   }
-
-  gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off);
 }
 
 // Sums the split-K partials and applies the epilogue. One thread per 4 output channels.
@@ -980,7 +1039,25 @@ int launch_gemm_pipe_cm(const GemmArgs& ga, hipStream_t st) {
     attr_set = true;
   }
   long tiles = (long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-  dim3 grid((unsigned)tiles, 1, (unsigned)(d.nb_o * d.nb_i * d.splits));
+  // persistent launch: as many workgroups as the chip holds at once (a multiple of 8, one share per XCD); each walks
+  // tiles b, b + grid, ... with its DMA ring running across tile boundaries.  LGD_GEMM_PERSIST=0 = one tile per
+  // workgroup (A/B timing).  Split-K / batched launches already spread over blockIdx.z and keep one tile each.
+  static long resident = -1;
+  if (resident < 0) {
+    const char* e = getenv("LGD_GEMM_PERSIST");
+    int per_cu = 0, cus = 0, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &per_cu, reinterpret_cast<const void*>(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, true>), 64 * WM * WN, SMEM);
+    resident = (e && e[0] == '0') ? 0 : (long)(cus / 8) * 8 * (per_cu > 0 ? per_cu : 1);
+  }
+  // measured (tools/gemm_ab.py, LGD_GEMM_PERSIST=0 vs 1): +4..9 % where K <= 640 (5-10 K tiles per output tile: the
+  // pipeline fill is a visible share of a tile), neutral to -8 % from K = 1280 up — enabled for short K walks only
+  const bool persist = resident > 0 && d.nb_o * d.nb_i * d.splits == 1 && tiles > resident && d.K <= 10 * BK;
+  dim3 grid((unsigned)(persist ? resident : tiles), 1, (unsigned)(d.nb_o * d.nb_i * d.splits));
 #ifdef LGD_GEMM_ABLATION
   static int abl = -1;
   if (abl < 0) { const char* e = getenv("LGD_GEMM_ABL"); abl = e ? atoi(e) : 0; }
@@ -990,19 +1067,20 @@ int launch_gemm_pipe_cm(const GemmArgs& ga, hipStream_t st) {
       hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), SMEM, st, ga);
     };
     switch (abl) {
-      case 1: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, 1>); break;
-      case 2: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, 2>); break;
-      case 3: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, 3>); break;
-      case 4: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, 4>); break;
-      case 6: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, 6>); break;
-      case 8: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, 8>); break;
-      case 11: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, 11>); break;
+      case 1: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, false, 1>); break;
+      case 2: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, false, 2>); break;
+      case 3: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, false, 3>); break;
+      case 4: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, false, 4>); break;
+      case 6: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, false, 6>); break;
+      case 8: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, false, 8>); break;
+      case 11: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, false, 11>); break;
       default: break;
     }
     return lgd_check_launch();
   }
 #endif
-  hipLaunchKernelGGL((gemm_pipe_kernel<MI, NI, WM, WN, NS, CM>), grid, dim3(64 * WM * WN), SMEM, st, ga);
+  if (persist) hipLaunchKernelGGL((gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, true>), grid, dim3(64 * WM * WN), SMEM, st, ga);
+  else hipLaunchKernelGGL((gemm_pipe_kernel<MI, NI, WM, WN, NS, CM>), grid, dim3(64 * WM * WN), SMEM, st, ga);
   return lgd_check_launch();
 }
 
