@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--sam", action="store_true",
+                    help="refine every per-box mask with SAM (sam-vit-base architecture, seeded random weights, "
+                         "device-side processor) as real runs do; the default uses box masks (SURVEY.md 8d)")
     ap.add_argument("--cpu-dryrun", action="store_true",
                     help="rendezvous / weight broadcast / partition / timing collectives on CPU (gloo), no GPU work")
     args = ap.parse_args()
@@ -229,6 +232,20 @@ def main():
     sm = LMDSampler(eng, DDIMScheduler(prediction_type=cfg.prediction_type), vae=vae)
 
     side = 8 * cfg.sample_size
+    refiner = None
+    if args.sam:
+        if args.no_decode or args.workload == "backward_guidance":
+            raise SystemExit("--sam needs the decoded single-object images of LMD+ (no --no-decode, not backward_guidance)")
+        import transformers
+        from lgd_amd.sam_refine import SamRefiner, wrap_sam
+        torch.manual_seed(0)
+        hf_sam = transformers.SamModel(transformers.SamConfig())          # architecture + parameter names; random weights
+        with torch.no_grad():
+            for name, prm in hf_sam.named_parameters():                   # HF zero-initialises the position tables
+                if "pos" in name:
+                    prm.normal_(0.0, 0.02)
+        refiner = SamRefiner(wrap_sam(hf_sam, "device", device=dev), height=side, width=side)
+        del hf_sam
 
     def one_step():
         if not lays:
@@ -236,7 +253,7 @@ def main():
         if args.workload == "backward_guidance":       # generation/backward_guidance.py:46-49 defaults
             return backward_guidance_generate_batch(sm, lays, num_inference_steps=T, height=side, width=side,
                                                     decode=not args.no_decode)
-        return lmd_plus_generate_batch(sm, lays, num_inference_steps=T, decode=not args.no_decode)
+        return lmd_plus_generate_batch(sm, lays, num_inference_steps=T, decode=not args.no_decode, mask_refiner=refiner)
 
     for _ in range(args.warmup):
         one_step()
@@ -343,7 +360,10 @@ def main():
                vs_baseline=None, dtype="fp16", data="synthetic",
                config=dict(workload=f"{method}{what} (lmd_v0.1 cache), {T} DDIM steps, {side}x{side}, {args.config} "
                                     f"({arch}, seeded random weights), VAE decodes "
-                                    f"{'excluded' if args.no_decode else 'included'}",
+                                    f"{'excluded' if args.no_decode else 'included'}"
+                                    + ("; per-box masks refined by SAM (sam-vit-base architecture, random weights, "
+                                       "HIP model + device-side processor)" if args.sam else "; per-box masks = box masks"),
+                           mask_refinement="sam" if args.sam else "box",
                            layouts_per_gpu=(args.layouts if args.workload == "batch4" else round(n_total / world, 2)),
                            num_inference_steps=T, parallelism=f"dp{world}", rccl_ranks=world,
                            guidance_iters_per_image=round(iters_on + iters_off, 2),

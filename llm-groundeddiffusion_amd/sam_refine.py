@@ -25,11 +25,95 @@ from . import hostprep
 from .sam import HipSamModel, SamConfig
 
 
+class _Encoding(dict):
+    """What the processor returns, as far as models/sam.py:39 uses it: a mapping with `.to(device)`."""
+
+    def to(self, *_a, **_k):
+        return self
+
+
+class DeviceSamProcessor:
+    """The Hugging Face `SamProcessor` + `SamImageProcessor` defaults restated with torch ops on the model's device, for
+    generation loops where the host-side PIL path (resize of every decoded single-object image on the CPU) would stall
+    the GPU: longest edge -> 1024 (bilinear, half-pixel centres, result rounded to the 8-bit grid as PIL does), 1/255,
+    ImageNet mean / std, zero padding bottom / right; prompts scaled by new/old size ([ext] processing_sam.py
+    `_normalize_coordinates`); `post_process_masks` = interpolate to the padded size, crop, interpolate to the original
+    size, threshold ([ext] image_processing_sam.py).  Differs from the PIL path by the 8-bit rounding of ties only."""
+    MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+    def __init__(self, device="cuda", longest_edge=1024):
+        self.dev, self.target = torch.device(device), int(longest_edge)
+        self.image_processor = self
+        self.on_device = True
+
+    def _shape(self, h, w):
+        scale = self.target / max(h, w)
+        return int(h * scale + 0.5), int(w * scale + 0.5)
+
+    def __call__(self, images, input_points=None, input_labels=None, input_boxes=None, return_tensors="pt", **_kw):
+        imgs = [images] if isinstance(images, np.ndarray) and images.ndim == 3 else list(images)
+        mean = torch.tensor(self.MEAN, device=self.dev).view(1, 3, 1, 1)
+        std = torch.tensor(self.STD, device=self.dev).view(1, 3, 1, 1)
+        px, orig, resh = [], [], []
+        for im in imgs:
+            t = torch.as_tensor(np.ascontiguousarray(im)).to(self.dev)
+            if t.dim() != 3 or t.shape[2] != 3:
+                raise ValueError("images must be HxWx3 arrays")
+            h, w = int(t.shape[0]), int(t.shape[1])
+            nh, nw = self._shape(h, w)
+            r = F.interpolate(t.permute(2, 0, 1)[None].float(), (nh, nw), mode="bilinear", align_corners=False,
+                              antialias=(nh < h or nw < w)).round().clamp(0, 255)
+            r = (r / 255.0 - mean) / std
+            px.append(F.pad(r, (0, self.target - nw, 0, self.target - nh)))
+            orig.append([h, w])
+            resh.append([nh, nw])
+        enc = _Encoding(pixel_values=torch.cat(px), original_sizes=torch.tensor(orig), reshaped_input_sizes=torch.tensor(resh))
+
+        def scaled(prompts, box):
+            if len(prompts) != len(imgs):
+                sizes = [(orig[0], resh[0])] * len(prompts)
+            else:
+                sizes = list(zip(orig, resh))
+            out = []
+            for p, ((h, w), (nh, nw)) in zip(prompts, sizes):
+                a = np.array(p, dtype=np.float64)
+                a = a.reshape(-1, 2, 2) if box else a
+                a[..., 0] *= nw / w
+                a[..., 1] *= nh / h
+                out.append(a.reshape(-1, 4) if box else a)
+            return torch.from_numpy(np.array(out))
+        if input_boxes is not None:
+            if not (isinstance(input_boxes, list) and isinstance(input_boxes[0], list) and isinstance(input_boxes[0][0], list)):
+                raise ValueError("Input boxes must be a list of list of list of floating points.")
+            b = scaled(input_boxes, True)
+            enc["input_boxes"] = b.unsqueeze(1) if b.dim() != 3 else b
+        if input_points is not None:
+            if not (isinstance(input_points, list) and isinstance(input_points[0], list)):
+                raise ValueError("Input points must be a list of list of list of floating points.")
+            pts = scaled(input_points, False)
+            enc["input_points"] = pts.unsqueeze(1) if pts.dim() != 4 else pts
+        if input_labels is not None:
+            lab = torch.as_tensor(np.array(input_labels))
+            enc["input_labels"] = lab.unsqueeze(1) if lab.dim() != 3 else lab
+        return enc
+
+    def post_process_masks(self, masks, original_sizes, reshaped_input_sizes, mask_threshold=0.0, binarize=True):
+        out = []
+        for i, (h, w) in enumerate(torch.as_tensor(original_sizes).tolist()):
+            nh, nw = torch.as_tensor(reshaped_input_sizes).tolist()[i]
+            m = F.interpolate(masks[i].float(), (self.target, self.target), mode="bilinear", align_corners=False)
+            m = F.interpolate(m[..., :nh, :nw], (h, w), mode="bilinear", align_corners=False)
+            out.append(m > mask_threshold if binarize else m)
+        return out
+
+
 def wrap_sam(hf_sam_model, sam_processor=None, device="cuda"):
     """A loaded Hugging Face `SamModel` (weights) -> the `sam_model_dict` of the reference with the HIP model in it."""
     if sam_processor is None:
         import transformers
         sam_processor = transformers.SamProcessor(transformers.SamImageProcessor())
+    elif sam_processor == "device":
+        sam_processor = DeviceSamProcessor(device)
     model = HipSamModel(SamConfig.from_hf(hf_sam_model.config), hf_sam_model.state_dict(), device=device)
     return dict(sam_model=model, sam_processor=sam_processor)
 
@@ -54,10 +138,12 @@ def sam(sam_model_dict, image, input_points=None, input_boxes=None, target_mask_
         input_boxes = _listify(input_boxes)
     enc = processor(image, input_points=input_points, input_boxes=input_boxes, return_tensors="pt")
     out = model(**enc)
-    full = processor.image_processor.post_process_masks(out.pred_masks.float().cpu(), enc["original_sizes"].cpu(),
-                                                        enc["reshaped_input_sizes"].cpu())
+    logits = out.pred_masks.float()
+    if not getattr(processor, "on_device", False):                 # the Hugging Face processor works on host tensors
+        logits = logits.cpu()
+    full = processor.image_processor.post_process_masks(logits, enc["original_sizes"].cpu(), enc["reshaped_input_sizes"].cpu())
     conf_scores = out.iou_scores.float().cpu().numpy()[0, 0]
-    small = [F.interpolate(m.float(), target_mask_shape, mode="bilinear").bool() for m in full]
+    small = [F.interpolate(m.float(), target_mask_shape, mode="bilinear").bool().cpu() for m in full]
     return ([m.numpy() for m in small] if return_numpy else small), conf_scores
 
 

@@ -66,3 +66,37 @@ def test_coarse_mask_preprocessing(dsam):
     cand = np.stack([a > 0.5, np.zeros_like(a, dtype=bool)])
     iou = dsam.get_iou_with_resize(a > 0.5, cand, masks_shape=(16, 16))
     assert abs(iou[0] - 1.0) < 1e-5 and iou[1] == 0.0
+
+
+def test_device_processor_vs_hugging_face_processor(dsam):
+    """`DeviceSamProcessor` (torch ops, any device) against the Hugging Face `SamProcessor` the reference uses: same
+    tensors up to the 8-bit rounding of the resized image, same prompt scaling, same mask post-processing."""
+    hfp = transformers.SamProcessor(transformers.SamImageProcessor())
+    mine = dsam.DeviceSamProcessor(device="cpu")
+    images, boxes, _ = sam_cases.refine_inputs()
+    odd = np.random.RandomState(0).randint(0, 256, size=(300, 480, 3), dtype=np.uint8)      # non-square: padding + crop
+    for imgs, bx in (([images[0]], [[[40.0, 60.0, 300.0, 410.0]]]), ([odd], [[[10.0, 20.0, 200.0, 250.0], [5.0, 5.0, 470.0, 290.0]]])):
+        want = hfp(imgs, input_boxes=bx, return_tensors="pt")
+        got = mine(imgs, input_boxes=bx, return_tensors="pt")
+        assert got["pixel_values"].shape == want["pixel_values"].shape
+        assert float((got["pixel_values"] - want["pixel_values"]).abs().max()) < 0.02       # one 8-bit step = 0.017
+        assert float((got["pixel_values"] - want["pixel_values"]).abs().mean()) < 8e-3      # PIL resizes in fixed point
+        assert torch.equal(got["original_sizes"], want["original_sizes"].long())
+        assert torch.equal(got["reshaped_input_sizes"], want["reshaped_input_sizes"].long())
+        assert torch.allclose(got["input_boxes"], want["input_boxes"].double())
+        logits = torch.randn(1, len(bx[0]), 3, 256, 256, generator=torch.Generator().manual_seed(1))
+        a = hfp.image_processor.post_process_masks(logits, want["original_sizes"], want["reshaped_input_sizes"])
+        b = mine.post_process_masks(logits, got["original_sizes"], got["reshaped_input_sizes"])
+        assert torch.equal(a[0], b[0])
+    want = hfp([images[0]], input_points=[[[100.0, 200.0]]], return_tensors="pt")
+    got = mine([images[0]], input_points=[[[100.0, 200.0]]], return_tensors="pt")
+    assert got["input_points"].shape == want["input_points"].shape and torch.allclose(got["input_points"], want["input_points"].double())
+
+
+def test_refinement_replay_with_the_device_processor(dsam):
+    hf = sam_cases.build_refine_hf(transformers)
+    md = dsam.wrap_sam(hf, "device", device="cpu")
+    assert isinstance(md["sam_processor"], dsam.DeviceSamProcessor)
+    # the image differs from the PIL path by one 8-bit step in a quarter of the pixels: masks move at the threshold only
+    worst = sam_refine_checks.replay(dsam, md, min_agree=0.95, conf_tol=3e-2)       # measured worst 0.972
+    print("worst agreement with the PIL-path golden", worst)
