@@ -95,6 +95,39 @@ class UNet2DConditionModel:
     def to(self, *a, **k):
         return self
 
+    # ---- per-run constants
+    @staticmethod
+    def _ident(*tensors):
+        """Identity of device inputs without reading them back: same storage, same shape, not written since."""
+        return tuple((t.data_ptr(), tuple(t.shape), t._version, str(t.dtype)) for t in tensors)
+
+    def _prepare_constants(self, timestep, encoder_hidden_states, gl):
+        """Time-embedding rows, text K/V of the 16 cross-attention layers and the GLIGEN grounding tokens do not depend
+        on the latents.  Callers that drive `unet()` themselves pass the same prompt tensors on every step of a run
+        (pipelines.py:163-166 does), so they are rebuilt only when the timestep / the tensors change: a 50-step loop
+        costs 50 small time-embedding GEMM chains, one text projection pass and one PositionNet pass — not 50 of each."""
+        eng = self.engine
+        seen = self.__dict__.setdefault("_const_seen", {})
+        # every UNetEngine.prepare_* call clears `const_writer`: if the sampler (or another wrapper) has rebuilt the
+        # engine's tables since this wrapper's last call, nothing cached here is valid
+        mine = getattr(eng, "const_writer", None) is self
+        if not mine:
+            seen.clear()
+        if seen.get("t") != timestep:
+            eng.prepare_timesteps([timestep])
+            eng.set_step(0)
+            seen["t"] = timestep
+        key = self._ident(encoder_hidden_states)
+        if seen.get("text") != key:
+            eng.prepare_text(encoder_hidden_states)
+            seen["text"] = key
+        if gl is not None and eng.cfg.use_gated_attention:
+            key = self._ident(gl["boxes"], gl["masks"], gl["positive_embeddings"])
+            if seen.get("gligen") != key:
+                eng.prepare_gligen(boxes=gl["boxes"], masks=gl["masks"], positive_embeddings=gl["positive_embeddings"])
+                seen["gligen"] = key
+        eng.const_writer = self
+
     # ---- forward
     def __call__(self, sample, timestep, encoder_hidden_states, cross_attention_kwargs=None,
                  return_cross_attention_probs=False, **unused):
@@ -118,11 +151,7 @@ class UNet2DConditionModel:
         if B > eng.max_text_batch:
             raise RuntimeError(f"engine built for text batch <= {eng.max_text_batch}, got {B}")
         plan = eng.plan(B, L, grad=need_grad, fuser=fuser, stop_key=stop, save_keys=keys)
-        eng.prepare_timesteps([int(timestep)])
-        eng.set_step(0)
-        eng.prepare_text(encoder_hidden_states)
-        if gl is not None and eng.cfg.use_gated_attention:
-            eng.prepare_gligen(boxes=gl["boxes"], masks=gl["masks"], positive_embeddings=gl["positive_embeddings"])
+        self._prepare_constants(int(timestep), encoder_hidden_states, gl)
         if need_grad:
             maps = _MapsFn.apply(sample, plan, keys, 1024.0)
             eps = None

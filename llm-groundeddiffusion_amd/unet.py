@@ -584,6 +584,7 @@ class UNetEngine:
     def prepare_timesteps(self, timesteps: Sequence[int]):
         """Time-embedding MLP + every resnet's time_emb_proj for all timesteps of the run
         (unet_2d_condition.py:785-808 + [ext] ResnetBlock2D): table [T][sum Cout] fp32."""
+        self.const_writer = None          # whoever cached the previous tables must rebuild (dropin UNet wrapper)
         cfg, w = self.cfg, self.w
         c0 = cfg.block_out_channels[0]
         t = torch.as_tensor(list(timesteps), dtype=torch.float32, device=self.device)
@@ -608,6 +609,7 @@ class UNetEngine:
     def prepare_text(self, ehs: torch.Tensor):
         """to_k / to_v of all cross-attention layers for this prompt (time-invariant: computed once per
         run instead of once per UNet call; attention_processor.py:345-346,433-434)."""
+        self.const_writer = None          # whoever cached the previous tables must rebuild (dropin UNet wrapper)
         Bt, T, Cx = ehs.shape
         if Bt > self.max_text_batch or T != self.text_len:
             raise RuntimeError(f"text batch {Bt}x{T} exceeds the engine's text K/V buffers "
@@ -623,6 +625,7 @@ class UNetEngine:
         """GLIGEN grounding tokens for the run: PositionNet (unet_2d_condition.py:99-114), then per
         fuser layer linear(objs) and LayerNorm of those 30 rows, stored in the tail rows of the
         concat buffers (they do not depend on the latents or the timestep)."""
+        self.const_writer = None          # whoever cached the previous tables must rebuild (dropin UNet wrapper)
         w = self.w
         dev = self.device
         boxes, masks, pe = boxes.to(dev, F32), masks.to(dev, F32), positive_embeddings.to(dev, F32)

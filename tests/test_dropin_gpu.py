@@ -175,6 +175,50 @@ def test_unet_wrapper_and_attn_processor_hook(dropin, dev):
     assert relerr(p, pr) < 2e-2 and relerr(y, o) < 2e-2 and ("mid", 0, 0, 0) in d
 
 
+def test_unet_wrapper_reuses_run_constants(dropin, dev):
+    """A caller that drives `unet()` itself (pipelines.py:163-166) passes the same prompt tensors on every step: text
+    K/V and GLIGEN tokens are rebuilt only when those tensors (or, for the time rows, the timestep) change, and after
+    anything else has rebuilt the engine's tables."""
+    md = dropin.model_dict
+    eng = md.unet.engine
+    g = np.load(os.path.join(GOLD, "unet_fwd_tiny_gligen.npz"))
+    ehs = torch.from_numpy(g["ehs"]).to(dev)
+    gl = dict(boxes=torch.from_numpy(g["gl_boxes"]), positive_embeddings=torch.from_numpy(g["gl_emb"]),
+              masks=torch.from_numpy(g["gl_masks"]))
+    x = torch.from_numpy(g["x"]).to(dev)
+    from models import pipelines
+    pipelines.gligen_enable_fuser(md.unet, True)
+    counts = dict(text=0, gligen=0, time=0)
+    orig = eng.prepare_text, eng.prepare_gligen, eng.prepare_timesteps
+
+    def wrap(fn, key):
+        def f(*a, **k):
+            counts[key] += 1
+            return fn(*a, **k)
+        return f
+    eng.prepare_text, eng.prepare_gligen, eng.prepare_timesteps = (wrap(orig[0], "text"), wrap(orig[1], "gligen"),
+                                                                     wrap(orig[2], "time"))
+    try:
+        call = lambda t: md.unet(x, torch.tensor(t), encoder_hidden_states=ehs, cross_attention_kwargs=dict(gligen=gl)).sample
+        eng.prepare_text(ehs)                                  # someone else used the engine: nothing cached is valid
+        counts.update(text=0, gligen=0, time=0)
+        a = call(int(g["t"]))
+        assert counts == dict(text=1, gligen=1, time=1)
+        b = call(int(g["t"]))
+        c = call(int(g["t"]) - 20)
+        assert counts == dict(text=1, gligen=1, time=2) and torch.equal(a, b) and not torch.equal(a, c)
+        assert relerr(a, g["eps"]) < 2e-2
+        ehs.mul_(0.5)                                          # same storage, new contents
+        d = call(int(g["t"]) - 20)
+        assert counts == dict(text=2, gligen=1, time=2) and not torch.equal(c, d)
+        eng.prepare_timesteps([3])                             # e.g. the sampler ran in between
+        counts.update(text=0, gligen=0, time=0)
+        e = call(int(g["t"]) - 20)
+        assert counts == dict(text=1, gligen=1, time=1) and torch.equal(d, e)
+    finally:
+        eng.prepare_text, eng.prepare_gligen, eng.prepare_timesteps = orig
+
+
 def test_pipelines_generate_partial_frozen_signature(dropin, dev):
     """models.pipelines.generate_partial_frozen with the reference's positional signature."""
     import lgd_amd  # noqa: F401
