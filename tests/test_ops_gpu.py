@@ -130,6 +130,40 @@ def test_conv3x3_8wave_tiles(dev, tile):
     assert relerr(y, ref) < 3e-3
 
 
+@pytest.mark.parametrize("M,N,K,tile", [
+    (66017, 1000, 320, 34), (66017, 1000, 640, 33), (40000, 968, 192, 37), (70001, 320, 320, 38), (33000, 2560, 320, 35),
+    (131072, 320, 64, 39), (20000, 1920, 576, 40),
+])
+def test_gemm_persistent_tile_loop_ragged(dev, M, N, K, tile):
+    """More output tiles than resident workgroups and K <= 640: the 8-wave tiles run their persistent loop (one
+    workgroup walks tiles b, b + grid, ... with the DMA ring crossing tile boundaries).  Ragged M and N: clamped rows
+    in the last tiles of a walk, tile counts that are not a multiple of the grid, N tiles past the last column."""
+    x = rnd(M, K, dev=dev, seed=1).half()
+    w = rnd(N, K, dev=dev, seed=2, scale=K ** -0.5).half()
+    b = rnd(N, dev=dev, seed=3)
+    r = rnd(M, N, dev=dev, seed=4).half()
+    y = ops.linear(x, w, b, res=r, tile=tile, splits=1)
+    ref = x.float() @ w.float().t() + b + r.float()
+    assert relerr(y, ref) < 3e-3
+    y2 = ops.linear(x, w, b, res=r, tile=tile, splits=1)           # second launch: nothing stale between launches
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("B,H,Cout,tile", [(10, 48, 320, 37), (9, 64, 160, 38), (3, 96, 320, 34)])
+def test_conv3x3_persistent_tile_loop(dev, B, H, Cout, tile):
+    """3x3 convolution over 64 input channels (K = 576 <= 640) with more tiles than resident workgroups: the
+    chunk-major K walk restarts on every output tile of the persistent loop."""
+    C = 64
+    x = rnd(B, C, H, H, dev=dev, seed=1).half()
+    w = rnd(Cout, C, 3, 3, dev=dev, seed=2, scale=(9 * C) ** -0.5).half()
+    b = rnd(Cout, dev=dev, seed=3)
+    xl = x.permute(0, 2, 3, 1).reshape(B * H * H, C).contiguous()
+    res = rnd(B * H * H, Cout, dev=dev, seed=7).half()
+    y = ops.conv3x3(xl, pack_conv_w(w), B, H, H, bias=b, res=res, tile=tile, splits=1)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout) + res.float()
+    assert relerr(y, ref) < 3e-3
+
+
 def test_conv_dgrad_identity(dev):
     """dgrad of a stride-1 conv = conv with flipped, transposed weights (how the engine calls it)."""
     B, H, Cin, Cout = 1, 16, 64, 128
