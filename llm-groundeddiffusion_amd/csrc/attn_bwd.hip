@@ -16,6 +16,7 @@
 // row) remains as the fallback for 96 < Sk <= 128.
 #include "common.h"
 #include "../../include/lgd_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -26,17 +27,17 @@ constexpr int TR_LD = T64 + 8;  // halfs per row of a transposed tile
 // tile t+1 are in flight while tile t is multiplied.  A tile is 64 rows x DP; a thread owns
 // (row pair, 8-column segment) items, which lets the transposed image be written as 4-byte
 // (row pair) stores.  Rows past `nrows` and columns past `d` are zero.
-template <int DP>
+template <int DP, int NT = 256>
 struct PairTile {
   static constexpr int KSEG = DP / 8;
   static constexpr int ITEMS = (T64 / 2) * KSEG;
-  static constexpr int IT = (ITEMS + 255) / 256;
+  static constexpr int IT = (ITEMS + NT - 1) / NT;
   uint4 v[IT][2];
 
   __device__ __forceinline__ void load(const half_t* __restrict__ src, long ld, int row0, int nrows, int d) {
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-      const int idx = threadIdx.x + i * 256;
+      const int idx = threadIdx.x + i * NT;
       const int pair = idx & 31, seg = idx >> 5;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
@@ -50,7 +51,7 @@ struct PairTile {
   __device__ __forceinline__ void store(half_t* rm, half_t* tr) const {
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-      const int idx = threadIdx.x + i * 256;
+      const int idx = threadIdx.x + i * NT;
       if (idx >= ITEMS) continue;
       const int pair = idx & 31, seg = idx >> 5;
       if (RM) {
@@ -100,12 +101,16 @@ __device__ __forceinline__ half8_t tr_frag(const half_t* tr, int row, int c, int
 
 // dQ.  Each wave owns QT x 16 queries (K / V / K^T fragments read from LDS feed QT MFMAs each);
 // the next key tile is fetched into registers while the current one is multiplied.
-template <int DP, int QT, int NDT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
+// NW waves per workgroup (8: 256 queries share each staged key tile, as in the forward kernel); DB: two LDS stages and
+// one barrier per key tile instead of store-after-barrier with two.
+template <int DP, int QT, int NDT, int NW = 4, bool DB = false>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
   constexpr int K_LD = DP + 16;
   constexpr int NDC = DP / 32;   // NDT: 16-row output tiles that hold data (3 of DP/16 = 4 for d = 40)
+  constexpr int STAGE = 2 * T64 * K_LD + DP * TR_LD;   // halfs: K, V row-major + K transposed
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
-  half_t* Ks = reinterpret_cast<half_t*>(dyn_smem);
+  half_t* const smem = reinterpret_cast<half_t*>(dyn_smem);
+  half_t* Ks = smem;
   half_t* Vs = Ks + T64 * K_LD;
   half_t* Kt = Vs + T64 * K_LD;
 
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
   const int g = lane >> 4, c16 = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
   const int d = a.d;
-  const int q0 = blockIdx.x * (64 * QT) + wid * (16 * QT);
+  const int q0 = blockIdx.x * (16 * NW * QT) + wid * (16 * QT);
   const half_t* Qb = a.q + (long)b * a.q_bs + (long)h * d;
   const half_t* Kb = a.k + (long)b * a.k_bs + (long)h * d;
   const half_t* Vb = a.v + (long)b * a.v_bs + (long)h * d;
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
 
   const float sl2 = a.scale_log2;
   const int n_tiles = (a.Sk + T64 - 1) / T64;
-  PairTile<DP> kreg, vreg;
+  PairTile<DP, 64 * NW> kreg, vreg;
   kreg.load(Kb, a.ldk, 0, a.Sk, d);
   vreg.load(Vb, a.ldv, 0, a.Sk, d);
   kreg.template store<true, true>(Ks, Kt);
@@ -165,6 +170,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
   __syncthreads();
   for (int t = 0; t < n_tiles; ++t) {
     const int kv0 = t * T64;
+    if constexpr (DB) {
+      Ks = smem + (t & 1) * STAGE;
+      Vs = Ks + T64 * K_LD;
+      Kt = Vs + T64 * K_LD;
+    }
     if (t + 1 < n_tiles) {
       kreg.load(Kb, a.ldk, kv0 + T64, a.Sk, d);
       vreg.load(Vb, a.ldv, kv0 + T64, a.Sk, d);
@@ -220,11 +230,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
           dq[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ktf, dsf[qt], dq[qt][dt], 0, 0, 0);
       }
     }
-    __syncthreads();
-    if (t + 1 < n_tiles) {
-      kreg.template store<true, true>(Ks, Kt);
-      vreg.template store<true, false>(Vs, nullptr);
+    if constexpr (DB) {
+      // the other stage was last read in iteration t-1, which every wave left through the barrier below
+      if (t + 1 < n_tiles) {
+        half_t* nK = smem + ((t + 1) & 1) * STAGE;
+        kreg.template store<true, true>(nK, nK + 2 * T64 * K_LD);
+        vreg.template store<true, false>(nK + T64 * K_LD, nullptr);
+      }
       __syncthreads();
+    } else {
+      __syncthreads();
+      if (t + 1 < n_tiles) {
+        kreg.template store<true, true>(Ks, Kt);
+        vreg.template store<true, false>(Vs, nullptr);
+        __syncthreads();
+      }
     }
   }
 #pragma unroll
@@ -249,23 +269,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
 // dK, dV.  Each wave owns KT x 16 keys; loops over query tiles (Q, dO row-major and transposed,
 // lse and delta in LDS), next tile prefetched into registers.  Padded query rows are all-zero in
 // Q and dO, so they contribute nothing whatever their recomputed probability is.
-template <int DP, int KT, int NDT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
+template <int DP, int KT, int NDT, int NW = 4, bool DB = false>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
   constexpr int K_LD = DP + 16;
   constexpr int NDC = DP / 32;
+  constexpr int STAGE = 2 * T64 * K_LD + 2 * DP * TR_LD + 4 * T64;   // halfs (the two float[64] tables = 4*64 halfs)
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
-  half_t* Qs = reinterpret_cast<half_t*>(dyn_smem);
+  half_t* const smem = reinterpret_cast<half_t*>(dyn_smem);
+  half_t* Qs = smem;
   half_t* Gs = Qs + T64 * K_LD;          // dO row-major
   half_t* Qt = Gs + T64 * K_LD;          // Q transposed [d][q]
   half_t* Gt = Qt + DP * TR_LD;          // dO transposed [dv][q]
   float* s_lse = reinterpret_cast<float*>(Gt + DP * TR_LD);  // -lse
   float* s_delta = s_lse + T64;
+  auto set_stage = [&](int st) {
+    Qs = smem + st * STAGE;
+    Gs = Qs + T64 * K_LD;
+    Qt = Gs + T64 * K_LD;
+    Gt = Qt + DP * TR_LD;
+    s_lse = reinterpret_cast<float*>(Gt + DP * TR_LD);
+    s_delta = s_lse + T64;
+  };
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, c16 = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
   const int d = a.d;
-  const int k0 = blockIdx.x * (64 * KT) + wid * (16 * KT);
+  const int k0 = blockIdx.x * (16 * NW * KT) + wid * (16 * KT);
   const half_t* Qb = a.q + (long)b * a.q_bs + (long)h * d;
   const half_t* Kb = a.k + (long)b * a.k_bs + (long)h * d;
   const half_t* Vb = a.v + (long)b * a.v_bs + (long)h * d;
@@ -300,7 +330,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
 
   const float sl2 = a.scale_log2;
   const int n_tiles = (a.Sq + T64 - 1) / T64;
-  PairTile<DP> qreg, greg;
+  PairTile<DP, 64 * NW> qreg, greg;
   float st_l = 0.f, st_d = 0.f;
   auto load_stats = [&](int q0) {
     if (tid < T64) {
@@ -320,6 +350,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
   store_all();
   __syncthreads();
   for (int t = 0; t < n_tiles; ++t) {
+    if constexpr (DB) set_stage(t & 1);
     if (t + 1 < n_tiles) {
       qreg.load(Qb, a.ldq, (t + 1) * T64, a.Sq, d);
       greg.load(GOb, a.ldgo, (t + 1) * T64, a.Sq, d);
@@ -377,10 +408,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdArgs a) 
         }
       }
     }
-    __syncthreads();
-    if (t + 1 < n_tiles) {
-      store_all();
+    if constexpr (DB) {
+      if (t + 1 < n_tiles) {
+        set_stage((t + 1) & 1);
+        store_all();
+      }
       __syncthreads();
+    } else {
+      __syncthreads();
+      if (t + 1 < n_tiles) {
+        store_all();
+        __syncthreads();
+      }
     }
   }
 #pragma unroll
@@ -688,23 +727,24 @@ int launch_cross_bwd_mfma(const CrossBwdArgs& a, hipStream_t st) {
   return lgd_check_launch();
 }
 
-template <int DP, int NQ, int NK, int NDT>
+template <int DP, int NQ, int NK, int NDT, int NW = 4, bool DB = false>
 int launch_bwd_nt(const AttnBwdArgs& a, hipStream_t st) {
   constexpr int K_LD = DP + 16;
-  const size_t smem_dq = (size_t)(2 * T64 * K_LD + DP * TR_LD) * 2;
-  const size_t smem_dkv = (size_t)(2 * T64 * K_LD + 2 * DP * TR_LD) * 2 + 2 * T64 * 4;
+  constexpr int NST = DB ? 2 : 1;
+  const size_t smem_dq = (size_t)NST * (2 * T64 * K_LD + DP * TR_LD) * 2;
+  const size_t smem_dkv = (size_t)NST * ((2 * T64 * K_LD + 2 * DP * TR_LD) * 2 + 2 * T64 * 4);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DP, NK, NDT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DP, NK, NDT, NW, DB>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dkv);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DP, NQ, NDT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DP, NQ, NDT, NW, DB>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dq);
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, NQ, NDT>), dim3((a.Sq + 64 * NQ - 1) / (64 * NQ), a.H, a.B),
-                     dim3(256), smem_dq, st, a);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, NK, NDT>), dim3((a.Sk + 64 * NK - 1) / (64 * NK), a.H, a.B),
-                     dim3(256), smem_dkv, st, a);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, NQ, NDT, NW, DB>), dim3((a.Sq + 16 * NW * NQ - 1) / (16 * NW * NQ), a.H, a.B),
+                     dim3(64 * NW), smem_dq, st, a);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, NK, NDT, NW, DB>), dim3((a.Sk + 16 * NW * NK - 1) / (16 * NW * NK), a.H, a.B),
+                     dim3(64 * NW), smem_dkv, st, a);
   return lgd_check_launch();
 }
 
@@ -712,14 +752,30 @@ template <int DP>
 int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
   // two 16-row tiles per wave once there are enough 128-row workgroups to fill the chip
   const long wgs = (long)((a.Sq < a.Sk ? a.Sq : a.Sk) / 128) * a.H * a.B;
+  // LGD_ATTN_BWD (tools, A/B): 0 = single-buffered 4-wave kernels of round 1, 1 = double-buffered, 2 = double-buffered 8 waves.
+  // Measured (tools/attn_bwd_quick.py, same box): d = 40, S = 4096: 607 -> 587 (1) -> 547 us (2); with the fuser's
+  // 4126 keys 679 -> 653 -> 655; d = 80 and d = 160 unchanged; d = 64 at S = 9216 (SD2.1): 1067 -> 1199 us with two stages
+  // (79 KB of LDS per workgroup halves the resident workgroups) — so only the narrow-head case takes the new variants.
+  static int env = -1;
+  if (env == -1) { const char* e = getenv("LGD_ATTN_BWD"); env = e ? atoi(e) : -2; }
+  const bool narrow = env == -2;           // default: new variants for d <= 48 only
+  const int mode = narrow ? 0 : env;
   if constexpr (DP == 64) {
     if (a.d <= 48) {  // d = 40: the fourth 16-row tile of dQ / dK / dV would be all padding
-      if (wgs >= 512) return launch_bwd_nt<DP, 2, 2, 3>(a, st);
+      if (wgs >= 512) {
+        if ((narrow || mode == 2) && wgs >= 1024) return launch_bwd_nt<DP, 2, 2, 3, 8, true>(a, st);
+        if (narrow || mode >= 1) return launch_bwd_nt<DP, 2, 2, 3, 4, true>(a, st);
+        return launch_bwd_nt<DP, 2, 2, 3>(a, st);
+      }
       return launch_bwd_nt<DP, 1, 1, 3>(a, st);
     }
   }
   if constexpr (DP <= 96) {
-    if (wgs >= 512) return launch_bwd_nt<DP, 2, 2, DP / 16>(a, st);
+    if (wgs >= 512) {
+      if (mode == 2 && wgs >= 1024) return launch_bwd_nt<DP, 2, 2, DP / 16, 8, true>(a, st);
+      if (mode >= 1) return launch_bwd_nt<DP, 2, 2, DP / 16, 4, true>(a, st);
+      return launch_bwd_nt<DP, 2, 2, DP / 16>(a, st);
+    }
   }
   return launch_bwd_nt<DP, 1, 1, DP / 16>(a, st);
 }
