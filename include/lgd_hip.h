@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LGD_ABI_VERSION 3
+#define LGD_ABI_VERSION 4
 int lgd_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -177,6 +177,9 @@ int lgd_geglu_bwd_f16(const void* h, const void* gy, void* gh, int64_t rows, int
 int lgd_geglu_fwd_f16(const void* h, void* y, int64_t rows, int n, void* stream);
 /* y = x * sigmoid(1.702 x) (fp16): CLIP text encoder MLP activation ([ext] transformers CLIPMLP, "quick_gelu"). */
 int lgd_quick_gelu_f16(const void* x, void* y, int64_t n, void* stream);
+/* NCHW fp32 (B, C <= 8, HW) -> channels-last fp16 [B*HW][8] with zero channels behind C: input of the UNet's conv_in
+ * (unet_2d_condition.py:860, 4 -> 320 channels) when it runs as an implicit GEMM with K = 9*8. */
+int lgd_nchw_to_nhwc8_f16(const float* x, void* y, int B, int C, int HW, void* stream);
 /* y = a + b (fp16), n elements (gradient fan-in / residual). */
 int lgd_add_f16(const void* a, const void* b, void* y, int64_t n, void* stream);
 /* y = alpha * x (fp16) */

@@ -100,6 +100,20 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict_
   }
 }
 
+// NCHW fp32 (B, C <= 8, HW) -> channels-last fp16 [B*HW][8], channels >= C zero: the 4-channel latents become an
+// 8-channel map, the narrowest the implicit-GEMM convolution takes (one 16-byte vector per pixel and tap), so that
+// conv_in runs on the matrix cores (K = 72) instead of conv_in_kernel's LDS-bound scalar loop.
+__global__ __launch_bounds__(256) void nchw_to_nhwc8_kernel(const float* __restrict__ x, half_t* __restrict__ y,
+                                                             int C, long HW, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const long b = i / HW, p = i - b * HW;
+    half8_t o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = c < C ? (half_t)x[(b * C + c) * HW + p] : (half_t)0.f;
+    reinterpret_cast<half8_t*>(y)[i] = o;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // elementwise helpers (16-byte vectors, grid-stride)
 // ---------------------------------------------------------------------------------------------
@@ -361,6 +375,15 @@ extern "C" int lgd_scale_f16(const void* x, void* y, float alpha, int64_t n, voi
   hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), (const half_t*)x, (half_t*)y, alpha,
                      (long)(n / 8));
+  return lgd_check_launch();
+}
+
+extern "C" int lgd_nchw_to_nhwc8_f16(const float* x, void* y, int B, int C, int HW, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  if (B < 1 || C < 1 || C > 8 || HW < 1) return LGD_ERR_ARG;
+  const long total = (long)B * HW;
+  hipLaunchKernelGGL(nchw_to_nhwc8_kernel, dim3(ew_blocks(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     (half_t*)y, C, (long)HW, total);
   return lgd_check_launch();
 }
 

@@ -244,6 +244,15 @@ def conv_in(x_nchw, w, bias, out=None):
     return out
 
 
+def nchw_to_nhwc8(x_nchw, out=None):
+    """(B, C<=8, H, W) fp32 -> [B*H*W, 8] fp16, zero channels behind C."""
+    B, C_, H, W = x_nchw.shape
+    if out is None:
+        out = torch.empty((B * H * W, 8), device=x_nchw.device, dtype=F16)
+    _call("lgd_nchw_to_nhwc8_f16", _p(x_nchw), _p(out), B, C_, H * W, _stream())
+    return out
+
+
 def conv_out(x, w, bias, B, L, out=None, out_scale=1.0):
     Cin = x.shape[1]
     Cout = w.shape[0]

@@ -420,7 +420,11 @@ class Plan:
         lat = self.latents_in
         self._x0 = x
         x0 = x
-        self._add(lambda: ops.conv_in(lat, w.h["conv_in.w"], w.f["conv_in.b"], out=x0.t))
+        # conv_in on the matrix cores: latents -> 8-channel fp16 map (4 zero channels), 3x3 implicit GEMM with K = 72
+        lat8 = self._new(B * L * L, 8)
+        d_in = ops.gemm_desc(lat8, w.h["conv_in.w8"], x0.t, B * L * L, c0, 72, c0=8, lda0=8, taps=9, hin=L, win=L, hout=L,
+                             wout=L, bias=w.f["conv_in.b"], ldc=c0, splits=1)
+        self._add(lambda: (ops.nchw_to_nhwc8(lat, out=lat8), ops.gemm_launch(d_in)))
         skips = [(x, L)]
         H = L
         done = False

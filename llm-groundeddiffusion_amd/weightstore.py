@@ -113,6 +113,7 @@ class WeightStore:
         c0, ted, cx = cfg.block_out_channels[0], cfg.time_embed_dim, cfg.cross_attention_dim
         self._e16("conv_in.w", (c0, 9 * cfg.in_channels))
         self._e16("conv_in.wd", (cfg.in_channels, 9 * c0))
+        self._e16("conv_in.w8", (c0, 72))             # the same filter over 8 input channels (4..7 zero): implicit-GEMM form
         self._e32("conv_in.b", (c0,))
         self._lin("time_embedding.linear_1", ted, c0)
         self._lin("time_embedding.linear_2", ted, ted)
@@ -204,6 +205,8 @@ class WeightStore:
 
         h16["conv_in.w"] = pack_conv(sd["conv_in.weight"])
         h16["conv_in.wd"] = pack_conv_dgrad(sd["conv_in.weight"])
+        wi = sd["conv_in.weight"]
+        h16["conv_in.w8"] = pack_conv(torch.cat([wi, wi.new_zeros(wi.shape[0], 8 - wi.shape[1], 3, 3)], dim=1))
         f32["conv_in.b"] = sd["conv_in.bias"]
         lin("time_embedding.linear_1", "time_embedding.linear_1")
         lin("time_embedding.linear_2", "time_embedding.linear_2")

@@ -90,6 +90,7 @@ def test_gemm_geglu(dev, M, dim, splits, tile):
     (1, 16, 128, 64, 128, 1, False, 1), (2, 8, 1280, 1280, 1280, 1, False, 8),
     (2, 16, 320, 0, 320, 2, False, 1), (1, 8, 640, 0, 640, 1, True, 1),
     (1, 10, 64, 0, 128, 1, False, 1), (1, 16, 64, 0, 64, 1, 2, 1),
+    (2, 16, 8, 0, 32, 1, False, 1), (4, 64, 8, 0, 320, 1, False, 1),      # conv_in as an implicit GEMM: 8 input channels, K = 72
 ])
 def test_conv3x3(dev, B, H, C0, C1, Cout, stride, ups, splits, dma):
     C = C0 + C1
@@ -176,6 +177,14 @@ def test_conv_dgrad_identity(dev):
     gx = ops.conv3x3(gyl, pack_conv_w(wd), B, H, H)
     ref = x.grad.permute(0, 2, 3, 1).reshape(-1, Cin)
     assert relerr(gx, ref) < 3e-3
+
+
+def test_nchw_to_nhwc8(dev):
+    x = rnd(3, 4, 16, 16, dev=dev, seed=1)
+    y = ops.nchw_to_nhwc8(x)
+    ref = torch.zeros(3 * 256, 8, device=dev)
+    ref[:, :4] = x.permute(0, 2, 3, 1).reshape(-1, 4)
+    assert torch.equal(y, ref.half())
 
 
 def test_conv_in_out(dev):
