@@ -177,8 +177,9 @@ int lgd_geglu_bwd_f16(const void* h, const void* gy, void* gh, int64_t rows, int
 int lgd_geglu_fwd_f16(const void* h, void* y, int64_t rows, int n, void* stream);
 /* y = x * sigmoid(1.702 x) (fp16): CLIP text encoder MLP activation ([ext] transformers CLIPMLP, "quick_gelu"). */
 int lgd_quick_gelu_f16(const void* x, void* y, int64_t n, void* stream);
-/* NCHW fp32 (B, C <= 8, HW) -> channels-last fp16 [B*HW][8] with zero channels behind C: input of the UNet's conv_in
- * (unet_2d_condition.py:860, 4 -> 320 channels) when it runs as an implicit GEMM with K = 9*8. */
+/* NCHW fp32 (B, C <= 8, HW) -> channels-last fp16 [B*HW][8]: channels 0..C-1 = fp16(x), channels C..2C-1 (when 2C <= 8)
+ * = fp16(x - fp16(x)), the rest zero.  Input of the UNet's conv_in (unet_2d_condition.py:860, 4 -> 320 channels) when
+ * it runs as an implicit GEMM with K = 9*8 and the filter duplicated over the remainder channels. */
 int lgd_nchw_to_nhwc8_f16(const float* x, void* y, int B, int C, int HW, void* stream);
 /* y = a + b (fp16), n elements (gradient fan-in / residual). */
 int lgd_add_f16(const void* a, const void* b, void* y, int64_t n, void* stream);

@@ -100,16 +100,25 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict_
   }
 }
 
-// NCHW fp32 (B, C <= 8, HW) -> channels-last fp16 [B*HW][8], channels >= C zero: the 4-channel latents become an
+// NCHW fp32 (B, C <= 8, HW) -> channels-last fp16 [B*HW][8]: channels 0..C-1 = fp16(x), C..2C-1 = fp16(x - fp16(x))
+// when they fit, the rest zero: the 4-channel latents become an
 // 8-channel map, the narrowest the implicit-GEMM convolution takes (one 16-byte vector per pixel and tap), so that
 // conv_in runs on the matrix cores (K = 72) instead of conv_in_kernel's LDS-bound scalar loop.
 __global__ __launch_bounds__(256) void nchw_to_nhwc8_kernel(const float* __restrict__ x, half_t* __restrict__ y,
                                                              int C, long HW, long total) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
     const long b = i / HW, p = i - b * HW;
-    half8_t o;
+    half8_t o = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int c = 0; c < 8; ++c) o[c] = c < C ? (half_t)x[(b * C + c) * HW + p] : (half_t)0.f;
+    for (int c = 0; c < 8; ++c)
+      if (c < C) {
+        const float v = x[(b * C + c) * HW + p];
+        const half_t hi = (half_t)v;
+        o[c] = hi;
+        // the spare channels carry the rounding remainder (the filter is duplicated over them by the caller):
+        // hi + lo reproduces the fp32 latent to 2^-22, so the fp16 operand format costs conv_in no input precision
+        if (2 * C <= 8 && c + C < 8) o[c + C] = (half_t)(v - (float)hi);
+      }
     reinterpret_cast<half8_t*>(y)[i] = o;
   }
 }

@@ -206,7 +206,10 @@ class WeightStore:
         h16["conv_in.w"] = pack_conv(sd["conv_in.weight"])
         h16["conv_in.wd"] = pack_conv_dgrad(sd["conv_in.weight"])
         wi = sd["conv_in.weight"]
-        h16["conv_in.w8"] = pack_conv(torch.cat([wi, wi.new_zeros(wi.shape[0], 8 - wi.shape[1], 3, 3)], dim=1))
+        ci = wi.shape[1]
+        parts = [wi, wi] if 2 * ci <= 8 else [wi]            # second copy multiplies the fp16 rounding remainder of the latents
+        parts.append(wi.new_zeros(wi.shape[0], 8 - ci * len(parts), 3, 3))
+        h16["conv_in.w8"] = pack_conv(torch.cat(parts, dim=1))
         f32["conv_in.b"] = sd["conv_in.bias"]
         lin("time_embedding.linear_1", "time_embedding.linear_1")
         lin("time_embedding.linear_2", "time_embedding.linear_2")
