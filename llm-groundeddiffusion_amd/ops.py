@@ -80,7 +80,8 @@ def gemm_desc(a0, w, c, M, N, K, *, a1=None, lda0=None, lda1=0, c0=None, c1=0, t
     if splits is None:
         splits = ent["splits"] if ent else choose_splits(M, N, K, nb_o * nb_i)
     if not tile:
-        tile = ent["tile"] if (ent and ent["splits"] == splits) else choose_tile(M, N, nb_o * nb_i * max(splits, 1), bool(epi & EPI_GEGLU), K)
+        tile = ent["tile"] if (ent and ent["splits"] == splits) else choose_tile(M, N, nb_o * nb_i * max(splits, 1), bool(epi & EPI_GEGLU), K,
+                                                                             pipe_ok=(K % 64 == 0 and d.c0 % 64 == 0 and d.c1 % 64 == 0))
     if splits > 1 and ws is None:
         global WORKSPACE
         need = splits * M * N * nb_o * nb_i
@@ -104,7 +105,7 @@ _PIPE_DIMS = {33: (4, 5, 3), 34: (4, 4, 3), 35: (4, 2, 4), 37: (2, 5, 4), 38: (2
 TILE_NAMES.update({t: f"gemm_pipe_kernel<{mi},{ni},4,2,{ns}> {64 * mi}x{32 * ni}" for t, (mi, ni, ns) in _PIPE_DIMS.items()})
 
 
-def choose_tile(M, N, batches=1, geglu=False, K=64):
+def choose_tile(M, N, batches=1, geglu=False, K=64, pipe_ok=False):
     """Tile heuristic for shapes the tuning table does not list (same rule as the library's auto mode,
     done here so the choice is known to the profiler): the largest tile that still yields enough
     workgroups for 256 CUs; 160-wide tiles when they divide N (every UNet width is 320 k).  Codes
@@ -112,6 +113,17 @@ def choose_tile(M, N, batches=1, geglu=False, K=64):
     wgs = lambda bm, bn: batches * ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
     if M <= 32:
         return 21
+    if pipe_ok:
+        # shapes outside the measured table (VAE decoder, SAM, batch sizes the tuner did not visit): the 8-wave pipelined
+        # tiles, largest first, as soon as they fill the chip once — what the table picks for 2/3 of the UNet's shapes
+        if not geglu and N % 160 == 0 and wgs(256, 160) >= 256:
+            return 33
+        if N % 128 == 0 and wgs(256, 128) >= 256:
+            return 34
+        if not geglu and N % 160 == 0 and wgs(128, 160) >= 256:
+            return 37
+        if N % 128 == 0 and wgs(128, 128) >= 256:
+            return 38
     if not geglu and N % 160 == 0:
         if wgs(128, 160) >= 384:
             return 22
