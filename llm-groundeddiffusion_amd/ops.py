@@ -192,10 +192,12 @@ class LaunchProfiler:
 PROFILER = None
 
 
-def gemm_launch(desc, tag=None):
+def gemm_launch(desc, tag=None, flops=None):
+    """`flops`: algorithmic work when it differs from 2*M*N*K of the launch (conv_in multiplies a zero / remainder-padded K)."""
     if PROFILER is not None:
         nb = desc.nb_o * desc.nb_i
-        flops = 2.0 * desc.M * desc.N * desc.K * nb
+        if flops is None:
+            flops = 2.0 * desc.M * desc.N * desc.K * nb
         nbytes = 2.0 * nb * (desc.M * desc.K / max(desc.taps, 1) + desc.N * desc.K + desc.M * desc.N)
         return PROFILER.wrap(TILE_NAMES.get(desc.tile, "gemm"), flops, nbytes,
                              lambda: _call("lgd_gemm_f16", C.byref(desc), _stream()), tag)

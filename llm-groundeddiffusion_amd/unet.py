@@ -424,7 +424,8 @@ class Plan:
         lat8 = self._new(B * L * L, 8)
         d_in = ops.gemm_desc(lat8, w.h["conv_in.w8"], x0.t, B * L * L, c0, 72, c0=8, lda0=8, taps=9, hin=L, win=L, hout=L,
                              wout=L, bias=w.f["conv_in.b"], ldc=c0, splits=1)
-        self._add(lambda: (ops.nchw_to_nhwc8(lat, out=lat8), ops.gemm_launch(d_in)))
+        f_in = 2.0 * B * L * L * c0 * 9 * cfg.in_channels                   # algorithmic: the filter has 9 x 4 taps, not 72
+        self._add(lambda: (ops.nchw_to_nhwc8(lat, out=lat8), ops.gemm_launch(d_in, None, f_in)))
         skips = [(x, L)]
         H = L
         done = False
