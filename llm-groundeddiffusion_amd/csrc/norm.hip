@@ -490,39 +490,54 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     const int row = row0 + r;
-    if (row < rows) {
-      const int bb = row / rpb, rr = row - bb * rpb;
-      const half_t* xr = x + bb * x_bs + (long)rr * ldx;
+    const int bb = row / rpb, rr = row - bb * rpb;
+    const half_t* xr = x + bb * x_bs + (long)rr * ldx;
 #pragma unroll
-      for (int j = 0; j < MAXV; ++j) {
-        const int v = lane + j * 64;
-        if (v < nvec) h[r][j] = *reinterpret_cast<const half8_t*>(xr + v * 8);
-      }
+    for (int j = 0; j < MAXV; ++j) {
+      const int v = lane + j * 64;
+      h[r][j] = (row < rows && v < nvec) ? *reinterpret_cast<const half8_t*>(xr + v * 8)
+                                         : (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
+  // the ROWS rows of a wave go through every phase together: their butterfly reductions are independent chains that
+  // interleave (one row after the other cost ROWS x two dependent 6-step shuffle chains per wave)
+  float s[ROWS], q[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
-    const int row = row0 + r;
-    if (row >= rows) break;  // wave-uniform
-    float s = 0.f;
+    s[r] = 0.f;
 #pragma unroll
     for (int j = 0; j < MAXV; ++j)
-      if (lane + j * 64 < nvec) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += (float)h[r][j][e];
-      }
-    const float mean = wave_sum(s) / C;
-    float q = 0.f;
+      for (int e = 0; e < 8; ++e) s[r] += (float)h[r][j][e];          // lanes past nvec hold zeros
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) s[r] += __shfl_xor(s[r], o, 64);
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    s[r] /= C;                                                         // mean
+    q[r] = 0.f;
 #pragma unroll
     for (int j = 0; j < MAXV; ++j)
       if (lane + j * 64 < nvec) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float dlt = (float)h[r][j][e] - mean;
-          q += dlt * dlt;
+          const float dlt = (float)h[r][j][e] - s[r];
+          q[r] += dlt * dlt;
         }
       }
-    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) q[r] += __shfl_xor(q[r], o, 64);
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const int row = row0 + r;
+    if (row >= rows) break;  // wave-uniform
+    const float mean = s[r];
+    const float rstd = rsqrtf(q[r] / C + eps);
     if (stats && lane == 0) {
       stats[(long)row * 2] = mean;
       stats[(long)row * 2 + 1] = rstd;
