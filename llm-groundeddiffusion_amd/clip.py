@@ -23,8 +23,8 @@ F16, F32 = torch.float16, torch.float32
 
 @dataclass(frozen=True)
 class CLIPTextConfig:
-    """The fields of transformers' CLIPTextConfig that shape the computation (SD1.x: openai/clip-vit-large-patch14
-    text tower; SD2.x uses hidden 1024, 23 layers of OpenCLIP ViT-H with exact GELU — not covered here)."""
+    """The fields of transformers' CLIPTextConfig that shape the computation (defaults = SD1.x: openai/clip-vit-large-patch14
+    text tower; SD2.x = OpenCLIP ViT-H/14: hidden 1024, 23 layers, 16 heads, intermediate 4096, hidden_act "gelu")."""
     vocab_size: int = 49408
     hidden_size: int = 768
     intermediate_size: int = 3072
@@ -42,8 +42,9 @@ class _Out(tuple):
 
 class HipCLIPTextEncoder:
     def __init__(self, config: CLIPTextConfig, state_dict, device="cuda"):
-        if config.hidden_act != "quick_gelu":
-            raise RuntimeError(f"hidden_act={config.hidden_act!r}: only the quick-GELU text tower of SD1.x is implemented")
+        if config.hidden_act not in ("quick_gelu", "gelu"):
+            raise RuntimeError(f"hidden_act={config.hidden_act!r}: quick_gelu (SD1.x, CLIP ViT-L/14) and gelu (SD2.x, "
+                               "OpenCLIP ViT-H/14) text towers are implemented")
         if config.hidden_size % config.num_attention_heads or (config.hidden_size // config.num_attention_heads) % 8:
             raise RuntimeError("head width must be a multiple of 8")
         self.cfg = config
@@ -89,7 +90,8 @@ class HipCLIPTextEncoder:
             ops.attn_causal_fwd(qkv, qkv[:, C:], qkv[:, 2 * C:], o, B, H, S, d, d ** -0.5, view=(3 * C, S * 3 * C))
             x = ops.linear(o, L["out"][0], L["out"][1], res=x)
             h = ops.layernorm(x, L["ln2"][0], L["ln2"][1], eps)
-            h = ops.quick_gelu(ops.linear(h, L["fc1"][0], L["fc1"][1]))
+            h = ops.linear(h, L["fc1"][0], L["fc1"][1])
+            h = ops.quick_gelu(h) if cfg.hidden_act == "quick_gelu" else ops.act(h, ops.ACT_GELU)
             x = ops.linear(h, L["fc2"][0], L["fc2"][1], res=x)
         y = ops.layernorm(x, self.ln_f[0], self.ln_f[1], eps).float().reshape(B, S, C)
         if cfg.eos_token_id == 2:

@@ -56,3 +56,31 @@ def test_clip_text_encoder_vs_transformers(dev):
     # unpadded phrases of different lengths, as prepare_gligen_condition batches them (padding=True)
     short = enc(ids[:, :32])
     assert relerr(short[0], ref[0][:, :32]) < 2e-2        # causal: a prefix does not depend on what follows
+
+
+def test_clip_text_encoder_sd2_tower_vs_transformers(dev):
+    """SD2.x text tower (OpenCLIP ViT-H/14 as exported for stable-diffusion-2: hidden 1024, 23 layers, 16 heads, exact
+    GELU; BASELINE config 3 uses it for its prompts), random init, vs transformers' CLIPTextModel in fp32."""
+    transformers = pytest.importorskip("transformers")
+    hf_cfg = transformers.CLIPTextConfig(vocab_size=49408, hidden_size=1024, intermediate_size=4096, num_hidden_layers=23,
+                                         num_attention_heads=16, max_position_embeddings=77, hidden_act="gelu",
+                                         eos_token_id=2, bos_token_id=0, pad_token_id=1)
+    torch.manual_seed(0)
+    hf = transformers.CLIPTextModel(hf_cfg).float().eval()
+    cfg = CLIPTextConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=23, num_attention_heads=16,
+                         hidden_act="gelu")
+    enc = HipCLIPTextEncoder(cfg, hf.state_dict(), dev)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1000, 40000, (2, 77), generator=g)
+    ids[:, 0] = 49406
+    for b, n in enumerate((12, 70)):
+        ids[b, n:] = 49407
+    with torch.no_grad():
+        ref = hf(input_ids=ids)
+    out = enc(ids)
+    torch.cuda.synchronize()
+    e_h, e_p = relerr(out[0], ref[0]), relerr(out.pooler_output, ref.pooler_output)
+    print(f"SD2 text tower: hidden relerr {e_h:.3e}, pooled relerr {e_p:.3e}")
+    assert out[0].shape == (2, 77, 1024) and e_h < 2e-2 and e_p < 2e-2
+    with pytest.raises(RuntimeError):
+        HipCLIPTextEncoder(CLIPTextConfig(hidden_act="relu"), hf.state_dict(), dev)
