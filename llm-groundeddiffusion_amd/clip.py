@@ -102,3 +102,14 @@ class HipCLIPTextEncoder:
         out.last_hidden_state = y
         out.pooler_output = y[torch.arange(B, device=self.dev), eos]
         return out
+
+
+def from_hf(hf_text_model, device="cuda"):
+    """A loaded transformers `CLIPTextModel` (any checkpoint of the SD1.x / SD2.x families) -> the HIP encoder with the same
+    call surface; what `models.load_sd` puts into `model_dict.text_encoder`."""
+    c = hf_text_model.config
+    cfg = CLIPTextConfig(vocab_size=c.vocab_size, hidden_size=c.hidden_size, intermediate_size=c.intermediate_size,
+                         num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+                         max_position_embeddings=c.max_position_embeddings, layer_norm_eps=c.layer_norm_eps,
+                         hidden_act=c.hidden_act, eos_token_id=c.eos_token_id)
+    return HipCLIPTextEncoder(cfg, hf_text_model.state_dict(), device)

@@ -56,7 +56,8 @@ def load_synthetic(name="sd14_gligen", seed=0, device="cuda", with_vae=True):
 def load_sd(key="runwayml/stable-diffusion-v1-5", use_fp16=False, load_inverse_scheduler=False,
             use_dpm_multistep_scheduler=False, scheduler_cls=None):
     """models/models.py:16-62.  Needs the Hugging Face checkpoint (diffusers + network/cache); the UNet
-    state dict is repacked into the HIP engine's arenas, CLIP / VAE stay Hugging Face modules."""
+    state dict is repacked into the HIP engine's arenas, the CLIP text tower runs on the HIP kernels
+    (lgd_amd.clip), the VAE stays the Hugging Face module."""
     try:
         from diffusers import AutoencoderKL, DDIMScheduler as HFDDIM, UNet2DConditionModel as HFUNet
         from transformers import CLIPTextModel, CLIPTokenizer
@@ -74,7 +75,8 @@ def load_sd(key="runwayml/stable-diffusion-v1-5", use_fp16=False, load_inverse_s
                               prediction_type=sched_cfg.get("prediction_type", "epsilon"))
     vae = AutoencoderKL.from_pretrained(key, subfolder="vae").to(torch_device)
     tok = CLIPTokenizer.from_pretrained(key, subfolder="tokenizer")
-    te = CLIPTextModel.from_pretrained(key, subfolder="text_encoder").to(torch_device)
+    from lgd_amd.clip import from_hf as _hip_text_encoder
+    te = _hip_text_encoder(CLIPTextModel.from_pretrained(key, subfolder="text_encoder"), torch_device)   # HIP kernels
 
     class _HFVae:
         def decode(self, z):

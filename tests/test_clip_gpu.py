@@ -69,7 +69,9 @@ def test_clip_text_encoder_sd2_tower_vs_transformers(dev):
     hf = transformers.CLIPTextModel(hf_cfg).float().eval()
     cfg = CLIPTextConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=23, num_attention_heads=16,
                          hidden_act="gelu")
-    enc = HipCLIPTextEncoder(cfg, hf.state_dict(), dev)
+    from lgd_amd.clip import from_hf
+    enc = from_hf(hf, dev)                                  # what models.load_sd does with the checkpoint's text tower
+    assert enc.cfg == cfg
     g = torch.Generator().manual_seed(1)
     ids = torch.randint(1000, 40000, (2, 77), generator=g)
     ids[:, 0] = 49406
