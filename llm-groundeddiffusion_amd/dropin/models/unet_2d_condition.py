@@ -97,9 +97,24 @@ class UNet2DConditionModel:
 
     # ---- per-run constants
     @staticmethod
-    def _ident(*tensors):
-        """Identity of device inputs without reading them back: same storage, same shape, not written since."""
-        return tuple((t.data_ptr(), tuple(t.shape), t._version, str(t.dtype)) for t in tensors)
+    def _same(entry, tensors):
+        """Are `tensors` the very tensor OBJECTS cached in `entry`, unwritten since?  The cache keeps references to
+        the tensors, so their storage cannot be freed and handed to another prompt's embeddings at the same address
+        (identity by data_ptr alone would then silently reuse the previous prompt's K/V).  `_version` is unavailable
+        under torch.inference_mode(): treated as "changed" (rebuild)."""
+        if entry is None or len(entry[0]) != len(tensors):
+            return False
+        try:
+            return all(a is b for a, b in zip(entry[0], tensors)) and entry[1] == tuple(t._version for t in tensors)
+        except RuntimeError:
+            return False
+
+    @staticmethod
+    def _remember(tensors):
+        try:
+            return (tuple(tensors), tuple(t._version for t in tensors))
+        except RuntimeError:
+            return None
 
     def _prepare_constants(self, timestep, encoder_hidden_states, gl):
         """Time-embedding rows, text K/V of the 16 cross-attention layers and the GLIGEN grounding tokens do not depend
@@ -117,15 +132,15 @@ class UNet2DConditionModel:
             eng.prepare_timesteps([timestep])
             eng.set_step(0)
             seen["t"] = timestep
-        key = self._ident(encoder_hidden_states)
-        if seen.get("text") != key:
+        text = (encoder_hidden_states,)
+        if not self._same(seen.get("text"), text):
             eng.prepare_text(encoder_hidden_states)
-            seen["text"] = key
+            seen["text"] = self._remember(text)
         if gl is not None and eng.cfg.use_gated_attention:
-            key = self._ident(gl["boxes"], gl["masks"], gl["positive_embeddings"])
-            if seen.get("gligen") != key:
+            gts = (gl["boxes"], gl["masks"], gl["positive_embeddings"])
+            if not self._same(seen.get("gligen"), gts):
                 eng.prepare_gligen(boxes=gl["boxes"], masks=gl["masks"], positive_embeddings=gl["positive_embeddings"])
-                seen["gligen"] = key
+                seen["gligen"] = self._remember(gts)
         eng.const_writer = self
 
     # ---- forward

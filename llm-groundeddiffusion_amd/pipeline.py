@@ -171,13 +171,16 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
                             overall_bg_weight=4.0, ref_ca_loss_weight=2.0, fg_blending_ratio=0.1,
                             use_ref_ca=True, height=512, width=512, decode=True, guidance_attn_keys=None,
                             use_fast_schedule=False, so_center_box=False, so_horizontal_center_only=True,
-                            align_with_overall_bboxes=False, horizontal_shift_only=True, mask_refiner=None):
+                            align_with_overall_bboxes=False, horizontal_shift_only=True, mask_refiner=None,
+                            overall_first_step=0, overall_n_steps=None, overall_start=None):
     """LMD+ (generation/lmd_plus.py:193-520; per-box attention guidance is off by default there,
     max_index_step=0, :203 — with max_index_step > 0 every per-box GLIGEN generation is guided on its own box with
     the energy's default weights, lmd_plus.py:320-328) for a batch of independent layouts: the per-box generations of ALL layouts run
     as one batched denoising call (B = 2 x total boxes), then the overall generations of all layouts as
     another (B = 2 x layouts; guidance pass B = layouts with a per-image loop exit).  Results per layout
-    are independent of how layouts are batched (images only share kernel launches)."""
+    are independent of how layouts are batched (images only share kernel launches).
+    overall_first_step / overall_n_steps / overall_start (one latent tensor per layout): run only those steps of the
+    overall generation, from the given state — the teacher-forcing hook of the parity tests."""
     L = height // 8
     T = num_inference_steps
     frozen_steps = int(T * min(max(frozen_step_ratio, 0.0), 1.0))
@@ -241,11 +244,16 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
                         guidance_attn_keys=keys,
                         ref_maps=_ref_maps(sampler, d["saved"], keys, L, T) if use_ref_ca else None)
         gl = prepare_gligen_condition([list(lay.boxes[i]) for i in flat], lay.phrase_embeddings[flat], dev)
-        jobs_b.append(Job(composed, torch.cat([lay.overall_uncond, lay.overall_cond]), gligen=gl, guidance=guid,
+        start = composed
+        if overall_start is not None:                     # rows 1.. still feed the frozen-mask blend
+            start = composed.clone()
+            start[0] = torch.as_tensor(overall_start[li]).to(start.device, start.dtype)
+        jobs_b.append(Job(start, torch.cat([lay.overall_uncond, lay.overall_cond]), gligen=gl, guidance=guid,
                           frozen_mask=(fg_idx != 0)))
     res_b = sampler.denoise_batch(jobs_b, T, guidance_scale=guidance_scale, use_gligen=True,
                                   gligen_scheduled_sampling_beta=overall_gligen_scheduled_sampling_beta,
-                                  frozen_steps=frozen_steps, save_all_latents=False)
+                                  frozen_steps=frozen_steps, save_all_latents=False, first_step=overall_first_step,
+                                  n_steps=overall_n_steps)
     images = sampler.decode(torch.cat([r["latents"] for r in res_b])) if decode else [None] * len(lays)
     return [dict(image=images[li], latents=res_b[li]["latents"], so_images=per_lay[li]["so_images"],
                  guidance_iters=res_b[li]["guidance_iters"],

@@ -316,7 +316,8 @@ class LMDSampler:
                        use_gligen: bool = False, gligen_scheduled_sampling_beta: float = 0.3,
                        frozen_steps: int = 0, saved_cross_attn_keys: Sequence[Tuple] = (),
                        return_cond_ca_only: bool = False, save_all_latents: bool = True,
-                       trace: Optional[list] = None, fast_after_steps: Optional[int] = None, fast_rate: int = 2):
+                       trace: Optional[list] = None, fast_after_steps: Optional[int] = None, fast_rate: int = 2,
+                       first_step: int = 0, n_steps: Optional[int] = None):
         """Generic 50-step loop over a batch of independent images (one UNet call serves all of them:
         B = 2*len(jobs) for the CFG pass, len(jobs) for the guidance pass).
 
@@ -328,6 +329,9 @@ class LMDSampler:
         fast_after_steps / fast_rate: the optional fast tail (pipelines.py:151-152,358-359 + schedule.py):
           after that many steps only every fast_rate-th timestep is run, with the DDIM step size re-derived
           per step (dynamic_num_inference_steps, lmd_plus.py:109); T_run < T steps are executed.
+        first_step / n_steps: run only steps first_step .. first_step + n_steps - 1 of the schedule, starting from
+          the given latents (which then stand for the state BEFORE step first_step).  Used by the teacher-forced
+          parity tests (one guided step from the reference's own latents of that step) and by partial schedules.
         Returns per job dict(latents (1,C,L,L), latents_all (T_run+1,1,C,L,L), saved {key: [T_run,Bp,H,HW,Tp]},
         guidance_iters).
         """
@@ -400,7 +404,9 @@ class LMDSampler:
 
         # ---- state of this call
         st.lat.copy_(torch.cat([s.to(dev, F32) for s in starts]))
-        st.hist[0].copy_(st.lat)
+        first_step = max(0, min(int(first_step), Tr))
+        last_step = Tr if n_steps is None else min(Tr, first_step + int(n_steps))
+        st.hist[first_step].copy_(st.lat)
         st.mask.zero_()
         if frozen_steps > 0:
             for b, j in enumerate(jobs):
@@ -414,7 +420,7 @@ class LMDSampler:
         saved = [{k: torch.zeros((Tr, Bp, self.heads_of(k), hw[k], 1 if j.token is not None else eng.text_len),
                                  device=dev, dtype=F32) for k in save_keys} for j in jobs]
 
-        for index in range(Tr):
+        for index in range(first_step, last_step):
             eng.set_step(index)
             fuser_on = fuser_at(index)
             if guided and index < max_guided:

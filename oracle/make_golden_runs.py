@@ -74,10 +74,23 @@ def run_lmd_plus():
     o_phr = record_phrase_calls(g.guidance, rec["phrase_calls"])
     o_gl, o_comp = g.pipelines.generate_gligen, g.latents.compose_latents_with_alignment
 
+    # recorder around pipelines.latent_backward_guidance (looked up as a module global by generate_gligen at every
+    # step, pipelines.py:418): its `latents` argument is the state at the START of step `index` — the teacher-forcing
+    # points of tests/test_dropin_gpu.py::test_lmd_plus_overall_stage_teacher_forced
+    o_bg = g.pipelines.latent_backward_guidance
+    starts = []
+
+    def bg(scheduler, unet, cond_embeddings, index, bboxes, object_positions, t, latents, loss, **k):
+        starts.append((int(index), latents.detach().clone()))
+        return o_bg(scheduler, unet, cond_embeddings, index, bboxes, object_positions, t, latents, loss, **k)
+    g.pipelines.latent_backward_guidance = bg
+
     def gl(*a, **k):
+        starts.clear()
         out = o_gl(*a, **k)
         rec["gligen_calls"].append(dict(latents_in=a[1].detach().clone(), out_latents=out[0].detach().clone(),
-                                        latents_all=out[-1].detach().clone() if k.get("save_all_latents") else None))
+                                        latents_all=out[-1].detach().clone() if k.get("save_all_latents") else None,
+                                        starts=[x for _, x in sorted(starts, key=lambda p: p[0])]))
         return out
 
     def comp(*a, **k):
@@ -97,11 +110,15 @@ def run_lmd_plus():
         outs[f"{tag}_composed"] = rec["compose"][0][0].numpy()
         outs[f"{tag}_fg_idx"] = rec["compose"][0][1].numpy()
         outs[f"{tag}_final_latents"] = rec["gligen_calls"][-1]["out_latents"].numpy()
+        ov = rec["gligen_calls"][-1]["starts"]
+        assert len(ov) == 8, len(ov)                       # one call per step of the overall generation
+        outs[f"{tag}_ov_starts"] = torch.stack(ov).numpy()
         for i in range(n):
             outs[f"{tag}_so{i}_latents_all"] = rec["gligen_calls"][i]["latents_all"].numpy()
         outs[f"{tag}_phrase_calls"] = np.array(json.dumps(rec["phrase_calls"]))
         outs[f"{tag}_image_shape"] = np.array(r.image.shape)
     g.pipelines.generate_gligen, g.latents.compose_latents_with_alignment = o_gl, o_comp
+    g.pipelines.latent_backward_guidance = o_bg
     g.guidance.get_phrase_indices = o_phr
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "run_lmd_plus_tiny.npz"), **outs)
     print("wrote run_lmd_plus_tiny.npz", {k: getattr(v, "shape", None) for k, v in outs.items()})

@@ -27,6 +27,7 @@ from lgd_amd.sampler import LMDSampler, prepare_gligen_condition  # noqa: E402
 from lgd_amd.scheduler import DDIMScheduler  # noqa: E402
 from lgd_amd.unet import UNetEngine  # noqa: E402
 import gemm_table_cases as gtc  # noqa: E402
+from conftest import gate  # noqa: E402
 
 H16, F32 = torch.float16, torch.float32
 KEYS = [("mid", 0, 0, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 1, 2, 0)]
@@ -234,12 +235,12 @@ def test_fullsize_cfg_forward_vs_oracle(dev, fuser):
         ref = R.unet_forward(f["sd"], f["cd"], x, 501, ehs, saved=saved, save_keys=keys, fuser_enabled=fuser,
                              gligen=dict(boxes=gl[0].cpu(), positive_embeddings=gl[1].cpu(), masks=gl[2].cpu()))
     e = relerr(eps, ref)
-    print(f"[full, fuser={fuser}] eps relerr {e:.3e} rel-L2 {rel_l2(eps, ref):.3e}")
-    assert e < 2e-2
+    gate(f"[full, fuser={fuser}] eps relerr", e, 5e-3)
+    gate(f"[full, fuser={fuser}] eps rel-L2", rel_l2(eps, ref), 6e-3)
     for k in keys:
         em, el2 = relerr(plan.maps[k], saved[k]), rel_l2(plan.maps[k], saved[k])
-        print(f"[full, fuser={fuser}] map {k} relerr {em:.3e} rel-L2 {el2:.3e}")
-        assert em < 3e-2 and el2 < 1.5e-2
+        gate(f"[full, fuser={fuser}] map {k} relerr", em, 2.7e-2)
+        gate(f"[full, fuser={fuser}] map {k} rel-L2", el2, 1.2e-2)
     _FULL[("eps", fuser)] = eps
     _FULL[("maps", fuser)] = {k: plan.maps[k].clone() for k in keys}
 
@@ -267,13 +268,12 @@ def test_fullsize_batched_plans_match_b2(dev, nb):
     ref = _FULL[("eps", True)]
     for b in range(nb):
         e = max(relerr(eps[b], ref[0]), relerr(eps[nb + b], ref[1]))
-        assert e < 1e-2, (b, e)
+        gate(f"[full B={2 * nb}] eps of image {b} vs B=2", e, 1e-2)
     for k in keys:
         m = plan.maps[k]
         r = _FULL[("maps", True)][k]
         e = max(max(relerr(m[b], r[0]), relerr(m[nb + b], r[1])) for b in range(nb))
-        print(f"[full B={2 * nb}] map {k} vs B=2: {e:.3e}")
-        assert e < 2e-2
+        gate(f"[full B={2 * nb}] map {k} vs B=2", e, 2.8e-2)
 
 
 def test_fullsize_guidance_iteration_vs_oracle(dev):
@@ -301,7 +301,83 @@ def test_fullsize_guidance_iteration_vs_oracle(dev):
     l_hip, l_ref = tr[0]["loss"], tr_ref[0]["loss"]
     print(f"[full] guidance loss hip {l_hip:.4f} oracle {l_ref:.4f}; latent-gradient cosine {cos:.5f} "
           f"rel-L2 {rel_l2(a, b):.3e}")
-    assert abs(l_hip - l_ref) / abs(l_ref) < 2e-2 and cos > 0.98
+    gate("[full] guidance loss rel. error", abs(l_hip - l_ref) / abs(l_ref), 1e-4)
+    gate("[full] latent-gradient cosine", cos, 0.99988, at_least=True)
+    gate("[full] latent-gradient rel-L2", rel_l2(a, b), 2.7e-2)
+
+
+def test_fullsize_guided_gligen_loop_vs_oracle(dev):
+    """A 2-step guided generate_gligen loop (models/pipelines.py:323-473) at FULL width (sd14_gligen, L = 64): step 0
+    runs with the GLIGEN fuser on, one backward-guidance iteration and the frozen-mask blend, step 1 with the fuser off
+    and one more guidance iteration — latents after each step vs oracle/restate.py on the box's host cores."""
+    import restate as R
+    f = full(dev)
+    cfg, eng = f["cfg"], f["eng"]
+    x, ehs, cond, gl = _inputs(cfg, dev)
+    g = torch.Generator().manual_seed(5)
+    T = 2
+    hist_in = torch.randn((T + 1, 1, 4, 64, 64), generator=g)
+    hist_in[0] = x[:1]
+    fm = torch.zeros(64, 64, dtype=torch.bool)
+    fm[22:52, 10:32] = True
+    # _inputs() draws x first and the phrase embeddings second from one generator: rebuild them the same way
+    g0 = torch.Generator().manual_seed(0)
+    torch.randn((2, 4, 64, 64), generator=g0)
+    pe = torch.randn((2, cfg.gligen_positive_len), generator=g0)
+    guid = dict(bboxes=BOXES, object_positions=OBJ_POS, loss_scale=5, loss_threshold=0.0, max_iter=[1, 1],
+                max_index_step=2, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+    sm = LMDSampler(eng, DDIMScheduler())
+    out = sm.denoise(hist_in, ehs, T, gligen=gl, gligen_scheduled_sampling_beta=0.5, guidance=guid, frozen_steps=1,
+                     frozen_mask=fm)
+    torch.cuda.synchronize()
+    per_step = []
+    sk = {k: v for k, v in guid.items() if k not in ("bboxes", "object_positions")}
+    with torch.enable_grad():
+        R.generate_gligen(f["sd"], f["cd"], R.DDIM(), hist_in, (ehs, None, cond), T, BOXES, pe,
+                          gligen_scheduled_sampling_beta=0.5, frozen_steps=1, frozen_mask=fm, semantic_guidance=True,
+                          semantic_guidance_bboxes=BOXES, semantic_guidance_object_positions=OBJ_POS,
+                          semantic_guidance_kwargs=sk, per_step=per_step)
+    assert out["guidance_iters"] == 2
+    for i in range(T):
+        e, el2 = relerr(out["latents_all"][i + 1], per_step[i]), rel_l2(out["latents_all"][i + 1], per_step[i])
+        print(f"[full loop] latents after step {i}: relerr {e:.3e} rel-L2 {el2:.3e}")
+        assert e < 1.5e-2 and el2 < 5e-3
+
+
+def test_fullsize_sd21_guidance_iteration_vs_oracle(dev):
+    """BASELINE config 3 closed at full width: one latent_backward_guidance iteration (pipelines.py:16-82 as
+    generation/backward_guidance.py:99-120 calls it) on the SD2.1-768 topology at 96x96 latents — loss (HW = 144 / 576
+    energy maps) and the latent gradient through the dgrad plan of the 96^2 network vs the oracle."""
+    import restate as R
+    cfg = weights.CONFIGS["sd21"]
+    sd = weights.synth_state_dict(cfg, 0)
+    eng = UNetEngine(cfg, dev, sd)
+    cd = dict(block_out_channels=cfg.block_out_channels, layers_per_block=cfg.layers_per_block,
+              attention_head_dim=cfg.attention_head_dim, norm_num_groups=cfg.norm_num_groups, norm_eps=cfg.norm_eps,
+              gligen_positive_len=cfg.gligen_positive_len)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    L = cfg.sample_size
+    x = torch.randn((1, 4, L, L), generator=torch.Generator().manual_seed(0))
+    _, cond = weights.synth_embeddings(cfg, 1, seed=1)
+    sm = LMDSampler(eng, DDIMScheduler(prediction_type=cfg.prediction_type))
+    guid = dict(bboxes=BOXES, object_positions=OBJ_POS, loss_scale=30, loss_threshold=0.0, max_iter=1,
+                max_index_step=25, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+    tr, tr_ref = [], []
+    sm.guidance_only(x, cond, 50, 1, guid, trace=tr)
+    rs = R.DDIM(prediction_type=cfg.prediction_type)
+    rs.set_timesteps(50)
+    R.latent_backward_guidance(sd, cd, rs, cond, 1, BOXES, OBJ_POS, rs.timesteps[1], x.clone(), torch.tensor(1e4),
+                               loss_scale=30, loss_threshold=0.0, max_iter=1, max_index_step=25,
+                               guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0,
+                               trace=tr_ref)
+    a, b = tr[0]["grad"].cpu().double().reshape(-1), tr_ref[0]["grad"].double().reshape(-1)
+    cos = float(a @ b / (a.norm() * b.norm()))
+    l_hip, l_ref = tr[0]["loss"], tr_ref[0]["loss"]
+    print(f"[sd21 full] guidance loss hip {l_hip:.4f} oracle {l_ref:.4f}; latent-gradient cosine {cos:.5f} "
+          f"rel-L2 {rel_l2(a, b):.3e}")
+    assert abs(l_hip - l_ref) / abs(l_ref) < 5e-3 and cos > 0.999
+    del eng
+    torch.cuda.empty_cache()
 
 
 def test_fullsize_sd21_forward_vs_oracle(dev):
@@ -329,11 +405,11 @@ def test_fullsize_sd21_forward_vs_oracle(dev):
     with torch.no_grad():
         ref = R.unet_forward(sd, cd, x, 501, ehs, saved=saved, save_keys=KEYS)
     e = relerr(eps, ref)
-    print(f"[sd21 full] eps relerr {e:.3e} rel-L2 {rel_l2(eps, ref):.3e}")
-    assert e < 2e-2
+    gate("[sd21 full] eps relerr", e, 6e-3)
+    gate("[sd21 full] eps rel-L2", rel_l2(eps, ref), 6e-3)
     for k in KEYS:
         em, el2 = relerr(plan.maps[k], saved[k]), rel_l2(plan.maps[k], saved[k])
-        print(f"[sd21 full] map {k} relerr {em:.3e} rel-L2 {el2:.3e}")
-        assert em < 3e-2 and el2 < 1.5e-2
+        gate(f"[sd21 full] map {k} relerr", em, 3e-2)
+        gate(f"[sd21 full] map {k} rel-L2", el2, 1.3e-2)
     del eng
     torch.cuda.empty_cache()

@@ -23,6 +23,7 @@ def relerr(a, b):
 
 
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import gate  # noqa: E402
 from fake_text import FakeTextEncoder, FakeTokenizer  # noqa: E402
 
 
@@ -219,6 +220,36 @@ def test_unet_wrapper_reuses_run_constants(dropin, dev):
         eng.prepare_text, eng.prepare_gligen, eng.prepare_timesteps = orig
 
 
+def test_unet_wrapper_second_prompt_after_first_was_freed(dropin, dev):
+    """Two prompts back to back with the first prompt's tensors FREED in between: the caching allocator hands the
+    second prompt the same address / shape / version 0 — the constants cache must not mistake it for the first (it
+    keys on the tensor objects it keeps alive, not on data_ptr).  Also: torch.inference_mode() (no `_version`) works
+    and simply rebuilds."""
+    md = dropin.model_dict
+    g = np.load(os.path.join(GOLD, "unet_fwd_tiny.npz")) if not md.unet.engine.cfg.use_gated_attention else \
+        np.load(os.path.join(GOLD, "unet_fwd_tiny_gligen.npz"))
+    x = torch.from_numpy(g["x"]).to(dev)
+    t = torch.tensor(int(g["t"]))
+    from models import pipelines
+    pipelines.gligen_enable_fuser(md.unet, False)
+    e1 = torch.from_numpy(g["ehs"]).to(dev).clone()
+    ptr1 = e1.data_ptr()
+    a = md.unet(x, t, encoder_hidden_states=e1).sample.clone()
+    del e1
+    e2 = (torch.from_numpy(g["ehs"]).flip(1) * 0.7).to(dev).clone()           # a different prompt, likely the same address
+    same_addr = e2.data_ptr() == ptr1
+    b = md.unet(x, t, encoder_hidden_states=e2).sample.clone()
+    md.unet.engine.prepare_text(e2)                                            # ground truth: constants rebuilt by hand
+    md.unet.__dict__.pop("_const_seen", None)
+    c = md.unet(x, t, encoder_hidden_states=e2).sample.clone()
+    print(f"second prompt reused the freed address: {same_addr}")
+    assert torch.equal(b, c) and not torch.equal(a, b)
+    with torch.inference_mode():
+        e3 = e2.clone()
+        d = md.unet(x, t, encoder_hidden_states=e3).sample.clone()
+    assert torch.equal(d.cpu(), c.cpu())
+
+
 def test_pipelines_generate_partial_frozen_signature(dropin, dev):
     """models.pipelines.generate_partial_frozen with the reference's positional signature."""
     import lgd_amd  # noqa: F401
@@ -269,13 +300,15 @@ def test_lmd_plus_run_vs_reference_run_golden(dropin, dev):
             assert out["guidance_iters"] == 4 and torch.equal(out["fg_idx"].cpu(), torch.from_numpy(gold[f"{tag}_fg_idx"]))
             for i in range(n):
                 e = relerr(out["so_latents_all"][i][:gold[f"{tag}_so{i}_latents_all"].shape[0]], gold[f"{tag}_so{i}_latents_all"])
-                assert e < 5e-2, (tag, i, e)
+                gate(f"[run {tag}] per-box history {i}", e, 5e-2)
             e_c, e_f = relerr(out["composed"], gold[f"{tag}_composed"]), relerr(out["latents"], gold[f"{tag}_final_latents"])
             print(f"[run {tag}] composed relerr {e_c:.3e}, final latents relerr {e_f:.3e}")
             # composed latents (no guidance upstream) stay at 3e-3; the final latents sit behind four guided steps whose
             # top-k selections flip on near-ties between the fp16 path and the fp32 golden: max-norm 3.9e-2 .. 5.6e-2
             # depending on rounding order upstream (measured before / after the GroupNorm statistics' tree reduction)
-            assert out["composed"].shape == gold[f"{tag}_composed"].shape and e_c < 1e-2 and e_f < 8e-2
+            assert out["composed"].shape == gold[f"{tag}_composed"].shape
+            gate(f"[run {tag}] composed", e_c, 9e-3)
+            gate(f"[run {tag}] final latents (free-running; per-step gate: test_lmd_plus_overall_stage_teacher_forced)", e_f, 8e-2)
             # the plugin entry point runs the same thing and only hands back the image
             r = g.run(spec, bg_seed=seeds[0], fg_seed_start=seeds[1], num_inference_steps=8, frozen_step_ratio=0.5,
                       overall_max_index_step=3, overall_max_iter=[2, 1, 1], overall_loss_threshold=0.0, **extra)
@@ -290,6 +323,43 @@ def test_lmd_plus_run_vs_reference_run_golden(dropin, dev):
     finally:
         sys.path.remove(os.path.join(ROOT, "oracle", "stubs"))
         sys.modules.pop("inflect", None)
+
+
+def test_lmd_plus_overall_stage_teacher_forced(dropin, dev):
+    """Every step of the reference run()'s OVERALL generation (generation/lmd_plus.py:418-470 -> pipelines.generate_gligen
+    with semantic guidance, reference-attention transfer and the frozen-mask blend), one step at a time from the
+    reference's own latents at the start of that step (`*_ov_starts`, recorded around pipelines.latent_backward_guidance
+    by oracle/make_golden_runs.py).  The free-running comparison of the final latents (test below) sits behind four
+    guided steps whose top-k selections amplify rounding differences; here nothing accumulates."""
+    import models
+    keep = models.model_dict
+    models.model_dict = dropin.model_dict
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "stubs"))
+    try:
+        from generation._common import DEFAULT_OVERALL_NEGATIVE_PROMPT, DEFAULT_SO_NEGATIVE_PROMPT, build_layout
+        from lgd_amd.pipeline import lmd_plus_generate
+        gold = np.load(os.path.join(GOLD, "run_lmd_plus_tiny.npz"))
+        sm = dropin.model_dict.sampler
+        for tag, spec, seeds, extra in (("a", SPEC, (3, 3 + 123456789), {}), ("b", SPEC3, (11, 77), dict(use_fast_schedule=True))):
+            lay = build_layout(spec, seeds[0], seeds[1], DEFAULT_SO_NEGATIVE_PROMPT, DEFAULT_OVERALL_NEGATIVE_PROMPT, 256, 256)
+            kw = dict(num_inference_steps=8, frozen_step_ratio=0.5, overall_max_index_step=3, overall_max_iter=[2, 1, 1],
+                      overall_loss_threshold=0.0, height=256, width=256, decode=False, **extra)
+            starts = gold[f"{tag}_ov_starts"]
+            worst_g, worst_u = 0.0, 0.0
+            for i in range(8):
+                out = lmd_plus_generate(sm, lay, overall_first_step=i, overall_n_steps=1, overall_start=[starts[i]], **kw)
+                want = starts[i + 1] if i < 7 else gold[f"{tag}_final_latents"]
+                e = relerr(out["latents"], want)
+                print(f"[run {tag}] overall step {i} teacher-forced: relerr {e:.3e} (guidance iterations {out['guidance_iters']})")
+                assert out["guidance_iters"] == ([2, 1, 1] + [0] * 5)[i]
+                if i < 3:
+                    worst_g = max(worst_g, e)
+                else:
+                    worst_u = max(worst_u, e)
+            gate(f"[run {tag}] worst guided overall step", worst_g, 3e-2)
+            gate(f"[run {tag}] worst unguided overall step", worst_u, 1e-2)
+    finally:
+        models.model_dict = keep
 
 
 def test_lmd_run_vs_reference_run_golden(dev):
@@ -315,6 +385,7 @@ def test_lmd_run_vs_reference_run_golden(dev):
         assert torch.equal(out["fg_idx"].cpu(), torch.from_numpy(gold["fg_idx"]))
         e_c, e_f = relerr(out["composed"], gold["composed"]), relerr(out["latents"], gold["final_latents"])
         print(f"[run lmd] composed relerr {e_c:.3e}, final latents relerr {e_f:.3e}")
-        assert e_c < 5e-2 and e_f < 5e-2
+        gate("[run lmd] composed", e_c, 5e-2)
+        gate("[run lmd] final latents", e_f, 3.9e-2)
     finally:
         models.model_dict = keep

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import lgd_amd  # noqa: E402,F401
+from conftest import gate  # noqa: E402
 from lgd_amd import weights  # noqa: E402
 from lgd_amd.unet import UNetEngine  # noqa: E402
 from lgd_amd.sampler import LMDSampler, prepare_gligen_condition  # noqa: E402
@@ -77,16 +78,15 @@ def test_unet_forward_and_maps_vs_reference_golden(dev, name):
     eps = plan.forward(torch.from_numpy(g["x"]).to(dev))
     torch.cuda.synchronize()
     e = relerr(eps, g["eps"])
-    print(f"[{name}] eps relerr {e:.3e}")
-    assert e < 2e-2
+    gate(f"[{name}] eps relerr", e, 8e-3)
     for k in [OBJ_KEY, *KEYS]:
         # fp16 engine vs the fp32 reference after up to ~20 layers, softmax sharpened by the x4 to_q/to_k
         # weights: max-abs error within 3 % of the map's peak, rel-L2 within 1.5 %
         em = relerr(plan.maps[k], g["map_" + ks(k)])
         ref = torch.from_numpy(g["map_" + ks(k)]).to(dev).float()
         el2 = float((plan.maps[k].float() - ref).norm() / ref.norm())
-        print(f"[{name}] map {k} relerr {em:.3e} rel-L2 {el2:.3e}")
-        assert em < 3e-2 and el2 < 1.5e-2
+        gate(f"[{name}] map {k} relerr", em, 3e-2)
+        gate(f"[{name}] map {k} rel-L2", el2, 1.5e-2)
 
 
 def test_energy_kernel_vs_reference_golden(dev):
@@ -138,13 +138,15 @@ def test_backward_guidance_vs_reference_golden(dev, name):
     c0 = cosine(tr[0]["grad"], g["grad0"])
     r0 = rel_l2(tr[0]["grad"], g["grad0"])
     print(f"[{name}] first-iteration latent gradient: cosine {c0:.5f} rel-L2 {r0:.3e}")
-    assert abs(tr[0]["loss"] - float(g["losses"][0])) / float(g["losses"][0]) < 2e-2
-    assert c0 > 0.98 and r0 < 0.2
+    gate(f"[{name}] first loss rel. error", abs(tr[0]["loss"] - float(g["losses"][0])) / float(g["losses"][0]), 4e-4)
+    gate(f"[{name}] last loss rel. error", abs(tr[-1]["loss"] - float(g["losses"][-1])) / float(g["losses"][-1]), 1.5e-3)
+    gate(f"[{name}] first gradient cosine", c0, 0.9998, at_least=True)
+    gate(f"[{name}] first gradient rel-L2", r0, 3.5e-2)
     d_hip = lat.cpu() - torch.from_numpy(g["latents_in"])
     d_ref = torch.from_numpy(g["latents_out"]) - torch.from_numpy(g["latents_in"])
     c = cosine(d_hip, d_ref)
-    print(f"[{name}] total latent update: cosine {c:.5f} rel-L2 {rel_l2(d_hip, d_ref):.3e}")
-    assert c > 0.95
+    gate(f"[{name}] total latent update cosine", c, 0.9991, at_least=True)
+    gate(f"[{name}] total latent update rel-L2", rel_l2(d_hip, d_ref), 7e-2)
 
 
 def test_partial_frozen_and_semantic_guidance_loops(dev):
@@ -160,7 +162,10 @@ def test_partial_frozen_and_semantic_guidance_loops(dev):
     torch.cuda.synchronize()
     e = relerr(out["latents"], g["partial_frozen_out"])
     print(f"partial_frozen final latents relerr {e:.3e} (guidance iters {out['guidance_iters']})")
-    assert out["guidance_iters"] == 3 and e < 5e-2
+    assert out["guidance_iters"] == 3
+    # free-running 4-step guided loop: the error of a step is amplified by the next steps' top-k selections (the
+    # per-step error is gated at 1.5e-2 by test_teacher_forced_guided_steps_vs_reference_golden)
+    gate("partial_frozen final latents (free-running)", e, 5e-2)
     out = sm.denoise(torch.from_numpy(g["lat0"]), ehs, 4, guidance=guid,
                      saved_cross_attn_keys=[OBJ_KEY, *KEYS], return_cond_ca_only=True, return_token_ca_only=3)
     torch.cuda.synchronize()
@@ -169,7 +174,8 @@ def test_partial_frozen_and_semantic_guidance_loops(dev):
     print(f"semantic_guidance latents_all relerr {e:.3e}, saved map rel-L2 {em:.3e}")
     # maps after guided steps inherit the top-k selection sensitivity of the energy (fp16 vs fp32 can
     # pick different near-tied positions), hence an L2 criterion rather than a max-norm one
-    assert e < 5e-2 and em < 1e-1
+    gate("semantic_guidance latents_all", e, 1.7e-2)
+    gate("semantic_guidance saved map rel-L2", em, 1.6e-2)
 
 
 def test_gligen_loop(dev):
@@ -190,7 +196,56 @@ def test_gligen_loop(dev):
     print(f"gligen latents_all relerr {e:.3e}, saved map rel-L2 {em:.3e}, iters {out['guidance_iters']}")
     # the map saved after a guided step sits behind the energy's top-k selection (see above): any change of a rounding
     # order upstream (here: the tree reduction of the GroupNorm statistics) moves it by a few percent: 0.09 -> 0.115
-    assert out["guidance_iters"] == 4 and e < 5e-2 and em < 1.5e-1
+    assert out["guidance_iters"] == 4
+    gate("gligen latents_all (free-running)", e, 5e-2)
+    gate("gligen saved map rel-L2 (free-running, behind 3 guided steps)", em, 1.5e-1)
+
+
+@pytest.mark.parametrize("which", ["semantic_guidance", "gligen"])
+def test_teacher_forced_guided_steps_vs_reference_golden(dev, which):
+    """Every step of the reference's own guided loops, replayed ONE AT A TIME from the reference's own latents of
+    that step (the goldens carry the per-step histories): guidance iterations + CFG pass + DDIM update (+ frozen
+    blend) of step i start from golden[i] and must land on golden[i+1].  This separates the arithmetic error of a
+    guided step from the chaos the free-running loops accumulate behind the energy's top-k selection
+    (models/pipelines.py:16-82, 129-247, 323-473), so the gates here are tight."""
+    if which == "semantic_guidance":
+        g = np.load(os.path.join(GOLD, "loops_tiny.npz"))
+        eng, hist_ref, mi, mis = engine("tiny", dev), g["sg_latents_all"], [2, 1], 2
+    else:
+        g = np.load(os.path.join(GOLD, "loops_tiny_gligen.npz"))
+        eng, hist_ref, mi, mis = engine("tiny_gligen", dev), g["gligen_latents_all"], [2, 1], 3
+    sm = LMDSampler(eng, DDIMScheduler())
+    ehs = torch.from_numpy(g["ehs"])
+    guid = dict(bboxes=BBOXES, object_positions=OBJ_POS, loss_scale=5, loss_threshold=0.0, max_iter=mi,
+                max_index_step=mis, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0,
+                bg_weight=4.0)
+    worst = 0.0
+    for i in range(4):
+        if which == "semantic_guidance":
+            out = sm.denoise(torch.from_numpy(hist_ref[i]), ehs, 4, guidance=guid, first_step=i, n_steps=1,
+                             saved_cross_attn_keys=[OBJ_KEY, *KEYS], return_cond_ca_only=True, return_token_ca_only=3)
+        else:
+            gl = prepare_gligen_condition(BBOXES, torch.from_numpy(g["phrase_emb"]), dev)
+            h_in = torch.from_numpy(g["lat_all_in"]).clone()
+            h_in[0] = torch.from_numpy(hist_ref[i])              # state before step i; rows i+1.. feed the frozen blend
+            out = sm.denoise(h_in, ehs, 4, gligen=gl, gligen_scheduled_sampling_beta=0.5, guidance=guid, frozen_steps=2,
+                             frozen_mask=torch.from_numpy(g["frozen_mask"]), first_step=i, n_steps=1,
+                             saved_cross_attn_keys=[OBJ_KEY, *KEYS], return_cond_ca_only=True, return_token_ca_only=7)
+        torch.cuda.synchronize()
+        e = relerr(out["latents_all"][i + 1], hist_ref[i + 1])
+        want = (mi[i] if i < len(mi) else mi[-1]) if i < mis else 0
+        print(f"[{which}] teacher-forced step {i}: latents relerr {e:.3e} (guidance iterations {out['guidance_iters']})")
+        assert out["guidance_iters"] == want
+        worst = max(worst, e)
+        if which == "semantic_guidance" and i == 0:
+            em = rel_l2(out["saved"][("up", 1, 1, 0)][0], g["sg_saved_up11_step0"])
+            print(f"[{which}] teacher-forced saved map (step 0) rel-L2 {em:.3e}")
+            assert em < 3e-2
+        if which == "gligen" and i == 1:
+            em = rel_l2(out["saved"][("up", 1, 1, 0)][1], g["gligen_saved_up11_step1"])
+            print(f"[{which}] teacher-forced saved map (step 1) rel-L2 {em:.3e}")
+            assert em < 3e-2
+    assert worst < 1.5e-2
 
 
 def test_hip_vae_decoder_vs_torch(dev):
@@ -204,8 +259,8 @@ def test_hip_vae_decoder_vs_torch(dev):
     out = hip.decode(z)
     torch.cuda.synchronize()
     e = relerr(out, ref)
-    print(f"VAE decode relerr {e:.3e}")
-    assert out.shape == ref.shape and e < 2e-2
+    assert out.shape == ref.shape
+    gate("VAE decode relerr (reduced width)", e, 4.2e-3)
 
 
 def test_batched_denoise_matches_single(dev):
@@ -236,7 +291,7 @@ def test_batched_denoise_matches_single(dev):
         e = relerr(rb["latents_all"], rs["latents_all"])
         em = rel_l2(rb["saved"][("up", 1, 1, 0)], rs["saved"][("up", 1, 1, 0)])
         print(f"batched vs single: latents {e:.3e} maps {em:.3e}")
-        assert e < 3e-2 and em < 6e-2
+        assert e < 1e-6 and em < 1e-6          # measured: bit-identical (the buckets give both runs the same tiles)
 
 
 def test_fast_schedule_denoise(dev):
@@ -284,7 +339,7 @@ def test_lmd_batched_layouts_match_single_and_fast_schedule_runs(dev):
         print(f"LMD batched vs single: latents {e:.3e}; iters {rb['guidance_iters']} / {rs['guidance_iters']}")
         assert rb["guidance_iters"] == rs["guidance_iters"] == 3
         assert rb["so_guidance_iters"] == rs["so_guidance_iters"] == [2] * len(lay.boxes)
-        assert e < 3e-2
+        gate("LMD batched vs single latents", e, 7e-3)
     fast = lmd_generate(sm, lay1, use_fast_schedule=True, **kw)
     assert torch.isfinite(fast["latents"]).all() and fast["guidance_iters"] == 3
 
@@ -326,7 +381,9 @@ def test_fast_schedule_loop_vs_reference_golden(dev):
     e_fin = relerr(out["latents"], g["latents"])
     em = rel_l2(out["saved"][("up", 1, 1, 0)][n_run - 1], g["saved_up11_last"])
     print(f"fast schedule: history relerr {e_hist:.3e}, final latents {e_fin:.3e}, last map rel-L2 {em:.3e}")
-    assert e_hist < 3e-2 and e_fin < 5e-2 and em < 1e-1
+    gate("fast schedule history", e_hist, 1e-2)
+    gate("fast schedule final latents", e_fin, 9.5e-3)
+    gate("fast schedule last map rel-L2", em, 2.4e-2)
 
 
 def test_layout_without_boxes(dev):
@@ -346,8 +403,8 @@ def test_layout_without_boxes(dev):
     both = lmd_plus_generate_batch(sm, [full, empty], **kw)
     alone = lmd_plus_generate(sm, full, **kw)
     assert both[1]["guidance_iters"] == 0 and both[0]["guidance_iters"] == alone["guidance_iters"] == 2
-    assert relerr(both[0]["latents"], alone["latents"]) < 3e-2
-    assert relerr(both[1]["latents"], out["latents"]) < 3e-2
+    gate("2-box layout batched with an empty one vs alone", relerr(both[0]["latents"], alone["latents"]), 3e-2)
+    gate("empty layout batched vs alone", relerr(both[1]["latents"], out["latents"]), 3e-2)
 
 
 def test_plans_alias_one_arena_and_do_not_depend_on_stale_data(dev):
@@ -407,12 +464,14 @@ def test_many_boxes_are_chunked_and_padded_to_buckets(dev):
     a = lmd_plus_generate(sm8, lay10, **kw)
     b = lmd_plus_generate(sm3, lay10, **kw)
     assert torch.isfinite(a["latents"]).all() and a["guidance_iters"] == 2
-    assert relerr(a["composed"], b["composed"]) < 3e-2 and relerr(a["latents"], b["latents"]) < 3e-2
+    gate("10 boxes, chunk 8 vs 3: composed", relerr(a["composed"], b["composed"]), 3e-2)
+    gate("10 boxes, chunk 8 vs 3: latents", relerr(a["latents"], b["latents"]), 3e-2)
     lays = [CachedLayout.synthetic(cfg, boxes10[3 * i:3 * i + 3], 30 + i) for i in range(3)]
     both = lmd_plus_generate_batch(sm8, lays, **kw)
     for lay, rb in zip(lays, both):
         rs = lmd_plus_generate(sm8, lay, **kw)
-        assert relerr(rb["latents"], rs["latents"]) < 3e-2 and rb["guidance_iters"] == rs["guidance_iters"] == 2
+        gate("3x3 boxes batched vs single", relerr(rb["latents"], rs["latents"]), 3e-2)
+        assert rb["guidance_iters"] == rs["guidance_iters"] == 2
     with pytest.raises(RuntimeError):
         eng.prepare_text(torch.zeros(eng.max_text_batch + 1, 77, cfg.cross_attention_dim))
 

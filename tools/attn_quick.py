@@ -7,8 +7,11 @@ import lgd_amd
 from lgd_amd import ops
 dev = torch.device("cuda:0")
 print("LGD_ATTN_NW =", os.environ.get("LGD_ATTN_NW", "4"))
-for (B, H, S, Sk, d) in [(16, 8, 4096, 4096, 40), (8, 8, 4096, 4096, 40), (8, 8, 4096, 4126, 40), (16, 8, 1024, 1024, 80),
-                         (16, 8, 1024, 1054, 80), (8, 5, 9216, 9216, 64), (16, 8, 256, 256, 160)]:
+SHAPES = [(16, 8, 4096, 4096, 40), (8, 8, 4096, 4096, 40), (8, 8, 4096, 4126, 40), (16, 8, 1024, 1024, 80),
+          (16, 8, 1024, 1054, 80), (8, 5, 9216, 9216, 64), (16, 8, 256, 256, 160)]
+if os.environ.get("FIRST"):
+    SHAPES = SHAPES[:int(os.environ["FIRST"])]
+for (B, H, S, Sk, d) in SHAPES:
     C = H * d
     g = torch.Generator().manual_seed(0)
     q = torch.randn(B, S, C, generator=g).to(dev).half()
