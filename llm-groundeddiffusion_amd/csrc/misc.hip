@@ -238,8 +238,8 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const half_t* __res
 
 // Row softmax of scale*x (fp16 in/out, fp32 math), one wave per row; used by the single-head
 // 512-channel attention of the VAE decoder mid block (the flash kernel covers head dims <= 160).
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const half_t* __restrict__ x,
-                                                            half_t* __restrict__ y, long rows, int n,
+// (x and y may be the same buffer: every lane rewrites only elements it has read itself)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const half_t* x, half_t* y, long rows, int n,
                                                             float scale) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);

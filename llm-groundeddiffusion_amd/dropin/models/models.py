@@ -57,7 +57,8 @@ def load_sd(key="runwayml/stable-diffusion-v1-5", use_fp16=False, load_inverse_s
             use_dpm_multistep_scheduler=False, scheduler_cls=None):
     """models/models.py:16-62.  Needs the Hugging Face checkpoint (diffusers + network/cache); the UNet
     state dict is repacked into the HIP engine's arenas, the CLIP text tower runs on the HIP kernels
-    (lgd_amd.clip), the VAE stays the Hugging Face module."""
+    (lgd_amd.clip), the VAE decoder's state dict is repacked for the HIP kernels (lgd_amd.vae.HipVAEDecoder;
+    LGD_HF_VAE=1 in the environment keeps the Hugging Face module, for A/B checks against it)."""
     try:
         from diffusers import AutoencoderKL, DDIMScheduler as HFDDIM, UNet2DConditionModel as HFUNet
         from transformers import CLIPTextModel, CLIPTokenizer
@@ -81,7 +82,13 @@ def load_sd(key="runwayml/stable-diffusion-v1-5", use_fp16=False, load_inverse_s
     class _HFVae:
         def decode(self, z):
             return vae.decode(z.to(vae.dtype)).sample
-    return build_model_dict(cfg, {k: v.float() for k, v in hf.state_dict().items()}, vae=_HFVae(), tokenizer=tok,
+    import os as _os
+    if _os.environ.get("LGD_HF_VAE", "0") == "1":
+        dec = _HFVae()
+    else:
+        from lgd_amd.vae import HipVAEDecoder
+        dec = HipVAEDecoder.from_state_dict(vae.state_dict(), torch_device)      # models/models.py:41 on the HIP kernels
+    return build_model_dict(cfg, {k: v.float() for k, v in hf.state_dict().items()}, vae=dec, tokenizer=tok,
                             text_encoder=te, scheduler_config=sched_cfg)
 
 

@@ -1,17 +1,26 @@
-"""VAE decoder ([ext] diffusers AutoencoderKL, SD 1.x config).  It sits inside the images/s window
-because pipelines.decode (models/pipelines.py:117-127) runs once per box and once per image
+"""VAE decoder ([ext] diffusers AutoencoderKL, SD 1.x / 2.x config).  It sits inside the images/s window
+because pipelines.decode (models/pipelines.py:117-127, 588-595) runs once per box and once per image
 (SURVEY.md §8a P7, §8f rank 1).
 
 Two implementations of the same module:
-  * VAEDecoder      — plain PyTorch (reference for tests; on a fresh MI355X box MIOpen falls back to
-                      its naive convolution, 0.16 s per conv, which would dominate the benchmark);
-  * HipVAEDecoder   — the same weights run through the engine's own kernels (implicit-GEMM conv,
-                      GroupNorm+SiLU, GEMM + row softmax for the single 512-channel attention).
+  * VAEDecoder      — plain PyTorch fp32 restatement (the parity reference of the tests; on a fresh MI355X box
+                      MIOpen falls back to its naive convolution, 0.16 s per conv, which would dominate the
+                      benchmark).  `aekl_state_dict()` emits its parameters under AutoencoderKL's key names.
+  * HipVAEDecoder   — runs an AutoencoderKL DECODER state dict (`AutoencoderKL.state_dict()` of a real checkpoint,
+                      models/models.py:41, or VAEDecoder.aekl_state_dict()) on the engine's own kernels:
+                      implicit-GEMM convolutions, GroupNorm+SiLU, and for the single 512-wide mid-block attention
+                      three batched GEMM launches + a row softmax for the whole batch.
 
-Random-init weights of the exact decoder architecture (there are no checkpoints in the sandbox):
-post_quant_conv 4->4, conv_in 4->512, mid (resnet, 1-head attention, resnet), 4 up blocks
+Parity note: AutoencoderKL itself (diffusers 0.18.0) is absent from the sandbox, so the torch module below is a
+restatement from the published architecture — "parity unpinned" at that boundary; what the tests pin is
+HipVAEDecoder against that fp32 restatement at the full SD size, through the AutoencoderKL key map.
+
+Architecture (SD config: block_out_channels (128,256,512,512), layers_per_block 2, 32 groups, eps 1e-6):
+post_quant_conv 4->4 (1x1), conv_in 4->512, mid (resnet, 1-head attention, resnet), 4 up blocks
 (512,512,256,128) x 3 resnets with 3 nearest-2x upsamplers, GroupNorm+SiLU, conv_out 128->3.
 """
+import re
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -73,6 +82,41 @@ class VAEDecoder(nn.Module):
                 h = up(F.interpolate(h, scale_factor=2.0, mode="nearest"))
         return self.conv_out(F.silu(self.norm_out(h)))
 
+    def aekl_state_dict(self, legacy_attention_names=False):
+        """The parameters under AutoencoderKL's names (diffusers: `post_quant_conv.*`, `decoder.conv_in.*`,
+        `decoder.mid_block.resnets.N.*`, `decoder.mid_block.attentions.0.{group_norm,to_q,to_k,to_v,to_out.0}.*`,
+        `decoder.up_blocks.I.resnets.J.{norm1,conv1,norm2,conv2,conv_shortcut}.*`, `decoder.up_blocks.I.upsamplers.0.conv.*`,
+        `decoder.conv_norm_out.*`, `decoder.conv_out.*`).  legacy_attention_names: the pre-0.15 AttentionBlock names
+        (`query / key / value / proj_attn`) that SD checkpoints on the hub still carry."""
+        out = {}
+
+        def put(dst, m):
+            out[f"{dst}.weight"] = m.weight.detach().clone()
+            out[f"{dst}.bias"] = m.bias.detach().clone()
+
+        def res(dst, r):
+            put(f"{dst}.norm1", r.norm1); put(f"{dst}.conv1", r.conv1)
+            put(f"{dst}.norm2", r.norm2); put(f"{dst}.conv2", r.conv2)
+            if r.short is not None:
+                put(f"{dst}.conv_shortcut", r.short)
+        put("post_quant_conv", self.post_quant_conv)
+        put("decoder.conv_in", self.conv_in)
+        res("decoder.mid_block.resnets.0", self.mid[0])
+        res("decoder.mid_block.resnets.1", self.mid[2])
+        a = "decoder.mid_block.attentions.0"
+        names = dict(norm="group_norm", q="query", k="key", v="value", o="proj_attn") if legacy_attention_names else \
+            dict(norm="group_norm", q="to_q", k="to_k", v="to_v", o="to_out.0")
+        for k, n in names.items():
+            put(f"{a}.{n}", getattr(self.mid[1], k))
+        for i, (blk, up) in enumerate(self.ups):
+            for j, r in enumerate(blk):
+                res(f"decoder.up_blocks.{i}.resnets.{j}", r)
+            if up is not None:
+                put(f"decoder.up_blocks.{i}.upsamplers.0.conv", up)
+        put("decoder.conv_norm_out", self.norm_out)
+        put("decoder.conv_out", self.conv_out)
+        return out
+
 
 def make_vae(device, dtype=torch.float16, seed=0):
     g = torch.random.get_rng_state()
@@ -83,74 +127,147 @@ def make_vae(device, dtype=torch.float16, seed=0):
 
 
 class HipVAEDecoder:
-    """VAEDecoder.decode on the lgd_hip kernels (channels-last fp16, fp32 accumulate)."""
+    """AutoencoderKL.decode (the `.sample` tensor) on the lgd_hip kernels: channels-last fp16, fp32 accumulate.
 
-    def __init__(self, vae: VAEDecoder, device):
+    HipVAEDecoder(state_dict | VAEDecoder, device).  The state dict is AutoencoderKL's (encoder keys are ignored);
+    the decoder's shape (channels per up block, resnets per block, which blocks upsample) is read off the keys."""
+
+    def __init__(self, source, device, groups: int = 32, eps: float = 1e-6):
         from . import ops
         from .weightstore import pack_conv
         self.ops = ops
         self.dev = torch.device(device)
-        h16 = lambda t: t.detach().to(self.dev, torch.float16).contiguous()
-        f32 = lambda t: t.detach().to(self.dev, torch.float32).contiguous()
-        conv = lambda m: (h16(pack_conv(m.weight.detach().float())), f32(m.bias))
-        lin = lambda m: (h16(m.weight.detach().float().reshape(m.weight.shape[0], -1)), f32(m.bias))
-        norm = lambda m: (f32(m.weight), f32(m.bias))
-        res = lambda r: dict(n1=norm(r.norm1), c1=conv(r.conv1), n2=norm(r.norm2), c2=conv(r.conv2),
-                             sc=lin(r.short) if r.short is not None else None)
-        self.pq_w = f32(vae.post_quant_conv.weight.reshape(vae.post_quant_conv.weight.shape[0], -1))
-        self.pq_b = f32(vae.post_quant_conv.bias)
-        self.conv_in = conv(vae.conv_in)
-        a = vae.mid[1]
-        self.mid = [res(vae.mid[0]), dict(n=norm(a.norm), q=lin(a.q), k=lin(a.k), v=lin(a.v), o=lin(a.o)),
-                    res(vae.mid[2])]
-        self.ups = [([res(r) for r in blk], conv(up) if up is not None else None) for blk, up in vae.ups]
-        self.norm_out = norm(vae.norm_out)
-        w = pack_conv(vae.conv_out.weight.detach().float())              # [3, 9*C]
-        self.conv_out = (h16(torch.cat([w, torch.zeros(1, w.shape[1])])),    # pad to 4 output channels
-                         f32(torch.cat([vae.conv_out.bias.detach().float().cpu(), torch.zeros(1)])))
+        self.groups, self.eps = groups, eps
+        sd = source.aekl_state_dict() if isinstance(source, VAEDecoder) else dict(source)
+        sd = {k: v.detach().float().cpu() for k, v in sd.items() if k.startswith(("decoder.", "post_quant_conv."))}
+        if "decoder.conv_in.weight" not in sd:
+            raise RuntimeError("not an AutoencoderKL state dict: decoder.conv_in.weight is missing")
+        h16 = lambda t: t.to(self.dev, torch.float16).contiguous()
+        f32 = lambda t: t.to(self.dev, torch.float32).contiguous()
+        conv = lambda n: (h16(pack_conv(sd[f"{n}.weight"])), f32(sd[f"{n}.bias"]))
+        lin = lambda n: (h16(sd[f"{n}.weight"].reshape(sd[f"{n}.weight"].shape[0], -1)), f32(sd[f"{n}.bias"]))
+        norm = lambda n: (f32(sd[f"{n}.weight"]), f32(sd[f"{n}.bias"]))
+
+        def res(n):
+            return dict(n1=norm(f"{n}.norm1"), c1=conv(f"{n}.conv1"), n2=norm(f"{n}.norm2"), c2=conv(f"{n}.conv2"),
+                        sc=lin(f"{n}.conv_shortcut") if f"{n}.conv_shortcut.weight" in sd else None)
+
+        # post_quant_conv (1x1, 4 -> 4) folded into conv_in: conv_in(W1 z + b1) = conv_in'(z) + border-aware bias map
+        # (the zero padding of conv_in does not carry b1, so the folded bias depends on which taps lie inside the image)
+        w_in, b_in = sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"]
+        if "post_quant_conv.weight" in sd:
+            w1 = sd["post_quant_conv.weight"].reshape(sd["post_quant_conv.weight"].shape[0], -1)
+            b1 = sd["post_quant_conv.bias"]
+            self._tap_bias = torch.einsum("ockl,c->okl", w_in, b1)                   # [Cout,3,3]
+            w_in = torch.einsum("ockl,cd->odkl", w_in, w1)
+        else:
+            self._tap_bias = torch.zeros(w_in.shape[0], 3, 3)
+        self._b_in = b_in
+        ci = w_in.shape[1]
+        if ci > 4:
+            raise RuntimeError(f"latent_channels = {ci}: the 8-channel conv_in operand holds value + remainder of <= 4 channels")
+        # 8-channel operand of lgd_nchw_to_nhwc8_f16: channels 0..ci-1 = fp16 value, ci..2ci-1 = its rounding remainder
+        self.conv_in_w8 = h16(pack_conv(torch.cat([w_in, w_in, w_in.new_zeros(w_in.shape[0], 8 - 2 * ci, 3, 3)], dim=1)))
+        self.c_mid = w_in.shape[0]
+        self._bias_maps = {}
+
+        a = "decoder.mid_block.attentions.0"
+        legacy = f"{a}.query.weight" in sd
+        nq, nk, nv, no = ("query", "key", "value", "proj_attn") if legacy else ("to_q", "to_k", "to_v", "to_out.0")
+        # the softmax scale C^-1/2 is split over the q and k projections, so the fp16 score matrix holds scaled logits
+        # (raw 512-term dot products of a real VAE can leave the fp16 range)
+        s4 = float(self.c_mid) ** -0.25
+        wq, wk = sd[f"{a}.{nq}.weight"].reshape(self.c_mid, -1) * s4, sd[f"{a}.{nk}.weight"].reshape(self.c_mid, -1) * s4
+        self.attn = dict(n=norm(f"{a}.group_norm"),
+                         qk=(h16(torch.cat([wq, wk])), f32(torch.cat([sd[f"{a}.{nq}.bias"], sd[f"{a}.{nk}.bias"]]) * s4)),
+                         v=h16(sd[f"{a}.{nv}.weight"].reshape(self.c_mid, -1)), vb=f32(sd[f"{a}.{nv}.bias"]),
+                         o=(h16(sd[f"{a}.{no}.weight"].reshape(self.c_mid, -1)), f32(sd[f"{a}.{no}.bias"])))
+        self.mid = [res("decoder.mid_block.resnets.0"), res("decoder.mid_block.resnets.1")]
+        n_up = 1 + max(int(m.group(1)) for k in sd for m in [re.match(r"decoder\.up_blocks\.(\d+)\.", k)] if m)
+        self.ups = []
+        for i in range(n_up):
+            n_res = 1 + max(int(m.group(1)) for k in sd
+                            for m in [re.match(rf"decoder\.up_blocks\.{i}\.resnets\.(\d+)\.", k)] if m)
+            up = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+            self.ups.append(([res(f"decoder.up_blocks.{i}.resnets.{j}") for j in range(n_res)],
+                             conv(up) if f"{up}.weight" in sd else None))
+        self.norm_out = norm("decoder.conv_norm_out")
+        w = pack_conv(sd["decoder.conv_out.weight"])                                 # [3, 9*C]
+        self.conv_out = (h16(torch.cat([w, torch.zeros(1, w.shape[1])])),              # pad to 4 output channels
+                         f32(torch.cat([sd["decoder.conv_out.bias"], torch.zeros(1)])))
+
+    @classmethod
+    def from_state_dict(cls, state_dict, device, **kw):
+        """`AutoencoderKL.state_dict()` (models/models.py:41) -> decoder on the HIP kernels."""
+        return cls(state_dict, device, **kw)
+
+    def _bias_map(self, B, L):
+        """conv_in bias + what post_quant_conv's bias contributes through the taps that lie inside the image:
+        fp16 [B*L*L, C] (residual operand of the conv_in GEMM)."""
+        key = (B, L)
+        if key not in self._bias_maps:
+            v = torch.ones(3, L)
+            v[0, 0] = 0          # tap row ky = 0 reads y - 1: outside at y = 0
+            v[2, L - 1] = 0
+            m = torch.einsum("okl,ky,lx->yxo", self._tap_bias, v, v) + self._b_in            # [L, L, C]
+            self._bias_maps = {key: m.reshape(1, L * L, -1).expand(B, -1, -1).reshape(B * L * L, -1)
+                               .to(self.dev, torch.float16).contiguous()}
+        return self._bias_maps[key]
 
     def _res(self, p, x, B, H):
         ops = self.ops
         HW = H * H
-        h = ops.groupnorm(x, B, HW, 32, 1e-6, p["n1"][0], p["n1"][1], True)
+        h = ops.groupnorm(x, B, HW, self.groups, self.eps, p["n1"][0], p["n1"][1], True)
         h = ops.conv3x3(h, p["c1"][0], B, H, H, bias=p["c1"][1])
-        h = ops.groupnorm(h, B, HW, 32, 1e-6, p["n2"][0], p["n2"][1], True)
+        h = ops.groupnorm(h, B, HW, self.groups, self.eps, p["n2"][0], p["n2"][1], True)
         sc = x if p["sc"] is None else ops.linear(x, p["sc"][0], p["sc"][1])
         return ops.conv3x3(h, p["c2"][0], B, H, H, bias=p["c2"][1], res=sc)
 
     def _attn(self, p, x, B, H):
+        """Single-head attention over the H*H positions at width C (512): the head is wider than the flash kernels'
+        160, so the batch runs as three BATCHED GEMM launches + one row softmax:
+            scores[b] = q[b] k[b]^T      ->  P = softmax(scores)      (q, k carry C^-1/4 each)
+            vt[b]     = Wv n[b]^T        (V^T directly from the projection: no transpose pass)
+            out[b]    = P[b] vt[b]^T + bv   (rows of P sum to 1, so V's bias is added once, behind the product)"""
         ops = self.ops
         S = H * H
         C = x.shape[1]
-        n = ops.groupnorm(x, B, S, 32, 1e-6, p["n"][0], p["n"][1], False)
-        q, k, v = (ops.linear(n, p[t][0], p[t][1]) for t in "qkv")
-        outs = []
-        for b in range(B):
-            sl = slice(b * S, (b + 1) * S)
-            sc = ops.linear(q[sl], k[sl])                                 # [S, S] = q k^T
-            pr = ops.softmax_rows(sc, C ** -0.5)
-            outs.append(ops.linear(pr, v[sl].t().contiguous()))           # [S, C]
-        a = outs[0] if B == 1 else torch.cat(outs)
+        F16 = torch.float16
+        n = ops.groupnorm(x, B, S, self.groups, self.eps, p["n"][0], p["n"][1], False)
+        qk = ops.linear(n, p["qk"][0], p["qk"][1])                                  # [B*S, 2C]
+        sc = torch.empty((B * S, S), device=self.dev, dtype=F16)
+        ops.gemm_launch(ops.gemm_desc(qk, qk[:, C:], sc, S, S, C, lda0=2 * C, ldw=2 * C, ldc=S, nb_o=B,
+                                      a_bs=(S * 2 * C, 0), w_bs=(S * 2 * C, 0), c_bs=(S * S, 0)))
+        pr = ops.softmax_rows(sc, 1.0, out=sc)
+        vt = torch.empty((B * C, S), device=self.dev, dtype=F16)
+        ops.gemm_launch(ops.gemm_desc(p["v"], n, vt, C, S, C, lda0=C, ldw=C, ldc=S, nb_o=B,
+                                      a_bs=(0, 0), w_bs=(S * C, 0), c_bs=(C * S, 0)))
+        a = torch.empty((B * S, C), device=self.dev, dtype=F16)
+        ops.gemm_launch(ops.gemm_desc(pr, vt, a, S, C, S, lda0=S, ldw=S, ldc=C, bias=p["vb"], nb_o=B,
+                                      a_bs=(S * S, 0), w_bs=(C * S, 0), c_bs=(S * C, 0)))
         return ops.linear(a, p["o"][0], p["o"][1], res=x)
 
     @torch.no_grad()
     def decode(self, z):
         ops = self.ops
-        z = z.to(self.dev, torch.float32)
+        z = z.to(self.dev, torch.float32).contiguous()
         B, _, L, _ = z.shape
-        z = torch.einsum("oc,bchw->bohw", self.pq_w, z) + self.pq_b.view(1, -1, 1, 1)
-        h = ops.conv_in(z.contiguous(), self.conv_in[0], self.conv_in[1])
+        lat8 = ops.nchw_to_nhwc8(z)
+        h = torch.empty((B * L * L, self.c_mid), device=self.dev, dtype=torch.float16)
+        ops.gemm_launch(ops.gemm_desc(lat8, self.conv_in_w8, h, B * L * L, self.c_mid, 72, c0=8, lda0=8, taps=9, hin=L,
+                                      win=L, hout=L, wout=L, res=self._bias_map(B, L), ldr=self.c_mid, ldc=self.c_mid,
+                                      splits=1))
         H = L
         h = self._res(self.mid[0], h, B, H)
-        h = self._attn(self.mid[1], h, B, H)
-        h = self._res(self.mid[2], h, B, H)
+        h = self._attn(self.attn, h, B, H)
+        h = self._res(self.mid[1], h, B, H)
         for blk, up in self.ups:
             for r in blk:
                 h = self._res(r, h, B, H)
             if up is not None:
                 h = ops.conv3x3(h, up[0], B, H, H, bias=up[1], ups=1)
                 H *= 2
-        h = ops.groupnorm(h, B, H * H, 32, 1e-6, self.norm_out[0], self.norm_out[1], True)
+        h = ops.groupnorm(h, B, H * H, self.groups, self.eps, self.norm_out[0], self.norm_out[1], True)
         y = ops.conv_out(h, self.conv_out[0], self.conv_out[1], B, H)
         return y[:, :3]
 

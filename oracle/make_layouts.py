@@ -3,7 +3,7 @@
 parser (utils/parse.py: parse_input_with_negative + filter_boxes(scale_boxes=False), the
 `--no-scale-boxes-default` path of generate.py:282-299) and writes them as a small data fixture:
 
-    tests/golden/layouts_lmd_v0.1_gpt-4.json   [{prompt, gen_boxes:[[name,[x,y,w,h]]..], bg_prompt, neg_prompt}]
+    llm-groundeddiffusion_amd/data/layouts_lmd_v0.1_gpt-4.json   [{prompt, gen_boxes:[[name,[x,y,w,h]]..], bg_prompt, neg_prompt}]
 
 Build container only (needs /root/reference).  The GPU box reads the fixture, never the reference.
 """
@@ -20,8 +20,10 @@ import ref_harness as rh  # noqa: E402
 def main():
     rh.setup()
     from utils import parse
-    out_dir = os.path.join(ROOT, "tests", "golden")
     for name in ("lmd_v0.1_gpt-4", "demo_v0.1_gpt-4"):
+        # the lmd_v0.1 layouts are the benchmark's workload (product data); the demo layouts are test inputs
+        out_dir = os.path.join(ROOT, "llm-groundeddiffusion_amd", "data") if name.startswith("lmd_") else \
+            os.path.join(ROOT, "tests", "golden")
         cache = json.load(open(os.path.join(rh.REF_ROOT, "cache", f"cache_{name}.json")))
         rows = []
         for prompt, responses in cache.items():

@@ -346,8 +346,12 @@ def test_fullsize_guided_gligen_loop_vs_oracle(dev):
 
 def test_fullsize_sd21_guidance_iteration_vs_oracle(dev):
     """BASELINE config 3 closed at full width: one latent_backward_guidance iteration (pipelines.py:16-82 as
-    generation/backward_guidance.py:99-120 calls it) on the SD2.1-768 topology at 96x96 latents — loss (HW = 144 / 576
-    energy maps) and the latent gradient through the dgrad plan of the 96^2 network vs the oracle."""
+    generation/backward_guidance.py:99-120 calls it, loss_scale 30) on the SD2.1-768 topology at 96x96 latents.
+    The loss (HW = 144 / 576 energy maps) must match; the latent gradient is checked in two parts, because the
+    energy's top-k selection (utils/guidance.py:91-176) is discontinuous: (a) the map gradients — same number of
+    selected positions, and all but a handful identical (fp16 maps vs fp32 maps flip near-ties); (b) the network
+    backward — the ORACLE's map gradients fed through the HIP dgrad plan of the 96^2 network must reproduce the
+    oracle's latent gradient to fp16 accuracy.  End to end the few flipped selections cost a few percent."""
     import restate as R
     cfg = weights.CONFIGS["sd21"]
     sd = weights.synth_state_dict(cfg, 0)
@@ -359,23 +363,34 @@ def test_fullsize_sd21_guidance_iteration_vs_oracle(dev):
     L = cfg.sample_size
     x = torch.randn((1, 4, L, L), generator=torch.Generator().manual_seed(0))
     _, cond = weights.synth_embeddings(cfg, 1, seed=1)
-    sm = LMDSampler(eng, DDIMScheduler(prediction_type=cfg.prediction_type))
-    guid = dict(bboxes=BOXES, object_positions=OBJ_POS, loss_scale=30, loss_threshold=0.0, max_iter=1,
-                max_index_step=25, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
-    tr, tr_ref = [], []
-    sm.guidance_only(x, cond, 50, 1, guid, trace=tr)
+    kw = dict(fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
     rs = R.DDIM(prediction_type=cfg.prediction_type)
     rs.set_timesteps(50)
-    R.latent_backward_guidance(sd, cd, rs, cond, 1, BOXES, OBJ_POS, rs.timesteps[1], x.clone(), torch.tensor(1e4),
-                               loss_scale=30, loss_threshold=0.0, max_iter=1, max_index_step=25,
-                               guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0,
-                               trace=tr_ref)
-    a, b = tr[0]["grad"].cpu().double().reshape(-1), tr_ref[0]["grad"].double().reshape(-1)
-    cos = float(a @ b / (a.norm() * b.norm()))
-    l_hip, l_ref = tr[0]["loss"], tr_ref[0]["loss"]
-    print(f"[sd21 full] guidance loss hip {l_hip:.4f} oracle {l_ref:.4f}; latent-gradient cosine {cos:.5f} "
-          f"rel-L2 {rel_l2(a, b):.3e}")
-    assert abs(l_hip - l_ref) / abs(l_ref) < 5e-3 and cos > 0.999
+    lat = x.clone().requires_grad_(True)
+    saved = {}
+    R.unet_forward(sd, cd, lat, rs.timesteps[1], cond, saved=saved, save_keys=KEYS, stop_after=KEYS[-1])
+    loss = R.compute_ca_lossv3(saved, BOXES, OBJ_POS, KEYS, index=1, **kw) * 30
+    grads = torch.autograd.grad(loss, [saved[k] for k in KEYS] + [lat])
+    g_maps_ref, g_lat_ref = grads[:-1], grads[-1].double().reshape(-1)
+    sm = LMDSampler(eng, DDIMScheduler(prediction_type=cfg.prediction_type), use_graphs=False)
+    guid = dict(bboxes=BOXES, object_positions=OBJ_POS, loss_scale=30, loss_threshold=0.0, max_iter=1,
+                max_index_step=25, guidance_attn_keys=KEYS, **kw)
+    tr = []
+    sm.guidance_only(x, cond, 50, 1, guid, trace=tr)
+    cos = lambda a, b: float(a @ b / (a.norm() * b.norm()))
+    gate("[sd21 full] guidance loss rel. error", abs(tr[0]["loss"] - float(loss)) / float(loss), 7e-5)
+    pg = eng.plan(1, L, grad=True, fuser=False, stop_key=eng.last_key(KEYS), save_keys=KEYS, text_batch_offset=1)
+    for k, gm in zip(KEYS, g_maps_ref):
+        gh = pg.gmaps[k].float().cpu() / sm.grad_scale
+        assert int((gh != 0).sum()) == int((gm != 0).sum()), k           # the same number of selected positions
+        gate(f"[sd21 full] map-gradient support mismatch {k}", float(((gh != 0) != (gm != 0)).float().mean()) + 1e-9, 5e-4)
+    a = tr[0]["grad"].cpu().double().reshape(-1)
+    gate("[sd21 full] latent-gradient cosine end to end (incl. flipped top-k selections)", cos(a, g_lat_ref), 0.99, at_least=True)
+    for k, gm in zip(KEYS, g_maps_ref):
+        pg.gmaps[k].copy_((gm * sm.grad_scale).to(dev))
+    g2 = pg.backward(sm.grad_scale).cpu().double().reshape(-1)
+    gate("[sd21 full] oracle map-gradients through the HIP backward: cosine", cos(g2, g_lat_ref), 0.99985, at_least=True)
+    gate("[sd21 full] oracle map-gradients through the HIP backward: rel-L2", rel_l2(g2, g_lat_ref), 3e-2)
     del eng
     torch.cuda.empty_cache()
 

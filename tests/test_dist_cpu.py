@@ -88,7 +88,7 @@ def test_bench_self_spawns_ranks_and_balances_the_prompt_set():
     assert r["n_gpus"] == r["rccl_ranks"] == 2 and r["images"] == 40
     assert r["weight_broadcast_s"] > 0 and r["weights_identical"]
     a, b = r["per_rank_cost"]
-    assert abs(a - b) <= 1.0                                  # cost = layouts + boxes, LPT-balanced
+    assert abs(a - b) / max(a, b) <= 0.05                     # cost = algorithmic TFLOP per layout, LPT-balanced
 
 
 def test_cost_partition_is_complete_balanced_and_deterministic():
@@ -102,12 +102,17 @@ def test_cost_partition_is_complete_balanced_and_deterministic():
     assert len(sel) == len(set(sel)) == 100
     n_boxes = [len(cache[i]["gen_boxes"]) for i in sel]
     assert min(n_boxes) == 0 and max(n_boxes) == 5             # all four prompt categories are present
-    costs = [n + 1 for n in n_boxes]
+    # cost model = algorithmic TFLOP of a layout: (N + 1) generations + the overall stage's guidance iterations, which
+    # only layouts WITH boxes have (an empty layout is one unguided generation)
+    costs = [bench.layout_cost(n) for n in n_boxes]
+    assert abs(costs[n_boxes.index(0)] - (20 * bench.TF_MAIN_ON + 30 * bench.TF_MAIN_OFF)) < 1e-6
+    assert abs(bench.layout_cost(2) - 359.8) < 0.2
     for world in (1, 2, 4, 8):
         parts = bench.partition_by_cost(costs, world)
         assert sorted(i for p in parts for i in p) == list(range(100))
         loads = [sum(costs[i] for i in p) for p in parts]
         assert max(loads) - min(loads) <= max(costs)
+        assert max(loads) / (sum(loads) / world) <= 1.05, (world, loads)     # >= 95 % of linear by load alone
         assert parts == bench.partition_by_cost(costs, world)
     # per-image work of the default 2-box LMD+ image with all 65 iterations: SURVEY.md 8(d) "<= 359.8 TF"
     assert abs(bench.algorithmic_tflop(2, 50, 0.4, 55, 10) - 359.8) < 0.2

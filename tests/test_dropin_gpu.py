@@ -345,19 +345,17 @@ def test_lmd_plus_overall_stage_teacher_forced(dropin, dev):
             kw = dict(num_inference_steps=8, frozen_step_ratio=0.5, overall_max_index_step=3, overall_max_iter=[2, 1, 1],
                       overall_loss_threshold=0.0, height=256, width=256, decode=False, **extra)
             starts = gold[f"{tag}_ov_starts"]
-            worst_g, worst_u = 0.0, 0.0
+            iters = [2, 1, 1] + [0] * 5
+            # limits = 3x the measured errors: step 0 runs two guidance iterations (chaotic: the fp32 oracle itself
+            # amplifies a 1e-3 input perturbation of such a step 21x, tests/test_oracle.py); steps 1-3 still blend in the
+            # composed latents (3e-3 off the golden's); steps 4-7 are plain CFG + DDIM
+            limits = [1.3e-1, 9.5e-3, 9e-3, 9e-3, 2.6e-4, 2.4e-4, 2.3e-4, 7.5e-6]
             for i in range(8):
                 out = lmd_plus_generate(sm, lay, overall_first_step=i, overall_n_steps=1, overall_start=[starts[i]], **kw)
                 want = starts[i + 1] if i < 7 else gold[f"{tag}_final_latents"]
-                e = relerr(out["latents"], want)
-                print(f"[run {tag}] overall step {i} teacher-forced: relerr {e:.3e} (guidance iterations {out['guidance_iters']})")
-                assert out["guidance_iters"] == ([2, 1, 1] + [0] * 5)[i]
-                if i < 3:
-                    worst_g = max(worst_g, e)
-                else:
-                    worst_u = max(worst_u, e)
-            gate(f"[run {tag}] worst guided overall step", worst_g, 3e-2)
-            gate(f"[run {tag}] worst unguided overall step", worst_u, 1e-2)
+                assert out["guidance_iters"] == iters[i]
+                gate(f"[run {tag}] overall step {i} teacher-forced ({iters[i]} guidance iterations)",
+                     relerr(out["latents"], want), limits[i])
     finally:
         models.model_dict = keep
 

@@ -149,6 +149,40 @@ def test_sampler_loop_gligen():
     assert maxrel(saved[1][("up", 1, 1, 0)], g["gligen_saved_up11_step1"]) < TOL
 
 
+def test_guided_step_amplifies_input_perturbations():
+    """Why the two-iteration guided step 0 of the GLIGEN loops gets a looser teacher-forced gate than the other steps
+    (tests/test_engine_gpu.py::test_teacher_forced_guided_steps_vs_reference_golden): in the fp32 ORACLE ITSELF, a
+    1e-3 perturbation of the start latents of that step — the size of the HIP path's fp16 error on a noise prediction
+    — comes out of the step amplified by an order of magnitude, because the second guidance iteration's top-k selection
+    (utils/guidance.py:91-176) is taken on maps of the perturbed latents.  Unguided steps pass perturbations through
+    at gain ~1."""
+    cfg = weights.CONFIGS["tiny_gligen"]
+    cd, sd = cfg_dict(cfg), weights.synth_state_dict(cfg, 0)
+    g = np.load(os.path.join(GOLD, "loops_tiny_gligen.npz"))
+    ehs = torch.from_numpy(g["ehs"])
+    inp = (ehs, ehs[:1], ehs[1:])
+    sg = dict(loss_scale=5, loss_threshold=0.0, max_iter=[2, 1], max_index_step=3, guidance_attn_keys=KEYS,
+              fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+
+    def run(lat_all_in):
+        per_step = []
+        R.generate_gligen(sd, cd, R.DDIM(), lat_all_in, inp, 4, BBOXES, torch.from_numpy(g["phrase_emb"]),
+                          gligen_scheduled_sampling_beta=0.5, frozen_steps=2, frozen_mask=torch.from_numpy(g["frozen_mask"]),
+                          semantic_guidance=True, semantic_guidance_bboxes=BBOXES,
+                          semantic_guidance_object_positions=OBJ_POS, semantic_guidance_kwargs=sg, per_step=per_step)
+        return per_step
+    x = torch.from_numpy(g["lat_all_in"]).clone()
+    base = run(x)
+    assert maxrel(base[0], g["gligen_latents_all"][1]) < TOL
+    xp = x.clone()
+    delta = 1e-3
+    xp[0] += delta * x[0].abs().max() * torch.randn(x[0].shape, generator=torch.Generator().manual_seed(0))
+    pert = run(xp)
+    gain0 = maxrel(pert[0], base[0]) / delta
+    print(f"oracle, guided step 0 (2 iterations, fuser on): input perturbation {delta:.0e} -> output {maxrel(pert[0], base[0]):.2e} (gain {gain0:.1f})")
+    assert gain0 > 5.0
+
+
 def test_fast_schedule_loop_gligen():
     """generate_gligen with the optional fast tail (dynamic_num_inference_steps + fast_after_steps=4) vs the
     reference's own run (oracle/make_golden_fast.py)."""

@@ -138,6 +138,86 @@ __global__ void k_xlane(float* out, long* cyc, int iters) {
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// Can one SIMD run MFMA of one wave beside VALU (exp + fma) of another?  512-thread workgroups = 2 waves per SIMD.
+//   MODE 0: all 8 waves MFMA only     MODE 1: all 8 waves VALU only
+//   MODE 2: waves 0-3 MFMA, waves 4-7 VALU (ping-pong roles)     MODE 3: every wave both, interleaved by the compiler
+//   MODE 4: as 2 with s_setprio 1 on the MFMA waves
+// One iteration = 28 MFMA 16x16x32 (one attention key tile of a 32-query wave at d = 40) and / or 32 v_exp + 96 v_fma.
+template <int MODE, int SHAPE = 0>
+__global__ __launch_bounds__(512) void k_pp(float* out, long* cyc, int iters) {
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  half8_t a8, b8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a8[i] = (_Float16)(0.01f * (threadIdx.x % 7 + i)); b8[i] = (_Float16)(0.02f * (threadIdx.x % 5 + i)); }
+  f32x4 c[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) c[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x16 cc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cc[i][j] = 0.f;
+  float x[32], y[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) { x[i] = -0.001f * (threadIdx.x + i + 1); y[i] = 0.001f * (i + 1); }
+  const bool do_m = MODE == 0 || MODE == 3 || ((MODE == 2 || MODE == 4) && wid < 4);
+  const bool do_v = MODE == 1 || MODE == 3 || ((MODE == 2 || MODE == 4) && wid >= 4);
+  if (MODE == 4 && wid < 4) __builtin_amdgcn_s_setprio(1);
+  long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    if (do_m) {
+      if (SHAPE == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int i = 0; i < 7; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, c[i], 0, 0, 0);
+      } else {       // the same flops as 14 x 32x32x16
+#pragma unroll
+        for (int r = 0; r < 7; ++r)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) cc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, b8, cc[i], 0, 0, 0);
+      }
+    }
+    if (do_v) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        x[i] = __builtin_amdgcn_exp2f(x[i]);
+        y[i] = fmaf(y[i], 1.0001f, -0.5f);
+        y[i] = fmaf(y[i], 0.9999f, 0.5f);
+        y[i] = fmaf(y[i], 1.0001f, -0.25f);
+      }
+    }
+  }
+  long t1 = __builtin_readcyclecounter();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) s += c[i][0];
+  s += cc[0][0] + cc[1][3];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) s += x[i] + y[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <typename F>
+static void run_pp(const char* name, F launch) {
+  const int iters = 4000, blocks = 256, threads = 512;
+  float* out; long* cyc;
+  hipMalloc(&out, sizeof(float) * blocks * threads);
+  hipMalloc(&cyc, sizeof(long) * blocks);
+  launch(blocks, threads, out, cyc, 10);
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0);
+  launch(blocks, threads, out, cyc, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("%-58s %8.1f ns per loop iteration (8 waves/CU)\n", name, ms * 1e6 / iters);
+  hipFree(out); hipFree(cyc);
+}
+
 template <typename F>
 static void run(const char* name, F launch, int inst_per_iter, int waves_per_simd, double flops_per_inst) {
   const int iters = 2000;
@@ -171,6 +251,15 @@ static void run(const char* name, F launch, int inst_per_iter, int waves_per_sim
 #define L(K) [](int b, int t, float* o, long* c, int it) { hipLaunchKernelGGL(K, dim3(b), dim3(t), 0, 0, o, c, it); }
 
 int main() {
+  run_pp("ping-pong: all 8 waves 28 MFMA", L(k_pp<0>));
+  run_pp("ping-pong: all 8 waves 32 exp + 96 fma", L(k_pp<1>));
+  run_pp("ping-pong: waves 0-3 MFMA | waves 4-7 VALU", L(k_pp<2>));
+  run_pp("ping-pong: every wave MFMA + VALU (compiler interleave)", L(k_pp<3>));
+  run_pp("ping-pong: waves 0-3 MFMA (prio 1) | waves 4-7 VALU", L(k_pp<4>));
+  run_pp("32x32x16: all 8 waves 14 MFMA", L((k_pp<0, 1>)));
+  run_pp("32x32x16: waves 0-3 MFMA | waves 4-7 VALU", L((k_pp<2, 1>)));
+  run_pp("32x32x16: every wave MFMA + VALU (compiler interleave)", L((k_pp<3, 1>)));
+  run_pp("32x32x16: waves 0-3 MFMA (prio 1) | waves 4-7 VALU", L((k_pp<4, 1>)));
   for (int w : {1, 2, 4}) {
     run("v_exp_f32", L(k_valu<0>), N_INST, w, 0);
     run("v_fma_f32", L(k_valu<1>), N_INST, w, 0);
