@@ -25,8 +25,13 @@
 extern "C" {
 #endif
 
-#define LGD_ABI_VERSION 4
+#define LGD_ABI_VERSION 5
 int lgd_abi_version(void);
+/* Kernel-variant switches of the library (A/B timing and tests; the defaults are what the benchmark runs).  No
+ * counterpart in the reference.  "attn32": self-attention forward without map capture — 0 = the 16x16x32 kernel,
+ * 1 = (default) the 32x32x16 software-pipelined kernel where it applies (d + 2 <= 96, enough work to fill the chip),
+ * 2 = that kernel for every problem size.  Returns 0, or LGD_ERR_ARG for an unknown name. */
+int lgd_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM / implicit-GEMM convolution on MFMA (v_mfma_f32_16x16x32_f16).

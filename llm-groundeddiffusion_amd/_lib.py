@@ -14,7 +14,7 @@ import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgd_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -47,6 +47,7 @@ EPI_GEGLU, EPI_OUT_F32, EPI_RES_F32 = 1, 2, 4
 _P, _I, _L, _F = c_void_p, c_int, c_i64, c_float
 SIGNATURES = {
     "lgd_abi_version": [],
+    "lgd_set_option": [C.c_char_p, _I],
     "lgd_gemm_f16": [C.POINTER(LgdGemmDesc), _P],
     "lgd_conv_in_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lgd_conv_out_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P],

@@ -19,8 +19,22 @@
 #include "common.h"
 #include "../../include/lgd_hip.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
+
+int g_attn32_nw = -1;     // waves per workgroup of the 32x32x16 kernel: 8 (256 queries per workgroup) or 4
+int attn32_nw() {
+  if (g_attn32_nw < 0) { const char* e = getenv("LGD_ATTN32_NW"); g_attn32_nw = e ? atoi(e) : 8; }
+  return g_attn32_nw;
+}
+int g_attn32_var = 0;      // tools: 0 = fragment prefetch 2 slots ahead, pinned slot order; 1 = 4 ahead; 2 = compiler's order
+int attn32_var() { return g_attn32_var; }
+int g_attn32 = -1;
+int attn32_mode() {
+  if (g_attn32 < 0) { const char* e = getenv("LGD_ATTN32"); g_attn32 = e ? atoi(e) : 1; }
+  return g_attn32;
+}
 
 constexpr int KV_T = 64;         // keys per tile
 constexpr int VT_LD = KV_T + 8;  // halfs per row of the transposed V tile (ds_read_b64: conflict-free)
@@ -575,12 +589,408 @@ __global__ __launch_bounds__(64 * NW) void attn_self_kernel(const AttnArgs a) {
   }
 }
 
+// max over the two lanes (l, l + 32) that share a query in the 32x32 accumulator layout, delivered to both.
+// hipcc (ROCm 7.2) folds permlane32_swap(x, x) into {x, x} — it treats the swap of two EQUAL operands as the identity,
+// which drops the cross-lane exchange (every lane then sees the lower half's value only).  The second operand is
+// therefore made opaque to the optimiser before the swap.
+__device__ __forceinline__ float half_pair_max(float mx) {
+  unsigned u0 = __builtin_bit_cast(unsigned, mx), u1 = u0;
+  asm volatile("" : "+v"(u1));
+  auto sw = __builtin_amdgcn_permlane32_swap(u0, u1, false, false);
+  return fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Self-attention forward, 32x32x16 MFMA edition (round 3) for head dims with a spare slot (d + 2 <= DK).
+//
+// Why a second kernel.  Measured on MI355X (tools/ubench.hip, profiles/r03_ubench.txt): a SIMD does NOT run the VALU
+// instructions of one wave beside the MFMAs of another — a wave doing 28 MFMA 16x16x32 next to a wave doing 32 v_exp +
+// 96 v_fma takes the SUM of the two (511 ns vs 253 + 244), for 32x32x16 as well — and v_exp_f32 costs 3.6 plain VALU
+// slots.  attn_self_kernel above is therefore the sum MFMA (241 ns per 32-query x 64-key wave tile) + softmax VALU
+// (~225 ns) + stalls = 566 ns at d = 40, whatever the occupancy.  The only overlap the hardware offers is INSIDE one
+// wave's instruction stream: independent VALU instructions issued between that wave's own MFMAs (the guide's "<= 5
+// fillers per 32x32x16 gap"; 16x16x32 hides almost nothing: 7 % vs 17-36 % measured).  Hence:
+//   * 32x32x16 MFMAs for both products.  S^T = K Q^T per 32 keys x 32 queries: the contraction is padded to DK = 48
+//     for d = 40 (three k-steps of 16) instead of 64; O^T = V^T P^T in 32-row tiles of dv (two for d = 40 incl. the
+//     row of ones that produces the row sums).  A lane owns ONE query (lane & 31) and 16 of the 32 keys of a block
+//     (rows (r&3) + 8(r>>2) + 4(lane>>5)): the row max is 15 max3 + one permlane32 swap (no LDS bpermute), and the
+//     S^T accumulators convert to the P^T operand in registers — V^T is staged with the key order of each 16-key group
+//     permuted to match (position 8h + 4a + c holds key 8a + 4h + c), so that a V^T fragment is one ds_read_b128.
+//   * software pipelining across key tiles inside the wave: S(t+1) = K(t+1) Q^T is issued in the same basic block as
+//     P(t) = exp2(S(t)) and O += V^T(t) P(t); the two chains are independent, so the exponentials sit between the MFMAs.
+//     The reference-raise decision for tile t+1 (wave-uniform vote, rare) is taken after PV(t) completed, so a rescale
+//     covers everything accumulated at the old reference exactly once (S(t+1) is shifted explicitly).
+//   * K(t+1) and V(t) are staged in the same iteration (V lags K by one tile): one barrier per key tile, two stages each.
+//   * ragged key counts cost nothing in the loop: head-dim slot d+1 of Q holds -30000 and K holds 1 there for padded
+//     keys (0 for real ones), next to slot d = (-m_ref, 1) of the running-reference trick.
+template <int DK, int NDT, int NW, int PF = 2, bool PIN = true, int OCC = 1>
+__global__ __launch_bounds__(64 * NW, OCC) void attn_self32_kernel(const AttnArgs a) {
+  constexpr int NT = 64 * NW;
+  constexpr int NKS = DK / 16;                  // k-steps of the QK^T contraction
+  constexpr int K_LDB = DK * 2 + 16;            // bytes per K row: an odd multiple of 16 -> conflict-free ds_read_b128
+  static_assert(((K_LDB / 16) & 1) == 1, "K row stride must be an odd multiple of 16 bytes");
+  constexpr int VT_LDB = KV_T * 2 + 16;         // bytes per V^T row (64 keys): 144 = 9 x 16
+  constexpr int VROWS = NDT * 32;
+  constexpr int K_STAGE = KV_T * K_LDB;         // bytes
+  constexpr int V_STAGE = VROWS * VT_LDB;
+  constexpr int KSEG = DK / 8;                  // 16-byte segments per K row that may hold data
+  constexpr int K_IT = (KV_T * KSEG + NT - 1) / NT;
+  constexpr int V_ITEMS = (KV_T / 2) * KSEG;    // (key pair, 8-wide dv segment)
+  constexpr int V_IT = (V_ITEMS + NT - 1) / NT;
+  constexpr float MASKV = 30000.f;
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * K_STAGE + 2 * V_STAGE];
+  unsigned char* const Kst = smem;
+  unsigned char* const Vst = smem + 2 * K_STAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int qi = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (32 * NW) + wid * 32;
+  const int d = a.d;
+  const half_t* Qb = a.q + (long)b * a.q_bs + (long)h * d;
+  const half_t* Kb = a.k + (long)b * a.k_bs + (long)h * d;
+  const half_t* Vb = a.v + (long)b * a.v_bs + (long)h * d;
+
+  // ---- one-time LDS fill: zeros; ones at K column d (both stages) and at V^T row d
+  for (int i = tid; i < (int)sizeof(smem) / 16; i += NT) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  for (int i = tid; i < 2 * KV_T; i += NT) {
+    const int st = i / KV_T, row = i - st * KV_T;
+    *reinterpret_cast<half_t*>(Kst + st * K_STAGE + row * K_LDB + d * 2) = (half_t)1.f;
+    *reinterpret_cast<half_t*>(Vst + st * V_STAGE + d * VT_LDB + row * 2) = (half_t)1.f;
+  }
+
+  // ---- Q^T fragments (B operand of S^T): lane -> query qi, head-dim elements 16 s + 8 hh .. + 8, pre-scaled to the
+  // log2 domain; slot d carries -m_ref (K holds 1 there), slot d+1 carries -MASKV (K holds 1 there for padded keys)
+  half8_t qf[NKS];
+  {
+    const int qrow = q0 + qi;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      const int dd = s * 16 + hh * 8;
+      if (qrow < a.Sq && dd < d) {
+        qf[s] = *reinterpret_cast<const half8_t*>(Qb + (long)qrow * a.ldq + dd);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[s][e] = (half_t)((float)qf[s][e] * a.scale_log2);
+      } else {
+        qf[s] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+  }
+  const int s_m = d >> 4, h_m = (d >> 3) & 1;
+#pragma unroll
+  for (int s = 0; s < NKS; ++s)
+    if (s == s_m && hh == h_m) qf[s][1] = (half_t)(-MASKV);
+  auto set_ref = [&](float m) {
+#pragma unroll
+    for (int s = 0; s < NKS; ++s)
+      if (s == s_m && hh == h_m) qf[s][0] = (half_t)(-m);
+  };
+
+  // ---- staging coordinates (hoisted)
+  const half_t* kp[K_IT];
+  int k_row[K_IT], k_dst[K_IT];
+  bool k_use[K_IT];
+#pragma unroll
+  for (int i = 0; i < K_IT; ++i) {
+    const int idx = tid + i * NT;
+    const int row = idx / KSEG, seg = idx - row * KSEG;
+    k_use[i] = (idx < KV_T * KSEG) && (seg * 8 < d);
+    k_row[i] = row;
+    k_dst[i] = row * K_LDB + seg * 16;
+    kp[i] = Kb + (long)row * a.ldk + seg * 8;
+  }
+  const half_t* vp[V_IT];
+  int v_row[V_IT], v_dst[V_IT];
+  bool v_use[V_IT];
+#pragma unroll
+  for (int i = 0; i < V_IT; ++i) {
+    const int idx = tid + i * NT;
+    const int pair = idx & 31, seg = idx >> 5;
+    const int key = pair * 2;
+    // position of `key` inside its 16-key group: 8 h' + 4 a + c for key = 8 a + 4 h' + c
+    const int pos = (key & ~15) | (((key >> 2) & 1) << 3) | (((key >> 3) & 1) << 2) | (key & 3);
+    v_use[i] = (idx < V_ITEMS) && (seg * 8 < d);
+    v_row[i] = key;
+    v_dst[i] = (seg * 8) * VT_LDB + pos * 2;
+    vp[i] = Vb + (long)key * a.ldv + seg * 8;
+  }
+  uint4 k_reg[K_IT], v_reg[V_IT][2];
+  auto load_k = [&](int kv0) {
+    const bool full = kv0 + KV_T <= a.Sk;
+#pragma unroll
+    for (int i = 0; i < K_IT; ++i) {
+      const bool ok = k_use[i] && (full || kv0 + k_row[i] < a.Sk);
+      k_reg[i] = ok ? *reinterpret_cast<const uint4*>(kp[i]) : make_uint4(0, 0, 0, 0);
+      kp[i] += (long)KV_T * a.ldk;
+    }
+  };
+  auto load_v = [&](int kv0) {
+    const bool full = kv0 + KV_T <= a.Sk;
+#pragma unroll
+    for (int i = 0; i < V_IT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const bool ok = v_use[i] && (full || kv0 + v_row[i] + r < a.Sk);
+        v_reg[i][r] = ok ? *reinterpret_cast<const uint4*>(vp[i] + (long)r * a.ldv) : make_uint4(0, 0, 0, 0);
+      }
+      vp[i] += (long)KV_T * a.ldv;
+    }
+  };
+  auto store_k = [&](int stage, int kv0) {
+    unsigned char* base = Kst + stage * K_STAGE;
+#pragma unroll
+    for (int i = 0; i < K_IT; ++i)
+      if (k_use[i]) *reinterpret_cast<uint4*>(base + k_dst[i]) = k_reg[i];
+    if (kv0 + KV_T > a.Sk && tid < KV_T && kv0 + tid >= a.Sk)      // ragged last tile: flag the padded keys
+      *reinterpret_cast<half_t*>(base + tid * K_LDB + (d + 1) * 2) = (half_t)1.f;
+  };
+  auto store_v = [&](int stage) {
+    unsigned char* base = Vst + stage * V_STAGE;
+#pragma unroll
+    for (int i = 0; i < V_IT; ++i)
+      if (v_use[i]) {
+        const half_t* e0 = reinterpret_cast<const half_t*>(&v_reg[i][0]);
+        const half_t* e1 = reinterpret_cast<const half_t*>(&v_reg[i][1]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          half2_t pr = {e0[e], e1[e]};
+          *reinterpret_cast<half2_t*>(base + v_dst[i] + e * VT_LDB) = pr;
+        }
+      }
+  };
+
+  // ---- the two products
+  const unsigned k_lane = qi * K_LDB + hh * 16;       // + stage + kb * 32 * K_LDB + s * 32
+  const unsigned v_lane = qi * VT_LDB + hh * 16;      // + stage + dt * 32 * VT_LDB + kb * 64 + u * 32
+  auto qk = [&](int stage, f32x16 (&s)[2]) {
+    const unsigned char* base = Kst + stage * K_STAGE + k_lane;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const half8_t kf = *reinterpret_cast<const half8_t*>(base + kb * 32 * K_LDB + ks * 32);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], acc, 0, 0, 0);
+      }
+      s[kb] = acc;
+    }
+  };
+  f32x16 oacc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+  auto exp_pv = [&](int stage, const f32x16 (&s)[2]) {
+    const unsigned char* base = Vst + stage * V_STAGE + v_lane;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        half8_t pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (half_t)__builtin_amdgcn_exp2f(s[kb][8 * u + j]);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          const half8_t vf = *reinterpret_cast<const half8_t*>(base + dt * 32 * VT_LDB + kb * 64 + u * 32);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[dt], 0, 0, 0);
+        }
+      }
+  };
+  // row max of a score tile (relative to the current reference) -> every lane of the query's pair
+  auto tile_max = [&](const f32x16 (&s)[2]) {
+    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[0][r]), s[0][r + 1]);
+    mx = fmaxf(fmaxf(mx, s[0][15]), s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[1][r]), s[1][r + 1]);
+    mx = fmaxf(mx, s[1][15]);
+    return half_pair_max(mx);
+  };
+
+  // MFMA slots of one key tile: NQ = 2 NKS slots of S(t+1) (k-step major, the two 32-key blocks alternating), then
+  // NP = 4 NDT slots of O += V^T(t) P(t) (exp group g = 2 kb + u major, dv tile minor)
+  constexpr int NQ = 2 * NKS, NP = 4 * NDT, NM = NQ + NP;
+  constexpr int NE_SLOTS = NQ + 2 * NDT;        // the 32 exponentials are spread over the slots in front of PV(g = 2)
+  auto pipelined_tile = [&](int kstage, int vstage, const f32x16 (&sc)[2], f32x16 (&sn)[2]) {
+    const unsigned char* kbase = Kst + kstage * K_STAGE + k_lane;
+    const unsigned char* vbase = Vst + vstage * V_STAGE + v_lane;
+    auto frag = [&](int slot) -> half8_t {
+      if (slot < NQ) {
+        const int ks = slot >> 1, kb = slot & 1;
+        return *reinterpret_cast<const half8_t*>(kbase + kb * 32 * K_LDB + ks * 32);
+      }
+      const int p = slot - NQ, g = p / NDT, dt = p - g * NDT;
+      return *reinterpret_cast<const half8_t*>(vbase + dt * 32 * VT_LDB + g * 32);      // kb * 64 + u * 32 = 32 g
+    };
+    half8_t pf[4];
+    half8_t fr[PF + 1];                 // fragment ring: slot s multiplies fr[0]; fr[PF] is requested PF slots ahead
+#pragma unroll
+    for (int i = 0; i < PF; ++i) fr[i] = frag(i);
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sn[0][r] = 0.f; sn[1][r] = 0.f; }
+#pragma unroll
+    for (int slot = 0; slot < NM; ++slot) {
+      if (slot + PF < NM) fr[PF] = frag(slot + PF);
+      // exponentials due by the end of this slot (group g complete before PV slot NQ + g NDT)
+      const int e0 = slot < NE_SLOTS ? (32 * slot) / NE_SLOTS : 32;
+      const int e1 = slot + 1 < NE_SLOTS ? (32 * (slot + 1)) / NE_SLOTS : 32;
+#pragma unroll
+      for (int e = 0; e < 32; ++e)
+        if (e >= e0 && e < e1) pf[e >> 3][e & 7] = (half_t)__builtin_amdgcn_exp2f(sc[e >> 4][e & 15]);
+      if (slot < NQ) {
+        const int ks = slot >> 1, kb = slot & 1;
+        sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[0], qf[ks], sn[kb], 0, 0, 0);
+      } else {
+        const int p = slot - NQ, g = p / NDT, dt = p - g * NDT;
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[0], pf[g], oacc[dt], 0, 0, 0);
+      }
+      // row max of S(t+1) (complete since slot NQ - 1): 16 max3 spread over the slots behind the exponentials
+      if (slot >= NE_SLOTS) {
+        const int p0 = (16 * (slot - NE_SLOTS)) / (NM - NE_SLOTS), p1 = (16 * (slot + 1 - NE_SLOTS)) / (NM - NE_SLOTS);
+#pragma unroll
+        for (int pr = 0; pr < 16; ++pr)
+          if (pr >= p0 && pr < p1) mx = fmaxf(fmaxf(mx, sn[pr >> 3][2 * (pr & 7)]), sn[pr >> 3][2 * (pr & 7) + 1]);
+      }
+#pragma unroll
+      for (int i = 0; i < PF; ++i) fr[i] = fr[i + 1];
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+    }
+    return half_pair_max(mx);
+  };
+
+  float m_ref = 0.f;
+  const int n_tiles = (a.Sk + KV_T - 1) / KV_T;
+
+  // ---- prologue: K(0) staged, S(0) computed and referenced to its own row max; K(1), V(0) on their way
+  load_k(0);
+  store_k(0, 0);
+  load_v(0);
+  if (n_tiles > 1) load_k(KV_T);
+  __syncthreads();
+  f32x16 s_cur[2], s_nxt[2];
+  qk(0, s_cur);
+  {
+    const float mx = tile_max(s_cur);
+    m_ref = (float)(half_t)mx;             // rounded to fp16 so that the Q slot holds it exactly
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_cur[kb][r] -= m_ref;
+    set_ref(m_ref);
+  }
+
+  for (int t = 0; t < n_tiles; ++t) {
+    const bool more = t + 1 < n_tiles;
+    // [A] stage K(t+1) and V(t): K stage (t+1)&1 last held K(t-1) (read in iteration t-2), V stage t&1 last held
+    // V(t-2) (read in iteration t-2); the barrier of iteration t-1 lies in between
+    if (more) store_k((t + 1) & 1, (t + 1) * KV_T);
+    store_v(t & 1);
+    __syncthreads();
+    if (t + 2 < n_tiles) load_k((t + 2) * KV_T);
+    if (more) load_v((t + 1) * KV_T);
+    // [B] S(t+1) = K(t+1) Q^T   and   [C] P(t) = exp2(S(t)), O += V^T(t) P(t): independent chains, issued as ONE pinned
+    // sequence of MFMA slots — every slot = {fragment read two slots ahead, a few exponentials of P(t), one MFMA} — so
+    // that the softmax VALU work sits in the issue gaps of this wave's own MFMAs (the only MFMA/VALU overlap this
+    // chip has).  (The last iteration multiplies a stale K stage into s_nxt, which nobody reads.)
+    const float mx_nxt = pipelined_tile((t + 1) & 1, t & 1, s_cur, s_nxt);
+    // [D] reference of tile t+1 (PV(t) is complete: a rescale covers everything accumulated so far exactly once)
+    if (more) {
+      const float mx = mx_nxt;
+      if (__builtin_amdgcn_ballot_w64(mx > 8.f) != 0) {
+        const float m_new = (float)(half_t)fmaxf(m_ref, mx + m_ref);
+        const float shift = m_new - m_ref;
+        const float alpha = __builtin_amdgcn_exp2f(-shift);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s_nxt[kb][r] -= shift;
+        m_ref = m_new;
+        set_ref(m_new);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) s_cur[kb] = s_nxt[kb];
+    }
+  }
+
+  // ---- epilogue.  Row sum = O^T row d (the row of ones): tile d>>5, lane half ((d&31)>>2)&1, register (d&3) + 4((d&31)>>3)
+  float l;
+  {
+    const int dl = d & 31, dt_l = d >> 5, h_l = (dl >> 2) & 1, r_l = (dl & 3) + 4 * (dl >> 3);
+    float lv = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (dt == dt_l && r == r_l) lv = oacc[dt][r];
+    l = __shfl(lv, h_l * 32 + qi, 64);
+  }
+  const int qrow = q0 + qi;
+  if (qrow < a.Sq) {
+    const float inv = 1.f / l;
+    half_t* orow = a.o + (long)b * a.o_bs + (long)qrow * a.ldo + (long)h * d;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int dv = dt * 32 + g4 * 8 + hh * 4;
+        if (dv < d) {
+          half4_t o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (half_t)(oacc[dt][g4 * 4 + r] * inv);
+          *reinterpret_cast<half4_t*>(orow + dv) = o;
+        }
+      }
+    if (a.lse && hh == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow] = m_ref + log2f(l);
+  }
+}
+
 template <int DP, bool SAVE_P>
 void launch_attn_dp(const AttnArgs& a, hipStream_t st) {
   if constexpr (SAVE_P) {
     dim3 grid((a.Sq + 63) / 64, a.H, a.B);
     hipLaunchKernelGGL((attn_fwd_kernel<DP>), grid, dim3(256), 0, st, a);
   } else {
+    // round-3 kernel (32x32x16 MFMA, in-wave software pipelining) for the narrow heads with a spare slot, once there
+    // are enough 256-query blocks to fill the chip; LGD_ATTN32=0 keeps the 16x16x32 kernel (A/B timing, tools)
+    if constexpr (DP == 64 || DP == 96) {
+      // g_attn32 (lgd_set_option("attn32", v); initial value from LGD_ATTN32 in the environment): 0 = never (the
+      // 16x16x32 kernel: A/B timing), 1 = default, 2 = for every problem size (tests)
+      const int a32 = attn32_mode();
+      const int dk = ((a.d + 2 + 15) / 16) * 16;
+      // measured (tools/attn_quick.py, B = 16): d = 80 (DK = 96) 97 -> 80 us; d = 40 (DK = 48) 570 -> 630 us — at two
+      // waves per SIMD (170 VGPRs) its stalls are not covered the way the 16x16x32 kernel's four waves cover theirs —
+      // so by default only the DK = 96 heads take this kernel
+      if (a32 && a.d % 8 == 0 && (a32 == 2 || (dk == 96 && (long)((a.Sq + 255) / 256) * a.H * a.B >= 512))) {
+        const int var = attn32_var();
+        auto go = [&](auto kern, int nw) {
+          dim3 g32((a.Sq + 32 * nw - 1) / (32 * nw), a.H, a.B);
+          hipLaunchKernelGGL(kern, g32, dim3(64 * nw), 0, st, a);
+        };
+        if (attn32_nw() == 4) {
+          if (dk == 48) { go(&attn_self32_kernel<48, 2, 4>, 4); return; }
+          if (dk == 96) { go(&attn_self32_kernel<96, 3, 4>, 4); return; }
+        } else if (var == 1) {
+          if (dk == 48) { go(&attn_self32_kernel<48, 2, 8, 4, true>, 8); return; }
+          if (dk == 96) { go(&attn_self32_kernel<96, 3, 8, 4, true>, 8); return; }
+        } else if (var == 2) {
+          if (dk == 48) { go(&attn_self32_kernel<48, 2, 8, 1, true, 4>, 8); return; }     // <= 128 VGPRs: two workgroups per CU
+          if (dk == 96) { go(&attn_self32_kernel<96, 3, 8, 2, false>, 8); return; }
+        } else {
+          if (dk == 48) { go(&attn_self32_kernel<48, 2, 8>, 8); return; }
+          if (dk == 96) { go(&attn_self32_kernel<96, 3, 8>, 8); return; }
+        }
+      }
+    }
     // two query tiles per wave once there are enough 128-query blocks to fill the chip
     const bool qt2 = (long)((a.Sq + 127) / 128) * a.H * a.B >= 1024 && DP <= 96;
     dim3 grid(qt2 ? (a.Sq + 127) / 128 : (a.Sq + 63) / 64, a.H, a.B);
@@ -626,6 +1036,14 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
 bool bad_view(int64_t ld, int d) { return (ld % 8) != 0 || (d % 8) != 0; }
 
 }  // namespace
+
+extern "C" int lgd_set_option(const char* name, int value) {
+  if (!name) return LGD_ERR_ARG;
+  if (!strcmp(name, "attn32")) { g_attn32 = value; return LGD_OK; }
+  if (!strcmp(name, "attn32_nw") && (value == 4 || value == 8)) { g_attn32_nw = value; return LGD_OK; }
+  if (!strcmp(name, "attn32_var") && value >= 0 && value <= 2) { g_attn32_var = value; return LGD_OK; }
+  return LGD_ERR_ARG;
+}
 
 extern "C" int lgd_attn_fwd_f16(const void* q, int64_t ldq, int64_t q_bs, const void* k,
                                 int64_t ldk, int64_t k_bs, const void* v, int64_t ldv, int64_t v_bs,

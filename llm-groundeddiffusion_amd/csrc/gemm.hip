@@ -42,13 +42,11 @@ __device__ __forceinline__ float4 ld_bias4(const float* p, int n) {
   return *reinterpret_cast<const float4*>(p + n);
 }
 
-// Applies the epilogue to 4 consecutive output channels (n..n+3) of row m and stores them.
+// The epilogue arithmetic on 4 consecutive output channels (n..n+3) of row m: bias, GEGLU, alpha, residual.
 // For GEGLU `v` holds the value accumulators and `g` the gate accumulators of the same columns.
 template <bool GEGLU>
-__device__ __forceinline__ void epilogue_store4(const LgdGemmDesc& d, long c_off, long r_off, int m,
-                                                int n_out, f32x4 v, f32x4 g, float4 bv, float4 bg,
-                                                bool res_ready = false,
-                                                half4_t res_pre = (half4_t){0, 0, 0, 0}) {
+__device__ __forceinline__ f32x4 epilogue_value4(const LgdGemmDesc& d, long r_off, int m, int n_out, f32x4 v, f32x4 g,
+                                                 float4 bv, float4 bg, bool res_ready, half4_t res_pre) {
   // bv / bg: summed biases of the value / gate columns (zeros when absent); n_out: output column;
   // res_pre: the fp16 residual of these 4 outputs when the caller already fetched it (res_ready).
   v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
@@ -75,6 +73,16 @@ __device__ __forceinline__ void epilogue_store4(const LgdGemmDesc& d, long c_off
       for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
     }
   }
+  return v;
+}
+
+// Applies the epilogue to 4 consecutive output channels (n..n+3) of row m and stores them.
+template <bool GEGLU>
+__device__ __forceinline__ void epilogue_store4(const LgdGemmDesc& d, long c_off, long r_off, int m,
+                                                int n_out, f32x4 v, f32x4 g, float4 bv, float4 bg,
+                                                bool res_ready = false,
+                                                half4_t res_pre = (half4_t){0, 0, 0, 0}) {
+  v = epilogue_value4<GEGLU>(d, r_off, m, n_out, v, g, bv, bg, res_ready, res_pre);
   if (d.epi & LGD_EPI_OUT_F32) {
     float* cp = reinterpret_cast<float*>(d.c) + c_off + (long)m * d.ldc + n_out;
     *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -179,6 +187,110 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& ga, f32x4 (&acc)[N
           epilogue_store4<false>(d, c_off, r_off, m, n, acc[ni][mi], acc[ni][mi], bv, bv, res16,
                                  res16 ? rpre[nj][mi] : (half4_t){0, 0, 0, 0});
       }
+    }
+  }
+}
+
+// Epilogue of the 8-wave kernels through LDS (round 3): the MFMA fragment layout gives a lane 4 consecutive channels
+// of one pixel, so a direct store instruction writes 16 rows x 32 bytes — measured on MI355X, a 65536 x 960 fp16
+// output leaves the chip at 2.1 TB/s that way, and every short-K GEMM (q/k/v/out projections, feed-forward) sat on
+// that floor whatever its tile (tools/gemm_epi_probe.py).  Here the finished fp16 values of a group of wave rows are
+// parked in ONE free stage of the operand ring (row stride + 16 B), then written out as whole rows, 16 bytes per lane:
+// full 128-byte lines per request.  The arithmetic (bias, GEGLU, alpha, residual, single rounding to fp16) is
+// epilogue_value4, unchanged; the residual is still fetched in the fragment layout (reads of 32-byte pieces are served
+// by L1 / L2 at 4 TB/s; it is the WRITES of partial lines that were slow).
+//   `lds`: a STAGE_B-byte region nobody else touches (the stage consumed last: no DMA in flight into it, all fragment
+//   reads of it retired before the K loop's last barrier) — valid for one-tile and persistent workgroups alike.
+//   Bare s_barrier + lgkmcnt(0): a __syncthreads() would drain the DMA queue of a persistent workgroup.
+template <int MI, int NI, int WM, int WN, int STAGE_B, bool GEGLU, bool RES_PREFETCH>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& ga, f32x4 (&acc)[NI][MI], int m0, int n0, int wm,
+                                                  int wn, int lane, int tid, long c_off, long r_off,
+                                                  unsigned char* lds) {
+  const LgdGemmDesc& d = ga.d;
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = WM * 16 * MI, BN = WN * 16 * NI;
+  constexpr int BN_OUT = GEGLU ? BN / 2 : BN;
+  constexpr int NI_OUT = GEGLU ? NI / 2 : NI;           // output column tiles of a wave
+  constexpr int CROW = BN_OUT * 2 + 16;                 // bytes per staged row
+  // rounds over the 16-row tiles (mi) of EVERY wave: all waves work in both phases of a round, and a round still
+  // covers whole output rows (16 MI_R rows of each of the WM wave rows)
+  constexpr int R = (BM * CROW <= STAGE_B) ? 1 : ((BM / 2) * CROW <= STAGE_B) ? 2 : 4;
+  static_assert(MI % R == 0 && (BM / R) * CROW <= STAGE_B, "staged rows must fit one ring stage");
+  constexpr int MI_R = MI / R;
+  constexpr int WROWS = 16 * MI_R;                      // rows of one wave row per round
+  constexpr int RROWS = WM * WROWS;
+  constexpr int CPR = BN_OUT / 8;                       // 16-byte chunks per row
+  const int m_l = lane & 15, n_l = (lane >> 4) * 4;
+  const int n0_out = GEGLU ? n0 / 2 : n0;
+  const int n_total_out = GEGLU ? d.N / 2 : d.N;
+  const bool res16 = d.res && !(d.epi & LGD_EPI_RES_F32);
+  half_t* cbase = reinterpret_cast<half_t*>(d.c) + c_off;
+  // biases of this wave's columns: all loads in flight at once
+  float4 bv[NI_OUT], bg[NI_OUT];
+#pragma unroll
+  for (int no = 0; no < NI_OUT; ++no) {
+    const int n_out = n0_out + wn * 16 * NI_OUT + no * 16 + n_l;
+    const int n_in = GEGLU ? n0 + wn * 16 * NI + no * 32 + n_l : n_out;
+    bv[no] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bg[no] = bv[no];
+    if (n_out < n_total_out) {
+      bv[no] = ld_bias_sum4(d, n_in);
+      if (GEGLU && d.bias) bg[no] = ld_bias4(d.bias, n_in + 16);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    // residual fetches of the round first (one memory round trip for MI_R x NI_OUT pieces)
+    half4_t rpre[NI_OUT][MI_R];
+    if (res16 && !GEGLU) {
+      const half_t* rb = reinterpret_cast<const half_t*>(d.res) + r_off;
+#pragma unroll
+      for (int no = 0; no < NI_OUT; ++no) {
+        int n = n0_out + wn * 16 * NI_OUT + no * 16 + n_l;
+        if (n >= n_total_out) n = 0;
+#pragma unroll
+        for (int mj = 0; mj < MI_R; ++mj) {
+          int m = m0 + wm * 16 * MI + (r * MI_R + mj) * 16 + m_l;
+          if (m >= d.M) m = d.M - 1;
+          rpre[no][mj] = *reinterpret_cast<const half4_t*>(rb + (long)m * d.ldr + n);
+        }
+      }
+    }
+#pragma unroll
+    for (int no = 0; no < NI_OUT; ++no) {
+      const int n_out = n0_out + wn * 16 * NI_OUT + no * 16 + n_l;
+      const int nn = n_out < n_total_out ? n_out : 0;
+#pragma unroll
+      for (int mj = 0; mj < MI_R; ++mj) {
+        const int mi = r * MI_R + mj;
+        int m = m0 + wm * 16 * MI + mi * 16 + m_l;
+        if (m >= d.M) m = d.M - 1;
+        f32x4 v;
+        if constexpr (GEGLU) v = epilogue_value4<true>(d, r_off, m, nn, acc[2 * no][mi], acc[2 * no + 1][mi], bv[no], bg[no], false, (half4_t){0, 0, 0, 0});
+        else v = epilogue_value4<false>(d, r_off, m, nn, acc[no][mi], acc[no][mi], bv[no], bv[no], res16, res16 ? rpre[no][mj] : (half4_t){0, 0, 0, 0});
+        half4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+        *reinterpret_cast<half4_t*>(lds + (wm * WROWS + mj * 16 + m_l) * CROW + (wn * 16 * NI_OUT + no * 16 + n_l) * 2) = o;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // whole rows, 16 bytes per lane
+#pragma unroll
+    for (int i = 0; i < (RROWS * CPR + NT - 1) / NT; ++i) {
+      const int idx = tid + i * NT;
+      const int row = idx / CPR, ch = idx - row * CPR;
+      const int wr = row / WROWS;
+      const int m = m0 + wr * 16 * MI + r * WROWS + (row - wr * WROWS), n = n0_out + ch * 8;
+      if (idx < RROWS * CPR && m < d.M && n < n_total_out) {
+        const uint4 val = *reinterpret_cast<const uint4*>(lds + row * CROW + ch * 16);
+        *reinterpret_cast<uint4*>(cbase + (long)m * d.ldc + n) = val;
+      }
+    }
+    if (r + 1 < R) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
   }
 }
@@ -947,12 +1059,28 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
         so_cur = so_nxt; so_nxt = next_stage(so_nxt); so_iss = next_stage(so_iss);
       }
     };
+    // fp16 outputs without split-K leave through LDS as whole rows (gemm_epilogue_lds); the stage consumed last is free
+    const bool lds_epi = d.splits == 1 && !(d.epi & LGD_EPI_OUT_F32) && !(d.N & 7) && !(d.ldc & 7) && !(c_off & 7) &&
+                         !(reinterpret_cast<uintptr_t>(d.c) & 15) && !((d.epi & LGD_EPI_GEGLU) && (NI & 1));
+    auto epilogue = [&](int m0_, int n0_) {
+      if (lds_epi) {
+        unsigned char* free_stage = reinterpret_cast<unsigned char*>(smem) + so_iss;
+        if (d.epi & LGD_EPI_GEGLU) {
+          if constexpr (NI % 2 == 0)
+            gemm_epilogue_lds<MI, NI, WM, WN, STAGE_B, true, !PERSIST>(ga, acc, m0_, n0_, wm, wn, lane, tid, c_off, r_off, free_stage);
+        } else {
+          gemm_epilogue_lds<MI, NI, WM, WN, STAGE_B, false, !PERSIST>(ga, acc, m0_, n0_, wm, wn, lane, tid, c_off, r_off, free_stage);
+        }
+      } else {
+        gemm_epilogue<MI, NI>(ga, acc, m0_, n0_, wm, wn, lane, batch, split, c_off, r_off);
+      }
+    };
     if constexpr (PERSIST) {
       for (int v = blockIdx.x; v < total_tiles; v += gridDim.x) {
         tile_origin(v, m0, n0);
         k_loop();
         // epilogue of this output tile; the next tile's first D K tiles are already on their way into the ring
-        gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off);
+        epilogue(m0, n0);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -963,7 +1091,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
     } else {
       k_loop();
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off);
+      epilogue(m0, n0);
     }
   } else {
     for (int v = blockIdx.x; v < total_tiles; v += gridDim.x) {

@@ -29,6 +29,11 @@ def _call(name, *args):
     _lib.check(rc, name)
 
 
+def set_option(name: str, value: int):
+    """Kernel-variant switch of the library (lgd_set_option): e.g. set_option("attn32", 0 | 1 | 2)."""
+    _call("lgd_set_option", name.encode(), int(value))
+
+
 # ---------------------------------------------------------------------------------------------
 # GEMM / conv
 # ---------------------------------------------------------------------------------------------

@@ -282,6 +282,53 @@ def test_attn_fwd_bwd(dev, B, H, Sq, Sk, d):
     assert relerr(gv, un(vr.grad, Sk)) < 1e-2
 
 
+@pytest.mark.parametrize("B,H,Sq,Sk,d", [
+    (2, 8, 4096, 4096, 40), (1, 8, 300, 333, 40), (2, 8, 1024, 1054, 80), (1, 3, 77, 64, 40), (1, 2, 256, 1, 80),
+    (1, 8, 4096, 4126, 40), (1, 4, 129, 257, 24), (1, 2, 500, 190, 56), (1, 2, 64, 700, 88),
+])
+def test_attn_self32_kernel_every_size(dev, B, H, Sq, Sk, d):
+    """The round-3 self-attention forward (32x32x16 MFMA, in-wave pipelining; attention_processor.py:338-363 semantics)
+    forced for every problem size (lgd_set_option("attn32", 2)): ragged query / key counts (masked through the spare head-dim slot),
+    single-tile and single-key cases, every head dim it serves (d + 2 <= 48 or 96), output and log-sum-exp vs fp32
+    torch, and bit-for-bit determinism; with spiked keys the lazily raised reference must rescale."""
+    ops.set_option("attn32", 2)
+    try:
+        _attn_self32_case(dev, B, H, Sq, Sk, d)
+    finally:
+        ops.set_option("attn32", 1)
+
+
+def _attn_self32_case(dev, B, H, Sq, Sk, d):
+    C = H * d
+    scale = d ** -0.5
+    q = rnd(B, Sq, C, dev=dev, seed=1).half()
+    k = rnd(B, Sk, C, dev=dev, seed=2).half()
+    v = rnd(B, Sk, C, dev=dev, seed=3).half()
+    sp = lambda t, S: t.float().reshape(B, S, H, d).permute(0, 2, 1, 3)
+    for spike in (False, True):
+        if spike:
+            if Sk < 8:
+                continue
+            for qi, ki in [(5, Sk - 3), (Sq // 2 + 1, min(Sk - 1, Sk // 2 + 70)), (Sq - 1, min(Sk - 1, 200))]:
+                k[:, ki] = q[:, qi] * 6.0
+        o = torch.empty(B, Sq, C, device=dev, dtype=H16)
+        lse = torch.empty(B, H, Sq, device=dev)
+        ops.attn_fwd(q, k, v, o, B, H, Sq, Sk, d, scale, lse=lse)
+        o2 = torch.empty_like(o)
+        ops.attn_fwd(q, k, v, o2, B, H, Sq, Sk, d, scale)
+        ref, _ = _attn_ref(sp(q, Sq), sp(k, Sk), sp(v, Sk), scale)
+        e = relerr(o, ref.permute(0, 2, 1, 3).reshape(B, Sq, C))
+        lse_ref = torch.logsumexp(torch.einsum("bhqd,bhkd->bhqk", sp(q, Sq), sp(k, Sk)) * scale, dim=-1) * 1.4426950408889634
+        el = float((lse - lse_ref).abs().max())
+        print(f"attn32 B{B} H{H} {Sq}x{Sk} d{d} spike={spike}: relerr {e:.2e}, lse abs err {el:.2e}")
+        assert torch.isfinite(o).all() and torch.equal(o, o2)
+        assert e < 4e-3 and el < 2e-2
+    ops.set_option("attn32", 0)                        # and the 16x16x32 kernel it replaces agrees with it
+    o3 = torch.empty_like(o)
+    ops.attn_fwd(q, k, v, o3, B, H, Sq, Sk, d, scale)
+    assert relerr(o3, o) < 4e-3
+
+
 def test_attn_qkv_fused_view(dev):
     """q/k/v taken as column views of one fused [B,S,3C] projection output."""
     B, H, S, d = 2, 8, 256, 40
