@@ -590,14 +590,14 @@ __global__ __launch_bounds__(64 * NW) void attn_self_kernel(const AttnArgs a) {
 }
 
 // max over the two lanes (l, l + 32) that share a query in the 32x32 accumulator layout, delivered to both.
-// hipcc (ROCm 7.2) folds permlane32_swap(x, x) into {x, x} — it treats the swap of two EQUAL operands as the identity,
-// which drops the cross-lane exchange (every lane then sees the lower half's value only).  The second operand is
-// therefore made opaque to the optimiser before the swap.
+// Written as inline asm on purpose: with __builtin_amdgcn_permlane32_swap(x, x) hipcc (ROCm 7.2) drops the fmaxf of the
+// two results — it folds the swap of two copies of one value into the identity, also behind an opaque register copy —
+// and every lane then sees the lower half's value only (found with spiked keys in the upper half: fp16 inf in P).
+// s_nop 1 = the two wait states between a VALU write of an operand and v_permlane32_swap reading it.
 __device__ __forceinline__ float half_pair_max(float mx) {
-  unsigned u0 = __builtin_bit_cast(unsigned, mx), u1 = u0;
-  asm volatile("" : "+v"(u1));
-  auto sw = __builtin_amdgcn_permlane32_swap(u0, u1, false, false);
-  return fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+  float a = mx, b = mx;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
 }
 
 // ---------------------------------------------------------------------------------------------

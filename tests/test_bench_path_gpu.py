@@ -370,8 +370,11 @@ def test_fullsize_sd21_guidance_iteration_vs_oracle(dev):
     saved = {}
     R.unet_forward(sd, cd, lat, rs.timesteps[1], cond, saved=saved, save_keys=KEYS, stop_after=KEYS[-1])
     loss = R.compute_ca_lossv3(saved, BOXES, OBJ_POS, KEYS, index=1, **kw) * 30
-    grads = torch.autograd.grad(loss, [saved[k] for k in KEYS] + [lat])
-    g_maps_ref, g_lat_ref = grads[:-1], grads[-1].double().reshape(-1)
+    g_lat_ref = torch.autograd.grad(loss, [lat])[0].double().reshape(-1)
+    # the energy's own (direct) map gradients: the maps as leaves, without the network paths between the keys
+    leaves = {k: saved[k].detach().clone().requires_grad_(True) for k in KEYS}
+    g_maps_ref = torch.autograd.grad(R.compute_ca_lossv3(leaves, BOXES, OBJ_POS, KEYS, index=1, **kw) * 30,
+                                     [leaves[k] for k in KEYS])
     sm = LMDSampler(eng, DDIMScheduler(prediction_type=cfg.prediction_type), use_graphs=False)
     guid = dict(bboxes=BOXES, object_positions=OBJ_POS, loss_scale=30, loss_threshold=0.0, max_iter=1,
                 max_index_step=25, guidance_attn_keys=KEYS, **kw)
@@ -383,7 +386,7 @@ def test_fullsize_sd21_guidance_iteration_vs_oracle(dev):
     for k, gm in zip(KEYS, g_maps_ref):
         gh = pg.gmaps[k].float().cpu() / sm.grad_scale
         assert int((gh != 0).sum()) == int((gm != 0).sum()), k           # the same number of selected positions
-        gate(f"[sd21 full] map-gradient support mismatch {k}", float(((gh != 0) != (gm != 0)).float().mean()) + 1e-9, 5e-4)
+        gate(f"[sd21 full] map-gradient support mismatch {k}", float(((gh != 0) != (gm != 0)).float().mean()) + 1e-9, 2.9e-4)
     a = tr[0]["grad"].cpu().double().reshape(-1)
     gate("[sd21 full] latent-gradient cosine end to end (incl. flipped top-k selections)", cos(a, g_lat_ref), 0.99, at_least=True)
     for k, gm in zip(KEYS, g_maps_ref):

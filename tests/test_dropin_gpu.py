@@ -349,7 +349,8 @@ def test_lmd_plus_overall_stage_teacher_forced(dropin, dev):
             # limits = 3x the measured errors: step 0 runs two guidance iterations (chaotic: the fp32 oracle itself
             # amplifies a 1e-3 input perturbation of such a step 21x, tests/test_oracle.py); steps 1-3 still blend in the
             # composed latents (3e-3 off the golden's); steps 4-7 are plain CFG + DDIM
-            limits = [1.3e-1, 9.5e-3, 9e-3, 9e-3, 2.6e-4, 2.4e-4, 2.3e-4, 7.5e-6]
+            limits = ([1.3e-1, 9.5e-3, 9e-3, 9e-3, 2.6e-4, 2.4e-4, 2.3e-4, 7.5e-6] if tag == "a" else
+                      [1.5e-1, 2.9e-2, 9.4e-3, 9.7e-3, 2.1e-4, 1.8e-4, 1.7e-4, 7.9e-6])
             for i in range(8):
                 out = lmd_plus_generate(sm, lay, overall_first_step=i, overall_n_steps=1, overall_start=[starts[i]], **kw)
                 want = starts[i + 1] if i < 7 else gold[f"{tag}_final_latents"]

@@ -10,7 +10,7 @@ def rnd(*shape, seed=0):
     g = torch.Generator(device="cpu").manual_seed(seed)
     return torch.randn(*shape, generator=g).to(dev)
 def run(B, H, S, d, spikes, mult=6.0, force=None):
-    if force is not None: os.environ["LGD_ATTN32"] = force
+    if force is not None: ops.set_option("attn32", int(force))
     C = H * d
     q = rnd(B, S, C, seed=1).half(); k = rnd(B, S, C, seed=2).half(); v = rnd(B, S, C, seed=3).half()
     for qi, ki in spikes:
@@ -30,11 +30,12 @@ def run(B, H, S, d, spikes, mult=6.0, force=None):
         info = f" first bad row {rows[0]} argmax {int(sc.argmax())} max {float(sc.max()):.1f} tile maxes (first 4) {[round(float(x),1) for x in tm[:4]]} last 3 {[round(float(x),1) for x in tm[-3:]]}"
     print(f"B{B} S{S} d{d} spikes {spikes} x{mult} force={force}: bad rows {len(rows)} nan {nan} inf {inf}{info}", flush=True)
 S = 4096
-print("lib", _lib.LIB_PATH)
-os.system("rocm-smi --showuniqueid --showserial 2>/dev/null | head -12")
-run(4, 8, S, 40, [(5, S - 3)])
-run(4, 8, S, 40, [(5, S - 70)])
-run(4, 8, S, 40, [(5, 70)])
-run(1, 8, S, 40, [(5, S - 3)], force="2")
-run(4, 8, S, 40, [(5, S - 3)], force="0")
-run(4, 8, S, 40, [(5, S - 3)], force="1")
+S = 1024
+run(16, 8, S, 80, [(5, S - 3), (S // 2 + 1, S // 2 + 70), (S - 1, 200)], force="1")
+run(16, 8, S, 80, [(5, S - 3)], force="1")
+run(16, 8, S, 80, [(5, 200)], force="1")
+run(16, 8, S, 80, [(5, 196)], force="1")
+run(16, 8, S, 80, [(5, 70)], force="1")
+run(16, 8, S, 80, [(5, 200)], mult=2.0, force="1")
+run(16, 8, S, 80, [], force="1")
+run(16, 8, S, 80, [(5, S - 3), (S // 2 + 1, S // 2 + 70), (S - 1, 200)], force="0")

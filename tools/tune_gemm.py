@@ -24,7 +24,7 @@ L = cfg.sample_size
 
 shapes = {}
 orig = ops.gemm_launch
-def rec(d, tag=None):
+def rec(d, tag=None, flops=None):
     key = ops.shape_key(d)
     shapes.setdefault(key, dict(M=d.M, N=d.N, K=d.K, taps=d.taps, c0=d.c0, c1=d.c1, hin=d.hin, win=d.win,
                                 hout=d.hout, wout=d.wout, stride=d.stride, ups=d.ups, epi=d.epi,
@@ -53,14 +53,14 @@ def make_problem(sh):
     M, N, K = sh["M"], sh["N"], sh["K"]
     c0, c1, taps = sh["c0"], sh["c1"], sh["taps"]
     rows_in = M if taps == 1 else max(1, (M // max(sh["hout"] * sh["wout"], 1))) * sh["hin"] * sh["win"]
-    g = torch.Generator(device="cpu").manual_seed(M * 31 + N * 7 + K)
-    a0 = torch.randn(rows_in, c0, generator=g).to(dev).half()
-    a1 = torch.randn(rows_in, c1, generator=g).to(dev).half() if c1 else None
-    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev).half()
+    g = torch.Generator(device=dev).manual_seed(M * 31 + N * 7 + K)
+    a0 = torch.randn(rows_in, c0, generator=g, device=dev).half()
+    a1 = torch.randn(rows_in, c1, generator=g, device=dev).half() if c1 else None
+    w = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).half()
     geglu = bool(sh["epi"] & 1)
     n_out = N // 2 if geglu else N
-    bias = torch.randn(N, generator=g).to(dev) if sh["has_bias"] else None
-    res = torch.randn(M, n_out, generator=g).to(dev).half() if sh["has_res"] else None
+    bias = torch.randn(N, generator=g, device=dev) if sh["has_bias"] else None
+    res = torch.randn(M, n_out, generator=g, device=dev).half() if sh["has_res"] else None
     return dict(a0=a0, a1=a1, w=w, bias=bias, res=res, n_out=n_out)
 
 
@@ -107,6 +107,12 @@ def bench(sh, pb, ref, tile, splits, reps=8):
     return e0.elapsed_time(e1) / reps * 1e3   # us
 
 table = json.load(open(out_path)) if (os.path.exists(out_path) and not os.environ.get("LGD_TUNE_FRESH")) else {}
+# LGD_TUNE_TOP=N: re-tune the N table entries that cost the passes the most time (count x us), keep the others
+if os.environ.get("LGD_TUNE_TOP"):
+    top = sorted((k for k in table if k in shapes), key=lambda k: -table[k]["us"] * shapes[k]["count"])[:int(os.environ["LGD_TUNE_TOP"])]
+    covered = sum(table[k]["us"] * shapes[k]["count"] for k in top) / max(sum(table[k]["us"] * shapes[k]["count"] for k in table if k in shapes), 1e-9)
+    print(f"re-tuning the {len(top)} most expensive shapes ({100 * covered:.1f} % of the passes' GEMM time)")
+    old_entries = {k: table.pop(k) for k in top}
 tot_old = tot_new = 0.0
 for key, sh in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"] * kv[1]["N"] * kv[1]["K"]):
     if key in table:
