@@ -115,7 +115,7 @@ if os.environ.get("LGD_TUNE_TOP"):
     old_entries = {k: table.pop(k) for k in top}
 tot_old = tot_new = 0.0
 for key, sh in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"] * kv[1]["N"] * kv[1]["K"]):
-    if key in table:
+    if key in table or sh["K"] % 64:          # K % 64 != 0 (conv_in, K = 72): the register-staged fallback, heuristic tile
         continue
     M, N, K = sh["M"], sh["N"], sh["K"]
     geglu = bool(sh["epi"] & 1)
