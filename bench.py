@@ -116,21 +116,25 @@ def cpu_baseline(cfg, generations, n_steps, beta, iters_on, iters_off):
     t_on, t_off = times.get(True, times[False]), times[False]
     sched = R.DDIM(prediction_type=cfg.prediction_type)
     sched.set_timesteps(n_steps)
-    t0 = time.time()
-    R.latent_backward_guidance(sd, cd, sched, cond, 0, boxes, [[1, 2, 3], [5, 6, 7]], sched.timesteps[0], x[:1],
-                               torch.tensor(1e4), loss_scale=5, loss_threshold=0.0, max_iter=1, max_index_step=30,
-                               guidance_attn_keys=R.DEFAULT_GUIDANCE_ATTN_KEYS, fg_top_p=0.2, bg_top_p=0.2,
-                               fg_weight=1.0, bg_weight=4.0,
-                               gligen=dict(boxes=gl["boxes"][:1], positive_embeddings=gl["positive_embeddings"][:1],
-                                           masks=gl["masks"][:1]) if gl else None)
-    t_g = time.time() - t0
+    tg = {}
+    for on in ([True, False] if gl is not None else [False]):      # guidance iterations with the fuser on AND off
+        t0 = time.time()
+        R.latent_backward_guidance(sd, cd, sched, cond, 0, boxes, [[1, 2, 3], [5, 6, 7]], sched.timesteps[0], x[:1],
+                                   torch.tensor(1e4), loss_scale=5, loss_threshold=0.0, max_iter=1, max_index_step=30,
+                                   guidance_attn_keys=R.DEFAULT_GUIDANCE_ATTN_KEYS, fg_top_p=0.2, bg_top_p=0.2,
+                                   fg_weight=1.0, bg_weight=4.0, fuser_enabled=on,
+                                   gligen=dict(boxes=gl["boxes"][:1], positive_embeddings=gl["positive_embeddings"][:1],
+                                               masks=gl["masks"][:1]) if gl else None)
+        tg[on] = time.time() - t0
+    tg_on, tg_off = tg.get(True, tg[False]), tg[False]
     n_on = int(beta * n_steps) if gl is not None else 0
-    per_image = generations * (n_on * t_on + (n_steps - n_on) * t_off) + (iters_on + iters_off) * t_g
+    per_image = generations * (n_on * t_on + (n_steps - n_on) * t_off) + iters_on * tg_on + iters_off * tg_off
     return dict(value=1.0 / per_image, unit="images/s", cores=cores, kind="port",
                 sample=(f"oracle/restate.py fp32 on {cores} host threads, measured: 1 CFG UNet call (B=2) fuser on "
-                        f"{t_on:.2f}s, fuser off {t_off:.2f}s, 1 guidance iteration (fwd+bwd, early exit, fuser on) "
-                        f"{t_g:.2f}s; extrapolated to one image = {generations:.2f} generation(s) x ({n_on} on + "
-                        f"{n_steps - n_on} off) UNet calls + {iters_on + iters_off:.1f} guidance iterations (VAE excluded)"))
+                        f"{t_on:.2f}s, fuser off {t_off:.2f}s, 1 guidance iteration (fwd+bwd, early exit) fuser on "
+                        f"{tg_on:.2f}s, fuser off {tg_off:.2f}s; extrapolated to one image = {generations:.2f} generation(s) x "
+                        f"({n_on} on + {n_steps - n_on} off) UNet calls + {iters_on:.1f} + {iters_off:.1f} guidance "
+                        f"iterations (fuser on + off; VAE excluded)"))
 
 
 def free_port():
@@ -340,13 +344,18 @@ def main():
         if agg:
             name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
             ach = a["flops"] / (a["ms"] * 1e-3)
-            traffic, traffic_note = None, "no PMC summary for this kernel under profiles/"
-            tpath = os.path.join(ROOT, "profiles", "r02_bench_traffic_pmc.json")
-            if os.path.exists(tpath):
+            # HBM bytes per launch come from a committed PMC summary of THIS command's short form (PMC passes serialise
+            # every dispatch: they cannot run inside the timed region) — the source file is named in the record
+            traffic, traffic_note, traffic_source = None, "no PMC summary for this kernel under profiles/", None
+            for fname in ("r03_bench_traffic_pmc.json", "r02_bench_traffic_pmc.json"):
+                tpath = os.path.join(ROOT, "profiles", fname)
+                if not os.path.exists(tpath):
+                    continue
                 tj = json.load(open(tpath))
                 ent = tj.get("kernels", {}).get(name.split(" ")[0])
                 if ent:
-                    traffic, traffic_note = ent["hbm_bytes_per_launch"], tj.get("method", "")
+                    traffic, traffic_note, traffic_source = ent["hbm_bytes_per_launch"], tj.get("method", ""), f"profiles/{fname}"
+                    break
             gem = [v for k, v in agg.items() if k.startswith("gemm")]
             gemm_tf = sum(v["flops"] for v in gem) / max(sum(v["ms"] for v in gem) * 1e-3, 1e-12) / 1e12 if gem else None
             ap_ = tag_agg.get("attn_path")
@@ -354,7 +363,7 @@ def main():
                             unit="TFLOP/s", frac=round(ach / MFMA_PEAK_F16, 4), traffic=traffic,
                             avg_launch_us=round(a["raw_ms"] * 1e3 / a["raw_n"], 2),
                             launches_per_image=round(a["n"]), est_ms_per_image=round(a["ms"], 1),
-                            traffic_note=traffic_note,
+                            traffic_note=traffic_note, traffic_source=traffic_source,
                             method="HIP events around each launch, eager replay of the benchmark's plans right after "
                                    "the timed region (the timed region itself replays hipGraphs); weights = the "
                                    "timed region's own pass counts",

@@ -80,6 +80,12 @@ typedef struct LgdGemmDesc {
   int32_t tile;       /* 0 auto; 1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64, 5: 32x128, 6: 128x160, 7: 64x160
                          (register-staged main loop); +16 = same tile, LDS-DMA main loop (K % 64 == 0);
                          25: 256x320, 26: 256x128 (8 waves, LDS-DMA only) */
+  int32_t* cnt;       /* split-K arrival counters (ABI v5), device int32[batches * tiles], ALL ZERO on entry, or NULL.
+                         With counters the split-K combine happens inside the GEMM launch: every workgroup stores its
+                         fp32 partial, publishes it (agent-scope release) and takes a ticket; the last arriver of an
+                         output tile sums the `splits` partials in split order 0,1,2.. (bit-identical to the separate
+                         reduce kernel), applies the epilogue and leaves the counter at zero again.  NULL = second
+                         launch (splitk_reduce_kernel).  One counter buffer may serve every GEMM of a stream. */
 } LgdGemmDesc;
 
 int lgd_gemm_f16(const LgdGemmDesc* desc /* host */, void* stream);
@@ -208,6 +214,15 @@ int lgd_upsample2x_bwd_f16(const void* gy, void* gx, int B, int H, int W, int C,
 int lgd_cfg_ddim_step_f32(const float* eps, const float* x, float* x_out, const float* coef_table,
                           const int32_t* dyn, const float* frozen_ref, const float* mask, float* hist,
                           int B, int C, int HW, void* stream);
+/* The same fused step for LINEAR MULTISTEP samplers — [ext] diffusers DPMSolverMultistepScheduler (dpmsolver++,
+ * order 2, midpoint; models/models.py:46-47 `use_dpm_multistep_scheduler`), whose update is linear in the latents, the
+ * current data prediction x0 and the previous one:
+ *   m = eu + gs*(ec-eu);  x0 = c0 x + c1 m;  x' = A x + B x0 + C x0_prev;  x0_prev <- x0;  blend / hist as above.
+ * coef_table: device fp32 [T][8] = {c0, c1, A, B, C, guidance_scale, 0, 0} (host: scheduler.DPMSolverMultistepScheduler).
+ * x0_prev: fp32 state buffer (B,C,L,L), read only when C != 0. */
+int lgd_cfg_multistep_step_f32(const float* eps, const float* x, float* x_out, float* x0_prev,
+                               const float* coef_table, const int32_t* dyn, const float* frozen_ref,
+                               const float* mask, float* hist, int B, int C, int HW, void* stream);
 /* guidance latent update (pipelines.py:60-69): x -= active[i/per_sample] * coef_table[*step_idx][col] * g.
  * active (device fp32 per image, or NULL = all on) emulates the per-image `while` exit of
  * pipelines.py:30 when several layouts are guided in one batch. */

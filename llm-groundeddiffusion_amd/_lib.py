@@ -38,6 +38,7 @@ class LgdGemmDesc(C.Structure):
         ("c", c_void_p), ("ldc", c_i64),
         ("splits", C.c_int32), ("ws", c_void_p),
         ("tile", C.c_int32),
+        ("cnt", c_void_p),
     ]
 
 
@@ -69,6 +70,7 @@ SIGNATURES = {
     "lgd_scale_f16": [_P, _P, _F, _L, _P],
     "lgd_upsample2x_bwd_f16": [_P, _P, _I, _I, _I, _I, _P],
     "lgd_cfg_ddim_step_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "lgd_cfg_multistep_step_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "lgd_axpy_f32": [_P, _P, _P, _P, _I, _P, _L, _L, _P],
     "lgd_select_row_f32": [_P, _P, _P, _I, _P],
     "lgd_attn_causal_fwd_f16": [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _F, _P],

@@ -111,7 +111,7 @@ __device__ __forceinline__ float4 ld_bias_sum4(const LgdGemmDesc& d, int n) {
 template <int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& ga, f32x4 (&acc)[NI][MI], int m0, int n0,
                                               int wm, int wn, int lane, int batch, int split,
-                                              long c_off, long r_off) {
+                                              long c_off, long r_off, int* lds_flag = nullptr) {
   const LgdGemmDesc& d = ga.d;
   const int m_l = lane & 15;
   const int n_l = (lane >> 4) * 4;
@@ -129,7 +129,45 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& ga, f32x4 (&acc)[N
         *reinterpret_cast<float4*>(ws + (long)m * d.N + n) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
-    return;
+    if (!d.cnt || !lds_flag) return;      // combined by splitk_reduce_kernel (second launch)
+    // ---- in-launch combine ("last arriver reduces"; the hand-off recipe of the CDNA guide, counter form): every
+    // wave drains its partial stores, the workgroup meets, ONE lane publishes with an agent-scope release (the asm
+    // wait restates the wait behind buffer_wbl2 where the compiler cannot drop it) and takes a ticket; the workgroup
+    // that draws splits - 1 acquires (one lane, agent scope: drops this CU's stale L1 lines), re-zeroes the counter and
+    // sums ALL partials — its own included — from memory in split order, so the result is bit-identical to the reduce
+    // kernel and independent of arrival order.  Correct for any placement of a tile's splits over CUs / XCDs.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int32_t* cnt = d.cnt + (long)batch * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *lds_flag = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (*lds_flag != d.splits - 1) return;
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const float* w0 = ga.d.ws + (long)batch * d.splits * (long)d.M * d.N;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + wm * 16 * MI + mi * 16 + m_l;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + wn * 16 * NI + ni * 16 + n_l;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < d.M && n < d.N) {
+          for (int s2 = 0; s2 < d.splits; ++s2) {
+            const float4 t = *reinterpret_cast<const float4*>(w0 + (long)s2 * d.M * d.N + (long)m * d.N + n);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+          }
+        }
+        acc[ni][mi] = v;
+      }
+    }
   }
   const bool geglu = d.epi & LGD_EPI_GEGLU;
   if (geglu) {
@@ -465,7 +503,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs ga) {
     }
   }
 
-  gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off);
+  gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off, reinterpret_cast<int*>(smem));
 }
 
 // 128 B of zeros: the source of every conv-padding / out-of-range segment of the LDS-DMA variant
@@ -669,7 +707,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_dma_kernel(const GemmArgs ga) {
     }
   }
 
-  gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off);
+  gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off, reinterpret_cast<int*>(smem));
 }
 
 // ---- pieces of the pipelined main loop that must not be left to the compiler's own wait insertion --------
@@ -1072,7 +1110,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
           gemm_epilogue_lds<MI, NI, WM, WN, STAGE_B, false, !PERSIST>(ga, acc, m0_, n0_, wm, wn, lane, tid, c_off, r_off, free_stage);
         }
       } else {
-        gemm_epilogue<MI, NI>(ga, acc, m0_, n0_, wm, wn, lane, batch, split, c_off, r_off);
+        gemm_epilogue<MI, NI>(ga, acc, m0_, n0_, wm, wn, lane, batch, split, c_off, r_off, reinterpret_cast<int*>(smem));
       }
     };
     if constexpr (PERSIST) {
@@ -1097,7 +1135,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
     for (int v = blockIdx.x; v < total_tiles; v += gridDim.x) {
       int m0, n0;
       tile_origin(v, m0, n0);
-      gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off);
+      gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off, reinterpret_cast<int*>(smem));
     }
   }
 }
@@ -1287,7 +1325,7 @@ extern "C" int lgd_gemm_f16(const LgdGemmDesc* desc, void* stream) {
       default: return LGD_ERR_ARG;
     }
     if (rc) return rc;
-    if (d.splits > 1) {
+    if (d.splits > 1 && !d.cnt) {
       int n_out = geglu ? d.N / 2 : d.N;
       long total = (long)d.M * (n_out / 4);
       int blocks = (int)((total + 255) / 256);
@@ -1316,7 +1354,7 @@ extern "C" int lgd_gemm_f16(const LgdGemmDesc* desc, void* stream) {
     default: return LGD_ERR_ARG;
   }
   if (rc) return rc;
-  if (d.splits > 1) {
+  if (d.splits > 1 && !d.cnt) {
     int n_out = geglu ? d.N / 2 : d.N;
     long total = (long)d.M * (n_out / 4);
     int blocks = (int)((total + 255) / 256);

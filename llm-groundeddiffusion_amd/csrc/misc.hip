@@ -309,6 +309,42 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(
   }
 }
 
+// Classifier-free guidance + one step of a LINEAR MULTISTEP sampler (DPM-Solver++ 2M and anything else whose update
+// is linear in the latents, the current data prediction and the previous one) + frozen-mask blend + history:
+//     m  = eu + gs (ec - eu)                  model output under CFG
+//     x0 = c0 x + c1 m                        data prediction (epsilon: 1/alpha_t, -sigma_t/alpha_t; v: alpha_t, -sigma_t)
+//     x' = A x + B x0 + C x0_prev             first-order steps have C = 0 (x0_prev is not read)
+//     x0_prev <- x0
+// coef rows: fp32 [T][8] = {c0, c1, A, B, C, guidance_scale, -, -}.
+__global__ __launch_bounds__(256) void cfg_multistep_kernel(
+    const float* __restrict__ eps, const float* __restrict__ x, float* __restrict__ x_out, float* __restrict__ x0_prev,
+    const float* __restrict__ coef_table, const int32_t* __restrict__ dyn, const float* __restrict__ frozen_ref,
+    const float* __restrict__ mask, float* __restrict__ hist, int B, int CHW, int HW) {
+  const int step = dyn[0];
+  const int frozen_steps = dyn[1];
+  const float* c = coef_table + step * 8;
+  const float c0 = c[0], c1 = c[1], A = c[2], Bc = c[3], Cc = c[4], gs = c[5];
+  const long n = (long)B * CHW;
+  const bool blend = frozen_ref && mask && step < frozen_steps;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    const float eu = eps[i], ec = eps[n + i];
+    const float m = eu + gs * (ec - eu);
+    const float xv = x[i];
+    const float x0 = c0 * xv + c1 * m;
+    float xn = A * xv + Bc * x0;
+    if (Cc != 0.f) xn += Cc * x0_prev[i];
+    x0_prev[i] = x0;
+    if (blend) {
+      const int b = (int)(i / CHW);
+      const int p = (int)(i % HW);
+      const float mk = mask[(long)b * HW + p];
+      xn = frozen_ref[(long)(step + 1) * n + i] * mk + xn * (1.f - mk);
+    }
+    x_out[i] = xn;
+    if (hist) hist[(long)(step + 1) * n + i] = xn;
+  }
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ g, float* __restrict__ x,
                                                     const float* __restrict__ coef_table,
                                                     const int32_t* __restrict__ step_idx, int col,
@@ -449,6 +485,17 @@ extern "C" int lgd_cfg_ddim_step_f32(const float* eps, const float* x, float* x_
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   hipLaunchKernelGGL(cfg_ddim_kernel, dim3(ew_blocks((long)B * C * HW)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), eps, x, x_out, coef_table, dyn, frozen_ref,
+                     mask, hist, B, C * HW, HW);
+  return lgd_check_launch();
+}
+
+extern "C" int lgd_cfg_multistep_step_f32(const float* eps, const float* x, float* x_out, float* x0_prev,
+                                          const float* coef_table, const int32_t* dyn, const float* frozen_ref,
+                                          const float* mask, float* hist, int B, int C, int HW, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  if (!eps || !x || !x_out || !x0_prev || !coef_table || !dyn) return LGD_ERR_ARG;
+  hipLaunchKernelGGL(cfg_multistep_kernel, dim3(ew_blocks((long)B * C * HW)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), eps, x, x_out, x0_prev, coef_table, dyn, frozen_ref,
                      mask, hist, B, C * HW, HW);
   return lgd_check_launch();
 }

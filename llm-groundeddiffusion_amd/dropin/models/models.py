@@ -7,7 +7,7 @@ import torch
 
 from lgd_amd import weights as _weights
 from lgd_amd.sampler import LMDSampler
-from lgd_amd.scheduler import DDIMScheduler
+from lgd_amd.scheduler import DDIMScheduler, DPMSolverMultistepScheduler
 from lgd_amd.unet import UNetEngine
 from utils import torch_device  # noqa: F401
 
@@ -25,7 +25,7 @@ class _EasyDict(dict):
 
 
 def build_model_dict(cfg, state_dict, vae=None, tokenizer=None, text_encoder=None, device="cuda",
-                     dtype=torch.float16, scheduler_config=None):
+                     dtype=torch.float16, scheduler_config=None, use_dpm_multistep_scheduler=False):
     """model_dict contract of models/models.py:55: vae, tokenizer, text_encoder, unet, scheduler, dtype.
     scheduler_config: the checkpoint's own scheduler_config.json fields (models/models.py:49 reads them through
     DDIMScheduler.from_pretrained); only what the DDIM eta=0 path uses is honoured, anything else must match."""
@@ -37,9 +37,12 @@ def build_model_dict(cfg, state_dict, vae=None, tokenizer=None, text_encoder=Non
             raise RuntimeError(f"scheduler_config.{k}={sc[k]!r} is not supported on the HIP path (expects {want!r})")
     if "prediction_type" in sc and sc["prediction_type"] != cfg.prediction_type:
         raise RuntimeError("scheduler prediction_type disagrees with the UNet config")
-    sched = DDIMScheduler(num_train_timesteps=sc.get("num_train_timesteps", 1000),
-                          beta_start=sc.get("beta_start", 0.00085), beta_end=sc.get("beta_end", 0.012),
-                          steps_offset=sc.get("steps_offset", 1), prediction_type=cfg.prediction_type)
+    skw = dict(num_train_timesteps=sc.get("num_train_timesteps", 1000), beta_start=sc.get("beta_start", 0.00085),
+               beta_end=sc.get("beta_end", 0.012), prediction_type=cfg.prediction_type)
+    if use_dpm_multistep_scheduler:                       # models/models.py:46-47
+        sched = DPMSolverMultistepScheduler(**skw)
+    else:
+        sched = DDIMScheduler(steps_offset=sc.get("steps_offset", 1), **skw)
     md = _EasyDict(vae=vae, tokenizer=tokenizer, text_encoder=text_encoder, unet=unet, scheduler=sched, dtype=dtype)
     md["sampler"] = LMDSampler(eng, sched, vae=vae)
     return md
@@ -64,8 +67,14 @@ def load_sd(key="runwayml/stable-diffusion-v1-5", use_fp16=False, load_inverse_s
         from transformers import CLIPTextModel, CLIPTokenizer
     except ImportError as e:
         raise RuntimeError("load_sd needs `diffusers` and HF checkpoints; use load_synthetic() offline") from e
-    if use_dpm_multistep_scheduler or scheduler_cls is not None:
-        raise RuntimeError("only the DDIM scheduler is implemented on the HIP path")
+    if scheduler_cls is not None:
+        name = getattr(scheduler_cls, "__name__", str(scheduler_cls))
+        if use_dpm_multistep_scheduler:
+            raise AssertionError("`use_dpm_multistep_scheduler` cannot be used with `scheduler_cls`")     # models.py:51
+        if name == "DPMSolverMultistepScheduler":
+            use_dpm_multistep_scheduler = True
+        elif name != "DDIMScheduler":
+            raise RuntimeError(f"scheduler {name}: the HIP path implements DDIMScheduler and DPMSolverMultistepScheduler")
     hf = HFUNet.from_pretrained(key, subfolder="unet")
     c = hf.config
     heads = c.attention_head_dim if isinstance(c.attention_head_dim, (list, tuple)) else (c.attention_head_dim,) * 4
@@ -89,7 +98,8 @@ def load_sd(key="runwayml/stable-diffusion-v1-5", use_fp16=False, load_inverse_s
         from lgd_amd.vae import HipVAEDecoder
         dec = HipVAEDecoder.from_state_dict(vae.state_dict(), torch_device)      # models/models.py:41 on the HIP kernels
     return build_model_dict(cfg, {k: v.float() for k, v in hf.state_dict().items()}, vae=dec, tokenizer=tok,
-                            text_encoder=te, scheduler_config=sched_cfg)
+                            text_encoder=te, scheduler_config=sched_cfg,
+                            use_dpm_multistep_scheduler=use_dpm_multistep_scheduler)
 
 
 def encode_prompts(tokenizer, text_encoder, prompts, negative_prompt="", return_full_only=False,

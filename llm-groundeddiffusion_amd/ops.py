@@ -39,6 +39,20 @@ def set_option(name: str, value: int):
 # ---------------------------------------------------------------------------------------------
 WORKSPACE = None          # shared split-K workspace (fp32 tensor), registered by the engine
 WS_FLOATS = 1 << 26
+COUNTERS = {}             # device -> int32 zeros: split-K arrival counters (left at zero by every launch)
+N_COUNTERS = 1 << 16
+import os as _os
+# In-launch split-K combine ("last arriver reduces", LgdGemmDesc.cnt): implemented, bit-identical, and MEASURED SLOWER on
+# MI355X than the second launch it replaces — every workgroup's agent-scope release is a write-back of its XCD's L2
+# (M = 256, K = 11520, 12 splits: 57 us vs 26 us; default bench 1.21 vs 1.28 images/s) — so it stays off.
+SPLITK_IN_LAUNCH = _os.environ.get("LGD_SPLITK_IN_LAUNCH", "0") == "1"
+
+
+def splitk_counters(device):
+    dev = torch.device(device)
+    if dev not in COUNTERS:
+        COUNTERS[dev] = torch.zeros(N_COUNTERS, device=dev, dtype=torch.int32)
+    return COUNTERS[dev]
 
 
 def choose_splits(M, N, K, batches=1):
@@ -97,6 +111,11 @@ def gemm_desc(a0, w, c, M, N, K, *, a1=None, lda0=None, lda1=0, c0=None, c1=0, t
         ws = WORKSPACE
     d.splits, d.ws = splits, ptr(ws)
     d.tile = tile
+    d.cnt = 0
+    if splits > 1 and SPLITK_IN_LAUNCH and torch.is_tensor(c) and c.is_cuda:
+        # the smallest tile of the library is 32 rows x 64 columns: an upper bound of the launch's output tiles
+        if nb_o * nb_i * ((M + 31) // 32) * ((N + 63) // 64) <= N_COUNTERS:
+            d.cnt = splitk_counters(c.device).data_ptr()
     return d
 
 
@@ -502,6 +521,14 @@ def cfg_ddim_step(eps, x, x_out, coef_table, dyn, *, frozen_ref=None, mask=None,
     """dyn: device int32[2] = {step, frozen_steps}."""
     B, C_, L, _ = x.shape
     _call("lgd_cfg_ddim_step_f32", _p(eps), _p(x), _p(x_out), _p(coef_table), _p(dyn),
+          _p(frozen_ref), _p(mask), _p(hist), B, C_, L * L, _stream())
+    return x_out
+
+
+def cfg_multistep_step(eps, x, x_out, x0_prev, coef_table, dyn, *, frozen_ref=None, mask=None, hist=None):
+    """CFG + one linear multistep update (DPM-Solver++ 2M); coef_table fp32 [T][8], see lgd_hip.h."""
+    B, C_, L, _ = x.shape
+    _call("lgd_cfg_multistep_step_f32", _p(eps), _p(x), _p(x_out), _p(x0_prev), _p(coef_table), _p(dyn),
           _p(frozen_ref), _p(mask), _p(hist), B, C_, L * L, _stream())
     return x_out
 

@@ -94,6 +94,8 @@ class _State:
         self.mask = torch.zeros((nb, L * L), device=dev, dtype=F32)
         self.active = torch.zeros(nb, device=dev, dtype=F32)      # per-image guidance on/off
         self.ctab = torch.zeros((T, 4), device=dev, dtype=F32)
+        self.mtab = torch.zeros((T, 8), device=dev, dtype=F32)      # linear-multistep schedulers (DPM-Solver++)
+        self.x0_prev = torch.zeros((nb, C, L, L), device=dev, dtype=F32)
         self.gtab = torch.zeros((T, 4), device=dev, dtype=F32)
         self.graphs = {}
 
@@ -351,7 +353,14 @@ class LMDSampler:
         if fast_after_steps is not None:
             ts = sch.fast_schedule(ts, int(fast_after_steps), int(fast_rate))
         Tr = len(ts)                                                          # steps actually run
-        st.ctab[:Tr].copy_(sch.coef_table(guidance_scale, dev, timesteps=ts, step_ratios=sch.dynamic_step_sizes(ts)))
+        multistep = bool(getattr(sch, "multistep", False))
+        if multistep:
+            if fast_after_steps is not None:
+                raise RuntimeError("the fast schedule (utils/schedule.py) re-derives DDIM step sizes; not defined for the "
+                                   "multistep scheduler")
+            st.mtab[:Tr].copy_(sch.multistep_table(guidance_scale, dev, timesteps=ts))
+        else:
+            st.ctab[:Tr].copy_(sch.coef_table(guidance_scale, dev, timesteps=ts, step_ratios=sch.dynamic_step_sizes(ts)))
         st.gtab[:Tr].copy_(sch.guidance_step_table(dev, timesteps=ts))
         n_ground = int(gligen_scheduled_sampling_beta * Tr) if use_gligen else 0   # pipelines.py:405
         save_keys = [tuple(k) for k in saved_cross_attn_keys]
@@ -394,9 +403,13 @@ class LMDSampler:
                 plan.latents_in[:nb].copy_(st.lat)                           # torch.cat([latents]*2)
                 plan.latents_in[nb:].copy_(st.lat)
                 plan.forward()
-                ops.cfg_ddim_step(plan.eps_out, st.lat, st.lat, st.ctab, eng.dyn, frozen_ref=st.frozen_ref,
-                                  mask=st.mask, hist=st.hist)
-            runners_main[f] = (main_fn, ("main", f, tuple(plan_keys)))
+                if multistep:
+                    ops.cfg_multistep_step(plan.eps_out, st.lat, st.lat, st.x0_prev, st.mtab, eng.dyn,
+                                           frozen_ref=st.frozen_ref, mask=st.mask, hist=st.hist)
+                else:
+                    ops.cfg_ddim_step(plan.eps_out, st.lat, st.lat, st.ctab, eng.dyn, frozen_ref=st.frozen_ref,
+                                      mask=st.mask, hist=st.hist)
+            runners_main[f] = (main_fn, ("main", f, tuple(plan_keys), multistep))
         if guided:
             for f in {fuser_at(i) for i in range(min(max_guided, Tr))}:
                 runners_guide[f] = self._guide_runners(st, nb, L, f, gkeys)

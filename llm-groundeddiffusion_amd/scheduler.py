@@ -106,3 +106,78 @@ class DDIMScheduler:
             nxt = int(timesteps[i + 1]) if i + 1 < len(timesteps) else -1
             out.append(n_train // (n_train // (int(t) - nxt)))
         return out
+
+
+
+class DPMSolverMultistepScheduler(DDIMScheduler):
+    """[ext] diffusers 0.18.0 DPMSolverMultistepScheduler with its defaults (algorithm_type "dpmsolver++",
+    solver_order 2, solver_type "midpoint", lower_order_final, no thresholding) — what `load_sd(...,
+    use_dpm_multistep_scheduler=True)` selects (models/models.py:46-47).  Restated from the published algorithm
+    (DPM-Solver++, Lu et al. 2022, eq. 2M) — diffusers is absent from the sandbox: parity unpinned at this boundary;
+    the first-order case is pinned against DDIM, which it equals identically (tests/test_schedule.py).
+
+    The update is linear in (x, x0, x0_prev), so the device side is the fused `lgd_cfg_multistep_step_f32` kernel
+    reading one coefficient row per step (`multistep_table`); nothing about the captured hipGraphs changes.
+    Backward guidance scales its latent update by sqrt(1 - alpha_bar_t) as with DDIM: the 0.18.0 class has no
+    `sigmas` attribute unless Karras sigmas are switched on (pipelines.py:60-69)."""
+    multistep = True
+
+    def __init__(self, *a, solver_order=2, lower_order_final=True, **k):
+        super().__init__(*a, **k)
+        self.config.update(solver_order=solver_order, lower_order_final=lower_order_final,
+                           algorithm_type="dpmsolver++", solver_type="midpoint")
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        self.num_inference_steps = num_inference_steps
+        n = self.config.num_train_timesteps
+        ts = np.linspace(0, n - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
+        self.timesteps = torch.from_numpy(ts)
+
+    def _als(self, t):
+        a = float(self.alphas_cumprod[int(t)])
+        alpha, sigma = a ** 0.5, (1.0 - a) ** 0.5
+        return alpha, sigma, float(np.log(alpha) - np.log(sigma))
+
+    def multistep_rows(self, timesteps=None):
+        """Per step: (c0, c1, A, B, C) of  x0 = c0 x + c1 m ;  x' = A x + B x0 + C x0_prev."""
+        ts = [int(t) for t in (self.timesteps if timesteps is None else timesteps)]
+        n = len(ts)
+        rows = []
+        for i, t in enumerate(ts):
+            t_next = ts[i + 1] if i + 1 < n else 0                          # the last step lands on timestep 0
+            a_t, s_t, l_t = self._als(t)
+            a_n, s_n, l_n = self._als(t_next)
+            h = l_n - l_t
+            if self.config.prediction_type == "v_prediction":
+                c0, c1 = a_t, -s_t
+            else:
+                c0, c1 = 1.0 / a_t, -s_t / a_t
+            first = (i == 0 or self.config.solver_order == 1 or
+                     (i == n - 1 and self.config.lower_order_final and n < 15))
+            A = s_n / s_t
+            e = float(np.expm1(-h))                                          # exp(-h) - 1
+            if first:
+                B, C = -a_n * e, 0.0
+            else:
+                _, _, l_p = self._als(ts[i - 1])
+                r = (l_t - l_p) / h
+                B, C = -a_n * e * (1.0 + 0.5 / r), 0.5 * a_n * e / r
+            rows.append((c0, c1, A, B, C))
+        return rows
+
+    def multistep_table(self, guidance_scale: float, device, timesteps=None) -> torch.Tensor:
+        rows = [[c0, c1, A, B, C, guidance_scale, 0.0, 0.0] for c0, c1, A, B, C in self.multistep_rows(timesteps)]
+        return torch.tensor(rows, dtype=torch.float32, device=device)
+
+    def coef_table(self, guidance_scale, device, timesteps=None, step_ratios=None):
+        raise RuntimeError("DPMSolverMultistepScheduler drives lgd_cfg_multistep_step_f32 (multistep_table)")
+
+    def prev_timestep(self, t, index=None):
+        raise RuntimeError("multistep scheduler: the next timestep is the next entry of `timesteps`")
+
+    def step_host(self, model_output, index, sample, x0_prev=None):
+        """Torch form of one step (tests): returns (prev_sample, x0)."""
+        c0, c1, A, B, C = self.multistep_rows()[index]
+        x0 = c0 * sample + c1 * model_output
+        out = A * sample + B * x0 + (C * x0_prev if C != 0.0 else 0.0)
+        return out, x0

@@ -299,9 +299,13 @@ class Plan:
             gq, gk, gv = g, g[:, C:], g[:, 2 * C:]
             pad = Sk > S
 
+            # query-gradient rows of the 30 grounding tokens stay zero (they have no queries): only that slice is
+            # cleared — the backward kernels overwrite every other element of the fused [q | k | v] gradient
+            gq_tail = g.view(B, Sk, 3 * C)[:, S:, :C] if pad else None
+
             def run():
                 if pad:
-                    g.zero_()      # query-gradient rows of the 30 grounding tokens stay zero
+                    gq_tail.zero_()
                 ops.attn_bwd(qt, kt, vt, o.t, o.g, lse, delta, gq, gk, gv, B, heads, S, Sk, d, scale,
                              q_view=view, k_view=view, v_view=view, gq_view=view, gk_view=view, gv_view=view)
             return run

@@ -410,6 +410,54 @@ def test_fast_schedule_loop_vs_reference_golden(dev):
     gate("fast schedule last map rel-L2", em, 2.4e-2)
 
 
+def test_dpm_solver_multistep_loop_vs_oracle_unet_host_loop(dev):
+    """`use_dpm_multistep_scheduler` (models/models.py:46-47): a 6-step CFG loop with the fused multistep kernel
+    (incl. the frozen-mask blend and the history) vs a host loop = oracle UNet (fp32) + the scheduler's torch form;
+    and the fused kernel alone vs its torch statement on random data (bit-level formula check)."""
+    import restate as R
+    from lgd_amd import ops
+    from lgd_amd.scheduler import DPMSolverMultistepScheduler
+    g = np.load(os.path.join(GOLD, "loops_tiny.npz"))
+    cfg = weights.CONFIGS["tiny"]
+    eng = engine("tiny", dev)
+    sd = weights.synth_state_dict(cfg, 0)
+    cd = dict(block_out_channels=cfg.block_out_channels, layers_per_block=cfg.layers_per_block,
+              attention_head_dim=cfg.attention_head_dim, norm_num_groups=cfg.norm_num_groups, norm_eps=cfg.norm_eps,
+              gligen_positive_len=cfg.gligen_positive_len)
+    ehs = torch.from_numpy(g["ehs"])
+    T = 6
+    sch = DPMSolverMultistepScheduler()
+    sm = LMDSampler(eng, sch)
+    hist_in = torch.randn((T + 1, 1, 4, L, L), generator=torch.Generator().manual_seed(2))
+    fm = torch.from_numpy(g["frozen_mask"])
+    out = sm.denoise(hist_in, ehs, T, frozen_steps=2, frozen_mask=fm)
+    torch.cuda.synchronize()
+    sch.set_timesteps(T)
+    x, x0p = hist_in[0].clone(), None
+    mask = fm.float().clamp(0, 1)
+    with torch.no_grad():
+        for i, t in enumerate(sch.timesteps.tolist()):
+            eps = R.unet_forward(sd, cd, torch.cat([x, x]), t, ehs)
+            m = eps[:1] + 7.5 * (eps[1:] - eps[:1])
+            x, x0p = sch.step_host(m, i, x, x0p)
+            if i < 2:
+                x = hist_in[i + 1] * mask + x * (1 - mask)
+            gate(f"DPM-Solver++ loop, latents after step {i}", relerr(out["latents_all"][i + 1], x), 1.5e-2)
+    # the kernel's formula
+    n = (2, 4, 8, 8)
+    gen = torch.Generator().manual_seed(3)
+    eps2 = torch.randn((4, 4, 8, 8), generator=gen).to(dev)
+    xx, prev = torch.randn(n, generator=gen).to(dev), torch.randn(n, generator=gen).to(dev)
+    tab = sch.multistep_table(7.5, dev)
+    dyn = torch.tensor([3, 0, 0, 0], dtype=torch.int32, device=dev)
+    xo, pv = torch.empty_like(xx), prev.clone()
+    ops.cfg_multistep_step(eps2, xx, xo, pv, tab, dyn)
+    c0, c1, A, B, C = sch.multistep_rows()[3]
+    m = eps2[:2] + 7.5 * (eps2[2:] - eps2[:2])
+    x0 = c0 * xx + c1 * m
+    assert relerr(pv, x0) < 1e-6 and relerr(xo, A * xx + B * x0 + C * prev) < 1e-6
+
+
 def test_layout_without_boxes(dev):
     """25 % of the cached lmd layouts have no boxes: no per-box stage, no guidance, the
     overall generation starts from the background noise and still runs GLIGEN with an empty (all-masked)
