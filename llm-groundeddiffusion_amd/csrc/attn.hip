@@ -275,6 +275,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   }
 }
 
+// max over the four lanes {q, q+16, q+32, q+48} that share a query in the 16x16 accumulator layout, delivered to all
+// four, without LDS (the ds_bpermute pair this replaces cost two LDS round trips per query tile and key tile):
+// v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of the other, v_permlane32_swap
+// the upper half of one with the lower half of the other.  Inline asm for the reason given at half_pair_max.
+__device__ __forceinline__ float quad_row_max(float mx) {
+  float a = mx, b = mx;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  a = fmaxf(a, b);
+  b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Self-attention forward (no map capture): the kernel the UNet spends most of its attention time
 // in (S = 4096, d = 40 at the 64x64 level).  Same transposed-product layout as attn_fwd_kernel, but
@@ -297,6 +310,11 @@ __global__ __launch_bounds__(64 * NW) void attn_self_kernel(const AttnArgs a) {
   constexpr int K_IT = (KV_T * KSEG + NT - 1) / NT;
   constexpr int V_ITEMS = (KV_T / 2) * KSEG;
   constexpr int V_IT = (V_ITEMS + NT - 1) / NT;
+  // V^T rows: 80 halfs = ten 16-byte slots (like the K rows): with that stride the four hardware lane groups of a
+  // ds_read_b128 fragment read hit 16 distinct slots.  Inside each 32-key block the keys are stored in the order the
+  // P^T operand wants them (position 8 g + 4 a + j holds key 16 a + 4 g + j), so a fragment is ONE 16-byte read
+  // (it was a ds_read2_b64: half the LDS rate, 2-way conflicted under its 32-bank rule — 30 % of the LDS cycles)
+  constexpr int VT_LD = KV_T + 16;
   constexpr int STAGE = KV_T * K_LD + NDT * 16 * VT_LD;
 
   __shared__ __attribute__((aligned(16))) half_t smem[2 * STAGE];
@@ -372,7 +390,9 @@ __global__ __launch_bounds__(64 * NW) void attn_self_kernel(const AttnArgs a) {
     const int pair = idx & 31, seg = idx >> 5;
     v_use[i] = (idx < V_ITEMS) && (seg * 8 < d);
     v_row[i] = pair * 2;
-    v_dst[i] = KV_T * K_LD + (seg * 8) * VT_LD + pair * 2;
+    const int key = pair * 2;
+    const int pos = (key & ~31) | (((key >> 2) & 3) << 3) | (((key >> 4) & 1) << 2) | (key & 3);
+    v_dst[i] = KV_T * K_LD + (seg * 8) * VT_LD + pos;
     vp[i] = Vb + (long)(pair * 2) * a.ldv + seg * 8;
   }
 
@@ -472,8 +492,7 @@ __global__ __launch_bounds__(64 * NW) void attn_self_kernel(const AttnArgs a) {
       mx = fmaxf(fmaxf(mx, s[qt][2][3]), s[qt][3][0]);
       mx = fmaxf(fmaxf(mx, s[qt][3][1]), s[qt][3][2]);
       mx = fmaxf(mx, s[qt][3][3]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = quad_row_max(mx);
       if (ONES) {
         mxs[qt] = mx;  // already relative to m_ref
         raise = raise || (mx > 8.f) || (t == 0);
@@ -541,10 +560,7 @@ __global__ __launch_bounds__(64 * NW) void attn_self_kernel(const AttnArgs a) {
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        const half_t* vrow = Vt + (dt * 16 + c16) * VT_LD + c * 32 + g * 4;
-        half4_t lo = *reinterpret_cast<const half4_t*>(vrow);
-        half4_t hi = *reinterpret_cast<const half4_t*>(vrow + 16);
-        half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const half8_t vf = *reinterpret_cast<const half8_t*>(Vt + (dt * 16 + c16) * VT_LD + c * 32 + g * 8);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
           oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][c], oacc[qt][dt], 0, 0, 0);
