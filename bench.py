@@ -157,13 +157,16 @@ def respawn(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="batch4", choices=["batch4", "lmd_v0.1", "backward_guidance"])
     ap.add_argument("--layouts", type=int, default=4, help="batch4: cached layouts per rank per step")
     ap.add_argument("--prompts", type=int, default=100, help="lmd_v0.1: prompts of the cache (whole job)")
     ap.add_argument("--config", default=None, help="default: sd14_gligen (sd21 for --workload backward_guidance)")
     ap.add_argument("--num-inference-steps", type=int, default=50)
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="concurrent denoising pipelines per GPU, each on its own HIP stream with its own engine state "
+                         "(lgd_amd/lanes.py): steps (batch4) or halves of the prompt set (lmd_v0.1) run side by side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -245,14 +248,12 @@ def main():
     # rank 0 materialises the weights; everyone else receives the two arenas over RCCL/xGMI
     eng = UNetEngine(cfg, dev, weights.synth_state_dict(cfg, 0) if rank == 0 else None)
     bcast_s = ldist.broadcast_weights(eng.w, src=0) if world > 1 else 0.0
-    vae = None if args.no_decode else make_hip_vae(dev)
-    sm = LMDSampler(eng, DDIMScheduler(prediction_type=cfg.prediction_type), vae=vae)
-
+    from lgd_amd.lanes import LanePool, make_lanes
     side = 8 * cfg.sample_size
-    refiner = None
-    if args.sam:
-        if args.no_decode or args.workload == "backward_guidance":
-            raise SystemExit("--sam needs the decoded single-object images of LMD+ (no --no-decode, not backward_guidance)")
+    if args.sam and (args.no_decode or args.workload == "backward_guidance"):
+        raise SystemExit("--sam needs the decoded single-object images of LMD+ (no --no-decode, not backward_guidance)")
+
+    def make_refiner():
         import transformers
         from lgd_amd.sam_refine import SamRefiner, wrap_sam
         torch.manual_seed(0)
@@ -261,38 +262,56 @@ def main():
             for name, prm in hf_sam.named_parameters():                   # HF zero-initialises the position tables
                 if "pos" in name:
                     prm.normal_(0.0, 0.02)
-        refiner = SamRefiner(wrap_sam(hf_sam, "device", device=dev), height=side, width=side)
-        del hf_sam
+        return SamRefiner(wrap_sam(hf_sam, "device", device=dev), height=side, width=side)
 
-    def one_step():
-        if not lays:
+    def make_sampler(e):
+        return LMDSampler(e, DDIMScheduler(prediction_type=cfg.prediction_type),
+                          vae=None if args.no_decode else make_hip_vae(dev))
+
+    # lanes: independent pipelines on their own HIP streams sharing one copy of the weights; with one lane this is
+    # the plain sequential loop on a side stream
+    lanes = make_lanes(eng, max(1, args.lanes), make_sampler)
+    for ln in lanes:
+        ln.extras["refiner"] = make_refiner() if args.sam else None
+    sm = lanes[0].sampler
+    lane_pool = LanePool(lanes, device=dev)
+
+    def one_step(lane, sub, n_steps=T, **kw):
+        if not sub:
             return []
         if args.workload == "backward_guidance":       # generation/backward_guidance.py:46-49 defaults
-            return backward_guidance_generate_batch(sm, lays, num_inference_steps=T, height=side, width=side,
-                                                    decode=not args.no_decode)
-        return lmd_plus_generate_batch(sm, lays, num_inference_steps=T, decode=not args.no_decode, mask_refiner=refiner)
+            return backward_guidance_generate_batch(lane.sampler, sub, num_inference_steps=n_steps, height=side,
+                                                    width=side, decode=not args.no_decode)
+        return lmd_plus_generate_batch(lane.sampler, sub, num_inference_steps=n_steps, decode=not args.no_decode,
+                                       mask_refiner=lane.extras["refiner"], **kw)
+
+    # jobs of one step: the whole batch (batch4 / backward_guidance: successive steps overlap across lanes) or, for
+    # the prompt-set workload, one cost-balanced share of this rank's layouts per lane
+    if args.workload == "lmd_v0.1" and len(lanes) > 1:
+        shares = partition_by_cost([layout_cost(l.n_boxes, T) for l in lays], len(lanes))
+        step_jobs = [[lays[j] for j in sh] for sh in shares]
+    else:
+        step_jobs = [lays]
 
     # launch plans, GEMM kernel attributes and captured hipGraphs of every batch bucket this rank will use are built
-    # BEFORE the timed barrier even with --warmup 0: a 2-step pass over the same layouts has the same batch
-    # composition, and the sampler's device state (hence its graphs) does not depend on the step count
+    # BEFORE the timed barrier even with --warmup 0, lane by lane: a 2-step pass over the same layouts has the same
+    # batch composition, and the sampler's device state (hence its graphs) does not depend on the step count
     t_pre = time.perf_counter()
-    if lays:
-        if args.workload == "backward_guidance":
-            backward_guidance_generate_batch(sm, lays, num_inference_steps=2, height=side, width=side, decode=not args.no_decode)
-        else:
-            lmd_plus_generate_batch(sm, lays, num_inference_steps=2, decode=not args.no_decode, mask_refiner=refiner,
-                                    overall_max_index_step=2, frozen_step_ratio=0.5)
+    pre_kw = {} if args.workload == "backward_guidance" else dict(overall_max_index_step=2, frozen_step_ratio=0.5)
+    for k in range(len(lanes)):
+        subs = step_jobs if len(step_jobs) == 1 else [step_jobs[k]]
+        lane_pool.map(lambda lane, sub: one_step(lane, sub, 2, **pre_kw), subs, pin=[k] * len(subs))
     torch.cuda.synchronize()
     prebuild_s = time.perf_counter() - t_pre
-    for _ in range(args.warmup):
-        one_step()
-    sm.pass_counts.clear()
+    if args.warmup:
+        lane_pool.map(one_step, step_jobs * args.warmup)
+    for ln in lanes:
+        ln.sampler.pass_counts.clear()
     ldist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     it_on = it_all = 0
-    for _ in range(args.steps):
-        outs = one_step()
+    for outs in lane_pool.map(one_step, step_jobs * args.steps):
         it_all += sum(o["guidance_iters"] for o in outs)
         it_on += sum(o["guidance_iters_fuser_on"] for o in outs)
     torch.cuda.synchronize()
@@ -303,6 +322,11 @@ def main():
     tot_on, tot_all = ldist.sum_over_ranks(float(it_on)), ldist.sum_over_ranks(float(it_all))
     tot_boxes = ldist.sum_over_ranks(float(my_boxes))
     n_images = args.steps * n_total
+    lane_pool.close()
+    pass_counts = {}
+    for ln in lanes:
+        for k_, v_ in ln.sampler.pass_counts.items():
+            pass_counts[k_] = pass_counts.get(k_, 0) + v_
     ldist.shutdown()            # all ranks together, right after the last collective; the rest is rank-0 local
     if rank != 0:
         return
@@ -313,8 +337,8 @@ def main():
     # launched eagerly on the same stream with HIP events around every GEMM/attention launch, and the
     # per-pass times are weighted by how often the timed region actually ran each pass (LMDSampler.pass_counts).
     roofline = None
-    if not args.no_roofline and sm.pass_counts:
-        counts = dict(sm.pass_counts)
+    if not args.no_roofline and pass_counts:
+        counts = pass_counts
         my_images = max(args.steps * len(lays), 1)
         agg, tag_agg = {}, {}
         reps = 2
@@ -403,6 +427,7 @@ def main():
                            guidance_iters_per_image=round(iters_on + iters_off, 2),
                            guidance_iters_fuser_on=round(iters_on, 2),
                            algorithmic_tflop_per_image=round(tf, 3) if tf else None,
+                           lanes_per_gpu=len(lanes),
                            weight_broadcast_s=round(bcast_s, 3), prebuild_s=round(prebuild_s, 2),
                            per_rank_busy_s=[round(b, 3) for b in per_rank_busy],
                            per_rank_idle_s=[round(max(dt - b, 0.0), 3) for b in per_rank_busy]),

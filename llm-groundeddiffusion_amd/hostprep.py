@@ -4,6 +4,8 @@ alignment shifts.  Tiny CPU tensors; the arithmetic follows the reference exactl
 box rounding must reproduce (utils/utils.py, utils/latents.py of the reference — cited per function).
 Everything returns CPU tensors; callers move them where they need them.
 """
+import threading
+
 import numpy as np
 import torch
 
@@ -158,9 +160,15 @@ def shift_tensor(tensor, x_offset, y_offset, base_w=8, base_h=8, offset_normaliz
 # -------------------------------------------------------------------------------------------------
 # latents (utils/latents.py of the reference)
 # -------------------------------------------------------------------------------------------------
+# torch.manual_seed() re-seeds the PROCESS-WIDE default generator (the reference's own idiom, latents.py:7-18): the
+# seed + draw pair must not interleave with another host thread's (lanes.LanePool)
+RNG_LOCK = threading.Lock()
+
+
 def seeded_noise(seed, in_channels, h, w, dtype=torch.float32):
     """latents.py:7-18: CPU generator; fp32 first (directly sampling fp16 gives different noise)."""
-    return torch.randn((1, in_channels, h, w), generator=torch.manual_seed(seed), dtype=dtype)
+    with RNG_LOCK:
+        return torch.randn((1, in_channels, h, w), generator=torch.manual_seed(seed), dtype=dtype)
 
 
 def input_latents_list(bg_seed, fg_seed_start, so_boxes, fg_blending_ratio, in_channels=4, H=64, W=64,

@@ -37,8 +37,22 @@ def set_option(name: str, value: int):
 # ---------------------------------------------------------------------------------------------
 # GEMM / conv
 # ---------------------------------------------------------------------------------------------
-WORKSPACE = None          # shared split-K workspace (fp32 tensor), registered by the engine
+import threading as _threading
+_TLS = _threading.local()   # split-K workspace of ad-hoc calls: one per host thread (= one per HIP stream lane, lanes.py)
 WS_FLOATS = 1 << 26
+
+
+def workspace(device) -> torch.Tensor:
+    """fp32 split-K scratch for calls that bring none.  Launches of ONE host thread run back to back on its current
+    stream and may share it; two threads driving two streams (lanes.LanePool) must not, hence thread-local.  Engines
+    own their own (UNetEngine.workspace): their descriptors are baked into plans and hipGraphs."""
+    dev = torch.device(device)
+    ws = getattr(_TLS, "ws", None)
+    if ws is None or ws.device != dev:
+        ws = _TLS.ws = torch.empty(WS_FLOATS, device=dev, dtype=F32)
+    return ws
+
+
 COUNTERS = {}             # device -> int32 zeros: split-K arrival counters (left at zero by every launch)
 N_COUNTERS = 1 << 16
 import os as _os
@@ -102,13 +116,10 @@ def gemm_desc(a0, w, c, M, N, K, *, a1=None, lda0=None, lda1=0, c0=None, c1=0, t
         tile = ent["tile"] if (ent and ent["splits"] == splits) else choose_tile(M, N, nb_o * nb_i * max(splits, 1), bool(epi & EPI_GEGLU), K,
                                                                              pipe_ok=(K % 64 == 0 and d.c0 % 64 == 0 and d.c1 % 64 == 0))
     if splits > 1 and ws is None:
-        global WORKSPACE
         need = splits * M * N * nb_o * nb_i
-        if WORKSPACE is None or WORKSPACE.device != (c.device if torch.is_tensor(c) else WORKSPACE.device):
-            WORKSPACE = torch.empty(WS_FLOATS, device=c.device if torch.is_tensor(c) else "cuda", dtype=F32)
-        if need > WORKSPACE.numel():
+        ws = workspace(c.device if torch.is_tensor(c) else "cuda")
+        if need > ws.numel():
             raise RuntimeError(f"split-K workspace too small for {splits}x{M}x{N}")
-        ws = WORKSPACE
     d.splits, d.ws = splits, ptr(ws)
     d.tile = tile
     d.cnt = 0

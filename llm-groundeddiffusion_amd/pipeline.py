@@ -84,7 +84,7 @@ class CachedLayout:
 
 
 from .hostprep import (align_with_bboxes, compose as compose_latents, get_centered_box,
-                       input_latents_list as _input_latents_list, proportion_to_mask, shift_tensor)
+                       input_latents_list as _input_latents_list, proportion_to_mask, seeded_noise, shift_tensor)
 
 
 def get_input_latents_list(bg_seed, fg_seed_start, so_boxes, fg_blending_ratio, in_channels=4, H=64, W=64):
@@ -369,7 +369,7 @@ def backward_guidance_generate_batch(sampler: LMDSampler, lays: List[CachedLayou
     keys = [tuple(k) for k in (guidance_attn_keys or DEFAULT_GUIDANCE_ATTN_KEYS)]
     jobs = []
     for lay in lays:
-        lat = torch.randn((1, C, L, L), generator=torch.manual_seed(lay.bg_seed), dtype=F32)
+        lat = seeded_noise(lay.bg_seed, C, L, L)
         overall_bboxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
         guid = None
         if overall_bboxes:

@@ -15,10 +15,13 @@ Per step (all on one HIP stream, no host round trip except the reference's own `
 """
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import threading
+
 import torch
 
 from . import ops
 from .energy import EnergyTables
+from .lanes import GATE
 from .scheduler import DDIMScheduler
 from .unet import N_OBJ_TOKENS, UNetEngine
 
@@ -69,16 +72,20 @@ class HipGraph:
     frozen-step count, latents, maps) lives in device memory at fixed addresses."""
 
     def __init__(self, fn, warmup: int = 1):
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                fn()                       # also triggers one-time hipFuncSetAttribute calls
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            fn()
+        # exclusive among the host threads of a lanes.LanePool: other lanes park at their next step boundary
+        with GATE.exclusive():
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    fn()                       # also triggers one-time hipFuncSetAttribute calls
+            cur.wait_stream(side)
+            cur.synchronize()
+            side.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                fn()
 
     def __call__(self):
         self.graph.replay()
@@ -222,6 +229,7 @@ class LMDSampler:
         energy.bind(plan_g.maps, plan_g.gmaps)
         it = 0
         while True:
+            GATE.checkpoint()
             act = [gs is not None and index < gs.max_index_step and it < gs.iters_at(index)
                    and gs.loss / gs.loss_scale > gs.loss_threshold for gs in states]
             if not any(act):
@@ -439,6 +447,7 @@ class LMDSampler:
                                  device=dev, dtype=F32) for k in save_keys} for j in jobs]
 
         for index in range(first_step, last_step):
+            GATE.checkpoint()                                            # lanes.py: another lane may be waiting to capture
             eng.set_step(index)
             fuser_on = fuser_at(index)
             if guided and index < max_guided:

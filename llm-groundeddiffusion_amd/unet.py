@@ -521,13 +521,22 @@ class UNetEngine:
     MAX_PLANS = 48               # LRU bound on cached launch plans (their buffers alias one arena anyway)
 
     def __init__(self, cfg: UNetConfig, device="cuda", state_dict: Optional[Dict[str, torch.Tensor]] = None,
-                 text_len: int = 77, max_text_batch: int = 32):
+                 text_len: int = 77, max_text_batch: int = 32, weights: Optional[WeightStore] = None):
+        """weights: the WeightStore of another engine of the same configuration on the same device — the two
+        engines then read ONE copy of the parameters (read-only after load) while everything a run writes (time /
+        text / GLIGEN tables, activation arena, split-K scratch, plans, graphs) stays per engine, so they can run
+        concurrently on two HIP streams (lanes.LanePool)."""
         self.cfg = cfg
         self.device = torch.device(device)
         self.blocks = unet_blocks(cfg)
-        self.w = WeightStore(cfg, self.device)
-        if state_dict is not None:
-            self.w.load_state_dict(state_dict)
+        if weights is not None:
+            if weights.cfg != cfg or torch.device(weights.device) != self.device or state_dict is not None:
+                raise ValueError("shared weights must come from an engine of the same configuration and device")
+            self.w = weights
+        else:
+            self.w = WeightStore(cfg, self.device)
+            if state_dict is not None:
+                self.w.load_state_dict(state_dict)
         self.text_len = text_len
         self.max_text_batch = max_text_batch
         self.temb_cur = torch.zeros(self.w.temb_total, device=self.device, dtype=F32)
@@ -577,10 +586,11 @@ class UNetEngine:
 
     # ---- shared scratch ---------------------------------------------------------------------
     def workspace(self, n_floats: int = 0) -> torch.Tensor:
-        """One split-K workspace shared by all ops (they run back-to-back on one stream)."""
-        if ops.WORKSPACE is None or ops.WORKSPACE.device != self.device:
-            ops.WORKSPACE = torch.empty(ops.WS_FLOATS, device=self.device, dtype=F32)
-        return ops.WORKSPACE
+        """One split-K workspace shared by all ops of THIS engine (they run back-to-back on one stream; another
+        engine on another stream has its own)."""
+        if self._ws is None:
+            self._ws = torch.empty(ops.WS_FLOATS, device=self.device, dtype=F32)
+        return self._ws
 
     def fuser_cat(self, prefix: str, B: int, S: int, text_off: int) -> torch.Tensor:
         key = (prefix, B, text_off)
