@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--prompts", type=int, default=100, help="lmd_v0.1: prompts of the cache (whole job)")
     ap.add_argument("--config", default=None, help="default: sd14_gligen (sd21 for --workload backward_guidance)")
     ap.add_argument("--num-inference-steps", type=int, default=50)
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=4,
                     help="concurrent denoising pipelines per GPU, each on its own HIP stream with its own engine state "
                          "(lgd_amd/lanes.py): steps (batch4) or halves of the prompt set (lmd_v0.1) run side by side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -389,8 +389,10 @@ def main():
                             launches_per_image=round(a["n"]), est_ms_per_image=round(a["ms"], 1),
                             traffic_note=traffic_note, traffic_source=traffic_source,
                             method="HIP events around each launch, eager replay of the benchmark's plans right after "
-                                   "the timed region (the timed region itself replays hipGraphs); weights = the "
-                                   "timed region's own pass counts",
+                                   "the timed region, ONE launch sequence alone on the GPU (the timed region itself "
+                                   "replays hipGraphs, on config.lanes_per_gpu streams side by side — kernels of "
+                                   "different lanes overlap there, so per-kernel durations can only be taken here); "
+                                   "weights = the timed region's own pass counts",
                             all_gemm_tflops=round(gemm_tf, 1) if gemm_tf else None,
                             attention_path=(dict(what="q/k/v/out projections + SDPA (self, GLIGEN fuser, cross)",
                                                  ms_per_image=round(ap_["ms"], 1),
@@ -427,7 +429,7 @@ def main():
                            guidance_iters_per_image=round(iters_on + iters_off, 2),
                            guidance_iters_fuser_on=round(iters_on, 2),
                            algorithmic_tflop_per_image=round(tf, 3) if tf else None,
-                           lanes_per_gpu=len(lanes),
+                           lanes_per_gpu=len(lanes), gemm_tuning=ops.TUNING_MODE,
                            weight_broadcast_s=round(bcast_s, 3), prebuild_s=round(prebuild_s, 2),
                            per_rank_busy_s=[round(b, 3) for b in per_rank_busy],
                            per_rank_idle_s=[round(max(dt - b, 0.0), 3) for b in per_rank_busy]),

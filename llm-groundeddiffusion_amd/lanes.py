@@ -225,7 +225,10 @@ class LanePool:
 def make_lanes(engine, n_lanes: int, make_sampler: Callable[[Any], Any]) -> List[Lane]:
     """Lane 0 drives `engine` itself; lanes 1.. get engines that share its parameters.  make_sampler(engine) builds
     the lane's LMDSampler (scheduler, VAE, batch limits: whatever the caller wants, one fresh set per lane)."""
+    from . import ops
     from .unet import UNetEngine
+    if int(n_lanes) > 1:
+        ops.set_tuning_mode("throughput")       # plans built from here on: GEMM tiles chosen for a shared GPU
     lanes = []
     for i in range(max(1, int(n_lanes))):
         eng = engine if i == 0 else UNetEngine(engine.cfg, engine.device, text_len=engine.text_len,

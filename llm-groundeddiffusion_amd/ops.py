@@ -177,17 +177,35 @@ def shape_key(d) -> str:
             f"_e{d.epi & 1}_b{d.nb_o * d.nb_i}")
 
 
-_TUNING = None
+_TUNING = {}
+# "latency": tile / split-K per shape chosen for the shortest isolated launch (one launch sequence owns the GPU);
+# "throughput": chosen for the lowest cost when several sequences share the GPU (lanes.LanePool; the same launch on
+# 4 streams at once, tools/tune_gemm.py LGD_TUNE_STREAMS=4): fewer split-K slabs, larger tiles — a launch may leave CUs
+# idle, another lane fills them.  Plans read the table when they are BUILT.
+TUNING_MODE = _os.environ.get("LGD_TUNING_MODE", "latency")
+_TUNING_FILES = {"latency": ("tuning_gfx950.json",), "throughput": ("tuning_gfx950.json", "tuning_gfx950_lanes.json")}
+
+
+def set_tuning_mode(mode: str):
+    global TUNING_MODE
+    if mode not in _TUNING_FILES:
+        raise ValueError(f"tuning mode {mode!r}: expected one of {sorted(_TUNING_FILES)}")
+    if _os.environ.get("LGD_TUNING_MODE"):       # an explicit environment choice wins (A/B measurements)
+        return
+    TUNING_MODE = mode
 
 
 def tuning_table():
-    global _TUNING
-    if _TUNING is None:
+    mode = TUNING_MODE
+    if mode not in _TUNING:
         import json
-        import os
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_gfx950.json")
-        _TUNING = json.load(open(path)) if os.path.exists(path) else {}
-    return _TUNING
+        tab = {}
+        for fname in _TUNING_FILES[mode]:      # later files override earlier ones shape by shape
+            path = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), fname)
+            if _os.path.exists(path):
+                tab.update(json.load(open(path)))
+        _TUNING[mode] = tab
+    return _TUNING[mode]
 
 
 class LaunchProfiler:

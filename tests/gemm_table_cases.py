@@ -32,8 +32,18 @@ def mode(s: Shape):
     return (s.tile, s.taps, s.stride, s.ups, s.c1 > 0, s.geglu, s.splits > 1)
 
 
+TABLE_LANES = TABLE.replace("tuning_gfx950.json", "tuning_gfx950_lanes.json")     # ops.TUNING_MODE == "throughput"
+
+
 def table():
-    return {k: parse(k, e) for k, e in json.load(open(TABLE)).items()}
+    """Entries of both tables; a shape both hold appears twice (key suffixed) when its launch configuration differs."""
+    out = {k: parse(k, e) for k, e in json.load(open(TABLE)).items()}
+    if os.path.exists(TABLE_LANES):
+        for k, e in json.load(open(TABLE_LANES)).items():
+            s = parse(k, e)
+            if k not in out or (out[k].tile, out[k].splits) != (s.tile, s.splits):
+                out[k + "@lanes"] = s._replace(key=k + "@lanes")
+    return out
 
 
 def cases():

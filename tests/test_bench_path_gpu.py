@@ -116,9 +116,15 @@ def test_tuned_gemm_mode_on_its_table_shape(dev, s):
     ops.gemm_launch(d)
     torch.cuda.synchronize()
     assert relerr(out, ref) < 3e-3
-    # what the engine would pick for this shape (tile=0 / splits=None) is this very table entry
-    d2 = ops.gemm_desc(x0, w, out, M, N, K, a1=x1, c0=s.c0, c1=s.c1, lda0=s.c0, lda1=s.c1,
-                       epi=ops.EPI_GEGLU if s.geglu else 0, ldc=out.shape[1], **kw)
+    # what the engine would pick for this shape (tile=0 / splits=None) is this very table entry ("@lanes": of the
+    # table used when several launch sequences share the GPU, ops.TUNING_MODE == "throughput")
+    mode0 = ops.TUNING_MODE
+    ops.TUNING_MODE = "throughput" if s.key.endswith("@lanes") else "latency"
+    try:
+        d2 = ops.gemm_desc(x0, w, out, M, N, K, a1=x1, c0=s.c0, c1=s.c1, lda0=s.c0, lda1=s.c1,
+                           epi=ops.EPI_GEGLU if s.geglu else 0, ldc=out.shape[1], **kw)
+    finally:
+        ops.TUNING_MODE = mode0
     assert (d2.tile, d2.splits) == (s.tile, s.splits)
 
 

@@ -17,7 +17,9 @@ TILE_BN = {1: 128, 2: 64, 3: 128, 4: 64, 5: 128, 6: 160, 7: 160, 9: 320, 10: 128
 def test_table_entries_are_legal():
     table = json.load(open(TABLE))
     assert len(table) >= 200
-    for key, e in table.items():
+    lanes = TABLE.replace("tuning_gfx950.json", "tuning_gfx950_lanes.json")
+    entries = list(table.items()) + (list(json.load(open(lanes)).items()) if os.path.exists(lanes) else [])
+    for key, e in entries:
         m = re.match(r"M(\d+)_N(\d+)_K(\d+)_t(\d)_c(\d+)\+(\d+)_h(\d+)x(\d+)_s(\d)_u(\d)_e(\d)_b(\d+)$", key)
         assert m, key
         M, N, K, taps, c0, c1 = (int(m.group(i)) for i in range(1, 7))

@@ -84,6 +84,34 @@ def reference(sh, pb):
     return c.float()
 
 
+N_STREAMS = int(os.environ.get("LGD_TUNE_STREAMS", "1"))
+STREAMS = [torch.cuda.Stream() for _ in range(N_STREAMS)] if N_STREAMS > 1 else []
+
+
+def bench_concurrent(sh, pb, tile, splits, reps=6):
+    """Cost of a launch when the GPU is shared by several launch sequences (lgd_amd/lanes.py): the same candidate on
+    N_STREAMS streams at once, each with its own output and split-K scratch; us per launch = wall / (streams x reps).
+    What counts here is how much of the machine a launch occupies for how long, not how soon it finishes alone."""
+    ds = []
+    for _ in STREAMS:
+        c = torch.empty(sh["M"], pb["n_out"], device=dev, dtype=torch.float16)
+        ds.append((make_desc(sh, pb, c, tile, splits), c))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    cur = torch.cuda.current_stream()
+    e0.record()
+    for st, (d, _) in zip(STREAMS, ds):
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            for _ in range(reps):
+                orig(d)
+    for st in STREAMS:
+        cur.wait_stream(st)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (reps * len(STREAMS)) * 1e3
+
+
 def bench(sh, pb, ref, tile, splits, reps=8):
     """Launches a candidate, VERIFIES its output against the trusted reference, then times it (us) —
     a candidate that computes something else is never recorded."""
@@ -98,6 +126,8 @@ def bench(sh, pb, ref, tile, splits, reps=8):
     if not (err < VERIFY_TOL):
         rejected.append((ops.shape_key(d), tile, splits, err))
         return None
+    if N_STREAMS > 1:
+        return bench_concurrent(sh, pb, tile, splits)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -130,8 +160,8 @@ for key, sh in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"
         for sp in (1, 2, 3, 4, 6, 8, 12, 16):
             if sp > 1 and (K // 64 < 4 * sp or wgs * sp > 2048 or sp * M * N > (1 << 26)):
                 continue
-            if wgs * sp < 48 and sp < 16 and K // 64 >= 8 * sp:
-                continue   # hopelessly under-filled, a larger split exists
+            if wgs * sp < (8 if N_STREAMS > 1 else 48) and sp < 16 and K // 64 >= 8 * sp:
+                continue   # hopelessly under-filled, a larger split exists (shared GPU: other sequences fill it)
             cands.append((tile, sp))
     pb = make_problem(sh)
     ref = reference(sh, pb)
@@ -145,8 +175,20 @@ for key, sh in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"
     fl = 2.0 * M * N * K
     table[key] = dict(tile=best[1], splits=best[2], us=round(best[0], 2), tflops=round(fl / best[0] / 1e6, 1),
                       base_us=round(base, 2), count=sh["count"])
-    tot_old += base * sh["count"]; tot_new += best[0] * sh["count"]
-    print(f"{key:60s} n={sh['count']:3d} base {base:7.1f}us -> tile {best[1]} split {best[2]:2d} {best[0]:7.1f}us "
+    ref_us = base
+    if N_STREAMS > 1:
+        table[key]["streams"] = N_STREAMS
+        if os.environ.get("LGD_TUNE_TOP") and key in old_entries:     # what the latency-tuned choice costs in this regime
+            o = old_entries[key]
+            t_old = bench(sh, pb, ref, o["tile"], o["splits"])
+            if t_old is not None:
+                ref_us = t_old
+                table[key]["latency_choice"] = dict(tile=o["tile"], splits=o["splits"], us=round(t_old, 2))
+                if t_old <= best[0] * 1.02:                            # keep the latency choice unless clearly beaten
+                    best = (t_old, o["tile"], o["splits"])
+                    table[key].update(tile=o["tile"], splits=o["splits"], us=round(t_old, 2), tflops=round(fl / t_old / 1e6, 1))
+    tot_old += ref_us * sh["count"]; tot_new += best[0] * sh["count"]
+    print(f"{key:60s} n={sh['count']:3d} base {ref_us:7.1f}us -> tile {best[1]} split {best[2]:2d} {best[0]:7.1f}us "
           f"{fl / best[0] / 1e6:6.1f} TF/s", flush=True)
 print(f"sum over passes: {tot_old/1e3:.2f} ms -> {tot_new/1e3:.2f} ms")
 for r in rejected:
