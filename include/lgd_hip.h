@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LGD_ABI_VERSION 5
+#define LGD_ABI_VERSION 6
 int lgd_abi_version(void);
 /* Kernel-variant switches of the library (A/B timing and tests; the defaults are what the benchmark runs).  No
  * counterpart in the reference.  "attn32": self-attention forward without map capture — 0 = the 16x16x32 kernel,
@@ -223,6 +223,12 @@ int lgd_cfg_ddim_step_f32(const float* eps, const float* x, float* x_out, const 
 int lgd_cfg_multistep_step_f32(const float* eps, const float* x, float* x_out, float* x0_prev,
                                const float* coef_table, const int32_t* dyn, const float* frozen_ref,
                                const float* mask, float* hist, int B, int C, int HW, void* stream);
+/* Model-input scaling of sigma-space samplers — [ext] diffusers EulerDiscreteScheduler.scale_model_input, which the
+ * SDXL-refiner pass applies before every UNet call (generation/sdxl_refinement.py:29 -> StableDiffusionXLImg2ImgPipeline):
+ *   out[r][i] = x[i] * table[dyn[0] * row_stride + col]   for r < reps   (reps = 2: the CFG pair reads one latent).
+ * The factor is read on the device, so the call sits inside a captured hipGraph that replays for every step. */
+int lgd_scale_rows_f32(const float* x, float* out, const float* table, const int32_t* dyn, int row_stride, int col,
+                       int64_t n, int reps, void* stream);
 /* guidance latent update (pipelines.py:60-69): x -= active[i/per_sample] * coef_table[*step_idx][col] * g.
  * active (device fp32 per image, or NULL = all on) emulates the per-image `while` exit of
  * pipelines.py:30 when several layouts are guided in one batch. */

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgd_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -73,6 +73,7 @@ SIGNATURES = {
     "lgd_cfg_multistep_step_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "lgd_axpy_f32": [_P, _P, _P, _P, _I, _P, _L, _L, _P],
     "lgd_select_row_f32": [_P, _P, _P, _I, _P],
+    "lgd_scale_rows_f32": [_P, _P, _P, _P, _I, _I, _L, _I, _P],
     "lgd_attn_causal_fwd_f16": [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _F, _P],
     "lgd_quick_gelu_f16": [_P, _P, _L, _P],
     "lgd_act_f16": [_P, _P, _L, _I, _P],

@@ -67,13 +67,19 @@ class HipCLIPTextEncoder:
                 fc1=(h16(sd[f"{p}.mlp.fc1.weight"]), f32(sd[f"{p}.mlp.fc1.bias"])),
                 fc2=(h16(sd[f"{p}.mlp.fc2.weight"]), f32(sd[f"{p}.mlp.fc2.bias"]))))
         self.ln_f = (f32(sd["final_layer_norm.weight"]), f32(sd["final_layer_norm.bias"]))
+        # CLIPTextModelWithProjection (SDXL's text_encoder_2, OpenCLIP ViT-bigG/14): text_embeds = pooled @ W^T, no bias
+        self.text_projection = h16(state_dict["text_projection.weight"]) if "text_projection.weight" in state_dict else None
 
     def to(self, *_a, **_k):            # call-surface compatibility with nn.Module users
         return self
 
     @torch.no_grad()
-    def __call__(self, input_ids=None, attention_mask=None, **_kw):
+    def __call__(self, input_ids=None, attention_mask=None, output_hidden_states=False, **_kw):
         """input_ids (B, S<=77) int64 -> (last_hidden_state (B,S,C) fp32,) with `.pooler_output` (B,C).
+        output_hidden_states: `.hidden_states` = (embeddings, layer 1 output, ..., layer N output) as transformers
+        returns them (before the final LayerNorm) — SDXL conditions on hidden_states[-2].  With a text_projection
+        (CLIPTextModelWithProjection) `.text_embeds` = projected pooled state and element 0 of the output is
+        text_embeds, as in transformers.
         Like the reference's call sites, no padding mask is applied (models/models.py:73-78 pass ids only; CLIP's
         text tower is causal, so a token never sees the padding behind it)."""
         cfg = self.cfg
@@ -83,6 +89,7 @@ class HipCLIPTextEncoder:
         d = C // H
         x = (self.tok_emb[ids] + self.pos_emb[:S].unsqueeze(0)).reshape(B * S, C).to(F16).contiguous()
         eps = cfg.layer_norm_eps
+        hidden = [x.float().reshape(B, S, C)] if output_hidden_states else None
         for L in self.layers:
             h = ops.layernorm(x, L["ln1"][0], L["ln1"][1], eps)
             qkv = ops.linear(h, L["qkv"][0], L["qkv"][1])                          # [B*S, 3C]
@@ -93,20 +100,30 @@ class HipCLIPTextEncoder:
             h = ops.linear(h, L["fc1"][0], L["fc1"][1])
             h = ops.quick_gelu(h) if cfg.hidden_act == "quick_gelu" else ops.act(h, ops.ACT_GELU)
             x = ops.linear(h, L["fc2"][0], L["fc2"][1], res=x)
+            if hidden is not None:
+                hidden.append(x.float().reshape(B, S, C))
         y = ops.layernorm(x, self.ln_f[0], self.ln_f[1], eps).float().reshape(B, S, C)
         if cfg.eos_token_id == 2:
             eos = ids.argmax(dim=-1)
         else:
             eos = (ids == cfg.eos_token_id).int().argmax(dim=-1)
-        out = _Out((y,))
+        pooled = y[torch.arange(B, device=self.dev), eos]
+        if self.text_projection is not None:
+            te = ops.linear(pooled.to(F16).contiguous(), self.text_projection, None, out_f32=True)[:B]
+            out = _Out((te, y))
+            out.text_embeds = te
+        else:
+            out = _Out((y,))
         out.last_hidden_state = y
-        out.pooler_output = y[torch.arange(B, device=self.dev), eos]
+        out.pooler_output = pooled
+        out.hidden_states = tuple(hidden) if hidden is not None else None
         return out
 
 
 def from_hf(hf_text_model, device="cuda"):
-    """A loaded transformers `CLIPTextModel` (any checkpoint of the SD1.x / SD2.x families) -> the HIP encoder with the same
-    call surface; what `models.load_sd` puts into `model_dict.text_encoder`."""
+    """A loaded transformers `CLIPTextModel` (any checkpoint of the SD1.x / SD2.x families) or `CLIPTextModelWithProjection`
+    (SDXL text_encoder_2) -> the HIP encoder with the same call surface; what `models.load_sd` puts into
+    `model_dict.text_encoder`."""
     c = hf_text_model.config
     cfg = CLIPTextConfig(vocab_size=c.vocab_size, hidden_size=c.hidden_size, intermediate_size=c.intermediate_size,
                          num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,

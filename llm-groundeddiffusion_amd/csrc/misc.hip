@@ -345,6 +345,17 @@ __global__ __launch_bounds__(256) void cfg_multistep_kernel(
   }
 }
 
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                         const float* __restrict__ table,
+                                                         const int32_t* __restrict__ dyn, int row_stride, int col,
+                                                         long n, int reps) {
+  const float s = table[(long)dyn[0] * row_stride + col];
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    const float v = x[i] * s;
+    for (int r = 0; r < reps; ++r) out[r * n + i] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ g, float* __restrict__ x,
                                                     const float* __restrict__ coef_table,
                                                     const int32_t* __restrict__ step_idx, int col,
@@ -497,6 +508,15 @@ extern "C" int lgd_cfg_multistep_step_f32(const float* eps, const float* x, floa
   hipLaunchKernelGGL(cfg_multistep_kernel, dim3(ew_blocks((long)B * C * HW)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), eps, x, x_out, x0_prev, coef_table, dyn, frozen_ref,
                      mask, hist, B, C * HW, HW);
+  return lgd_check_launch();
+}
+
+extern "C" int lgd_scale_rows_f32(const float* x, float* out, const float* table, const int32_t* dyn, int row_stride,
+                                  int col, int64_t n, int reps, void* stream) {
+  (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
+  if (!x || !out || !table || !dyn || n < 1 || reps < 1 || col < 0 || col >= row_stride) return LGD_ERR_ARG;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(ew_blocks(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, out,
+                     table, dyn, row_stride, col, (long)n, reps);
   return lgd_check_launch();
 }
 

@@ -11,7 +11,7 @@ namespace {
 // A thread owns a fixed 8-channel vector column (tid + j*256 < C/8) and walks pixels, so loads of
 // a wave are contiguous within a pixel row.
 // ------------------------------------------------------------------------------------------
-constexpr int GN_MAXC = 2560;
+constexpr int GN_MAXC = 4096;   // SDXL-refiner up blocks normalise 1536 + 1536 channels
 
 // Deterministic per-group reduction: every thread deposits its 8 per-channel partial sums (two
 // quantities a, b) in LDS at [pixel lane][channel]; thread g < G then adds the channels of group g

@@ -568,6 +568,13 @@ def axpy(g, x, coef_table, step_idx, col, active=None):
           _stream())
 
 
+def scale_rows(x, out, table, dyn, col, reps=1):
+    """out[r] = x * table[dyn[0]][col], r < reps (EulerDiscrete.scale_model_input for the CFG pair; lgd_hip.h)."""
+    _call("lgd_scale_rows_f32", _p(x), _p(out), _p(table), _p(dyn), int(table.shape[1]), int(col), x.numel(), int(reps),
+          _stream())
+    return out
+
+
 def select_row(table, idx, out):
     _call("lgd_select_row_f32", _p(table), _p(idx), _p(out), out.numel(), _stream())
 

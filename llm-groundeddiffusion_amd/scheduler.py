@@ -181,3 +181,78 @@ class DPMSolverMultistepScheduler(DDIMScheduler):
         x0 = c0 * sample + c1 * model_output
         out = A * sample + B * x0 + (C * x0_prev if C != 0.0 else 0.0)
         return out, x0
+
+
+class EulerDiscreteScheduler:
+    """[ext] diffusers EulerDiscreteScheduler as the SDXL refiner configures it (scheduler_config of
+    stabilityai/stable-diffusion-xl-refiner-1.0: scaled_linear betas 0.00085..0.012, 1000 train steps, timestep_spacing
+    "leading", steps_offset 1, epsilon prediction, linear sigma interpolation, no Karras sigmas, s_churn 0) — the sampler
+    behind generation/sdxl_refinement.py:29.  diffusers is absent from the sandbox: restated from the published
+    algorithm (Karras et al. 2022, Algorithm 2 without churn), parity unpinned at this boundary.
+
+    In sigma space (x = x0 + sigma * eps) one Euler step is linear in (x, x0):
+        x0 = x - sigma eps ;  x' = x + (sigma' - sigma) (x - x0) / sigma = (sigma'/sigma) x + (1 - sigma'/sigma) x0
+    so the device side is the fused `lgd_cfg_multistep_step_f32` kernel with rows {1, -sigma, sigma'/sigma,
+    1 - sigma'/sigma, 0, guidance_scale, c_in, 0}; c_in = 1/sqrt(sigma^2 + 1) (scale_model_input) is applied by
+    `lgd_scale_rows_f32` from the same row."""
+    multistep = True
+    C_IN_COL = 6
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1,
+                 prediction_type="epsilon"):
+        if prediction_type != "epsilon":
+            raise NotImplementedError("EulerDiscreteScheduler: the refiner predicts epsilon")
+        self.config = _Cfg(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                           beta_schedule="scaled_linear", steps_offset=steps_offset, prediction_type=prediction_type,
+                           timestep_spacing="leading", interpolation_type="linear", use_karras_sigmas=False)
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.num_inference_steps = None
+        self.timesteps = None
+        self.sigmas = None
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        self.num_inference_steps = num_inference_steps
+        n = self.config.num_train_timesteps
+        ts = (np.arange(0, num_inference_steps) * (n // num_inference_steps)).round()[::-1].copy().astype(np.float32)
+        ts += self.config.steps_offset
+        sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        sig = np.interp(ts, np.arange(0, len(sig)), sig)
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(ts)
+
+    @property
+    def init_noise_sigma(self):
+        return float((self.sigmas.max() ** 2 + 1) ** 0.5)                   # "leading" spacing
+
+    def img2img_start(self, num_inference_steps, strength):
+        """StableDiffusionXLImg2ImgPipeline.get_timesteps (no denoising_start): index of the first step that runs."""
+        init = min(int(num_inference_steps * strength), num_inference_steps)
+        return max(num_inference_steps - init, 0)
+
+    def index_of(self, t):
+        return int((self.timesteps == float(t)).nonzero()[0])
+
+    def scale_model_input(self, sample, timestep):
+        s = float(self.sigmas[self.index_of(timestep)])
+        return sample / ((s * s + 1) ** 0.5)
+
+    def add_noise(self, original, noise, timestep):
+        return original + noise * float(self.sigmas[self.index_of(timestep)])
+
+    def multistep_rows(self, first=0):
+        rows = []
+        for i in range(first, len(self.timesteps)):
+            s, sn = float(self.sigmas[i]), float(self.sigmas[i + 1])
+            rows.append((1.0, -s, sn / s, 1.0 - sn / s, 0.0, 1.0 / (s * s + 1.0) ** 0.5))
+        return rows
+
+    def multistep_table(self, guidance_scale: float, device, first=0) -> torch.Tensor:
+        rows = [[c0, c1, A, B, C, guidance_scale, c_in, 0.0] for c0, c1, A, B, C, c_in in self.multistep_rows(first)]
+        return torch.tensor(rows, dtype=torch.float32, device=device)
+
+    def step_host(self, model_output, index, sample):
+        """Torch form of one step exactly as the scheduler class writes it (tests)."""
+        s, sn = self.sigmas[index], self.sigmas[index + 1]
+        pred_original = sample - s * model_output
+        return sample + (sample - pred_original) / s * (sn - s)

@@ -155,12 +155,26 @@ class Plan:
         Ho = (Hl - 1) // stride + 1
         M = B * Ho * Ho
         y = self._act(M, Cout)
-        bias2 = self.eng.temb_cur[temb_off:temb_off + Cout] if temb_off is not None else None
-        d = ops.gemm_desc(x.t, W, y.t, M, Cout, K, a1=x1.t if x1 else None, c0=c0, c1=c1, lda0=c0,
-                          lda1=c1, taps=9, hin=H, win=H, hout=Ho, wout=Ho, stride=stride,
-                          ups=1 if ups else 0, bias=b, bias2=bias2, res=res.t if res else None,
-                          ldr=res.C if res else 0, ldc=Cout)
-        fwd = lambda: ops.gemm_launch(d)
+        eng = self.eng
+        if temb_off is not None and eng.temb_rows > 1:
+            # text_time conditioning (SDXL): the time embedding differs per image (pooled text + size / score ids), the
+            # GEMM epilogue takes ONE bias2 vector per launch -> one launch per image (1024^2 refiner: 16384 rows each)
+            assert stride == 1 and not ups and res is None
+            ds = []
+            for i in range(B):
+                row = eng.temb_cur[self.text_off + i]
+                sl = slice(i * H * H, (i + 1) * H * H)
+                ds.append(ops.gemm_desc(x.t[sl], W, y.t[sl], H * H, Cout, K, a1=x1.t[sl] if x1 else None, c0=c0, c1=c1,
+                                        lda0=c0, lda1=c1, taps=9, hin=H, win=H, hout=H, wout=H, bias=b,
+                                        bias2=row[temb_off:temb_off + Cout], ldc=Cout))
+            fwd = lambda: [ops.gemm_launch(dd) for dd in ds]
+        else:
+            bias2 = eng.temb_cur[0, temb_off:temb_off + Cout] if temb_off is not None else None
+            d = ops.gemm_desc(x.t, W, y.t, M, Cout, K, a1=x1.t if x1 else None, c0=c0, c1=c1, lda0=c0,
+                              lda1=c1, taps=9, hin=H, win=H, hout=Ho, wout=Ho, stride=stride,
+                              ups=1 if ups else 0, bias=b, bias2=bias2, res=res.t if res else None,
+                              ldr=res.C if res else 0, ldc=Cout)
+            fwd = lambda: ops.gemm_launch(d)
         if not self.grad:
             self._add(fwd)
             return y
@@ -317,7 +331,7 @@ class Plan:
         C = q.C
         d = C // heads
         T = eng.text_len
-        kv = eng.text_kv[layer_name]                    # [Bt, 77, 2C]
+        kv = eng.text_kv[layer_name]                    # [Bt, 77, 2C]; layer_name = UNetEngine.kv_name(prefix, depth index)
         kv_t = kv[self.text_off:]
         k_view = (2 * C, T * 2 * C)
         o = self._act(B * S, C)
@@ -379,37 +393,41 @@ class Plan:
         eng, B = self.eng, self.B
         S = H * H
         C, heads = a.channels, a.heads
-        t = f"{a.prefix}.transformer_blocks.0"
         n = self.groupnorm(x, None, f"{a.prefix}.norm", S, 1e-6, False)          # transformer_2d.py:283
         h = self.linear(n, f"{a.prefix}.proj_in")
-        # 1. self-attention (attention.py:185-195)
-        qkv = self.linear(self.layernorm(h, f"{t}.norm1"), f"{t}.attn1.qkv", bias=False)
-        h = self.linear(self.self_attn(qkv, heads, S), f"{t}.attn1.to_out.0", res=h)
-        self.dbg[f"{a.prefix}.after_attn1"] = h
-        # 1.5 GLIGEN gated self-attention (attention.py:43-53, 198-200)
-        if self.fuser:
-            f = f"{t}.fuser"
-            Sk = S + N_OBJ_TOKENS
-            cat = eng.fuser_cat(a.prefix, B, S, self.obj_off)        # [B*(S+30), C], tail rows preset
-            cat_act = self.layernorm(h, f"{f}.norm1", out_t=cat, ldy=C, S=S, y_bs=Sk * C)
-            # the gradient w.r.t. the concat buffer is consumed only by the LayerNorm backward of the
-            # visual rows; the 30 grounding rows are constants of the run
-            qkv_f = self.linear(cat_act, f"{f}.attn.qkv", bias=False)
-            o = self.self_attn(qkv_f, heads, S, Sk)
-            h = self.linear(o, f"{f}.attn.to_out.0", res=h, alpha=eng.w.scalars[f"{f}.alpha_attn"])
-            self.dbg[f"{a.prefix}.after_fuser_attn"] = h
-            h = self.ff(self.layernorm(h, f"{f}.norm2"), h, f"{f}.ff", alpha=eng.w.scalars[f"{f}.alpha_dense"])
-            self.dbg[f"{a.prefix}.after_fuser"] = h
-        # 2. cross-attention (attention.py:204-220) — the hook of attention_processor.py:377-483
-        q = self.linear(self.layernorm(h, f"{t}.norm2"), f"{t}.attn2.to_q", bias=False)
-        last = self.stop_key is not None and a.key == self.stop_key
-        o = self.cross_attn(q, a.key, a.prefix, heads, S, last)
-        if last:
-            return None
-        h = self.linear(o, f"{t}.attn2.to_out.0", res=h)
-        self.dbg[f"{a.prefix}.after_attn2"] = h
-        # 3. feed-forward (attention.py:223-233)
-        h = self.ff(self.layernorm(h, f"{t}.norm3"), h, f"{t}.ff")
+        for dpt in range(a.depth):                                               # transformer_2d.py:293-302
+            t = f"{a.prefix}.transformer_blocks.{dpt}"
+            key = tuple(a.key[:3]) + (dpt,)
+            # 1. self-attention (attention.py:185-195)
+            qkv = self.linear(self.layernorm(h, f"{t}.norm1"), f"{t}.attn1.qkv", bias=False)
+            h = self.linear(self.self_attn(qkv, heads, S), f"{t}.attn1.to_out.0", res=h)
+            if dpt == 0:
+                self.dbg[f"{a.prefix}.after_attn1"] = h
+            # 1.5 GLIGEN gated self-attention (attention.py:43-53, 198-200)
+            if self.fuser:
+                f = f"{t}.fuser"
+                Sk = S + N_OBJ_TOKENS
+                cat = eng.fuser_cat(eng.kv_name(a.prefix, dpt), B, S, self.obj_off)   # [B*(S+30), C], tail rows preset
+                cat_act = self.layernorm(h, f"{f}.norm1", out_t=cat, ldy=C, S=S, y_bs=Sk * C)
+                # the gradient w.r.t. the concat buffer is consumed only by the LayerNorm backward of the
+                # visual rows; the 30 grounding rows are constants of the run
+                qkv_f = self.linear(cat_act, f"{f}.attn.qkv", bias=False)
+                o = self.self_attn(qkv_f, heads, S, Sk)
+                h = self.linear(o, f"{f}.attn.to_out.0", res=h, alpha=eng.w.scalars[f"{f}.alpha_attn"])
+                self.dbg[f"{a.prefix}.after_fuser_attn"] = h
+                h = self.ff(self.layernorm(h, f"{f}.norm2"), h, f"{f}.ff", alpha=eng.w.scalars[f"{f}.alpha_dense"])
+                self.dbg[f"{a.prefix}.after_fuser"] = h
+            # 2. cross-attention (attention.py:204-220) — the hook of attention_processor.py:377-483
+            q = self.linear(self.layernorm(h, f"{t}.norm2"), f"{t}.attn2.to_q", bias=False)
+            last = self.stop_key is not None and key == self.stop_key
+            o = self.cross_attn(q, key, eng.kv_name(a.prefix, dpt), heads, S, last)
+            if last:
+                return None
+            h = self.linear(o, f"{t}.attn2.to_out.0", res=h)
+            if dpt == 0:
+                self.dbg[f"{a.prefix}.after_attn2"] = h
+            # 3. feed-forward (attention.py:223-233)
+            h = self.ff(self.layernorm(h, f"{t}.norm3"), h, f"{t}.ff")
         out = self.linear(h, f"{a.prefix}.proj_out", res=x)                      # transformer_2d.py:319-327
         self.dbg[f"{a.prefix}.out"] = out
         return out
@@ -539,21 +557,31 @@ class UNetEngine:
                 self.w.load_state_dict(state_dict)
         self.text_len = text_len
         self.max_text_batch = max_text_batch
-        self.temb_cur = torch.zeros(self.w.temb_total, device=self.device, dtype=F32)
+        # time-embedding projections of the current step: one row, or (text_time models) one row per image of the
+        # conditioning batch — plans bind these addresses when they are built
+        self.temb_rows = max_text_batch if cfg.addition_embed_type == "text_time" else 1
+        self.temb_cur = torch.zeros((self.temb_rows, self.w.temb_total), device=self.device, dtype=F32)
         self.temb_table = None
         self.dyn = torch.zeros(4, device=self.device, dtype=torch.int32)   # {step, frozen_steps, -, -}
         self.step_idx = self.dyn[:1]
         self.text_kv: Dict[str, torch.Tensor] = {}
         for b in self.blocks:
             for a in b.attns:
-                self.text_kv[a.prefix] = torch.zeros((max_text_batch, text_len, 2 * a.channels),
-                                                     device=self.device, dtype=F16)
+                for dpt in range(a.depth):
+                    self.text_kv[self.kv_name(a.prefix, dpt)] = torch.zeros((max_text_batch, text_len, 2 * a.channels),
+                                                                            device=self.device, dtype=F16)
         self._ws = None
         self._ws_size = 0
         self._fuser_cat: Dict[Tuple, torch.Tensor] = {}
         self._plans: "OrderedDict[Tuple, Plan]" = OrderedDict()
         self._objs = None
         self._arena: List[torch.Tensor] = []      # uint8 segments shared by all plans (Plan._alloc)
+
+    @staticmethod
+    def kv_name(prefix: str, depth_index: int = 0) -> str:
+        """Name of a transformer layer's text K/V (and GLIGEN concat) buffers: the attention block's prefix for its
+        first layer (every SD 1.x / 2.x block has exactly one), "prefix@d" for layer d of a deeper block (SDXL)."""
+        return prefix if depth_index == 0 else f"{prefix}@{depth_index}"
 
     # ---- activation arena -------------------------------------------------------------------
     def arena_take(self, cursor, shape, dtype):
@@ -600,23 +628,49 @@ class UNetEngine:
         return self._fuser_cat[key]
 
     # ---- per-run constants --------------------------------------------------------------------
-    def prepare_timesteps(self, timesteps: Sequence[int]):
+    def prepare_timesteps(self, timesteps: Sequence[int], added_cond: Optional[Dict[str, torch.Tensor]] = None):
         """Time-embedding MLP + every resnet's time_emb_proj for all timesteps of the run
-        (unet_2d_condition.py:785-808 + [ext] ResnetBlock2D): table [T][sum Cout] fp32."""
+        (unet_2d_condition.py:785-808 + [ext] ResnetBlock2D): table [T][sum Cout] fp32.
+        text_time models ([ext] diffusers SDXL UNet2DConditionModel.forward): added_cond = {"text_embeds": [R, pooled],
+        "time_ids": [R, 5]} for the R images of the conditioning batch; emb_t + add_embedding(cat(text_embeds,
+        Timesteps(time_ids))) is projected per image: table [T][R * sum Cout]."""
         self.const_writer = None          # whoever cached the previous tables must rebuild (dropin UNet wrapper)
         cfg, w = self.cfg, self.w
         c0 = cfg.block_out_channels[0]
+        silu = torch.nn.functional.silu
+
+        def sincos(v, dim):                                                       # flip_sin_to_cos, freq shift 0
+            half = dim // 2
+            freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=self.device) / half)
+            e = v[:, None] * freqs[None]
+            return torch.cat([torch.cos(e), torch.sin(e)], dim=-1)
+
         t = torch.as_tensor(list(timesteps), dtype=torch.float32, device=self.device)
-        half = c0 // 2
-        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=self.device) / half)
-        e = t[:, None] * freqs[None]
-        emb = torch.cat([torch.cos(e), torch.sin(e)], dim=-1).to(F16)            # flip_sin_to_cos
+        emb = sincos(t, c0).to(F16)
         T = emb.shape[0]
         h = ops.linear(emb.contiguous(), w.h["time_embedding.linear_1.w"], w.f["time_embedding.linear_1.b"], out_f32=True)
-        h = torch.nn.functional.silu(h).to(F16)
-        h = ops.linear(h, w.h["time_embedding.linear_2.w"], w.f["time_embedding.linear_2.b"], out_f32=True)
-        h = torch.nn.functional.silu(h).to(F16)
-        self.temb_table = ops.linear(h, w.h["temb_proj.w"], w.f["temb_proj.b"], out_f32=True)[:T].contiguous()
+        h = silu(h).to(F16)
+        h = ops.linear(h, w.h["time_embedding.linear_2.w"], w.f["time_embedding.linear_2.b"], out_f32=True)[:T]
+        if cfg.addition_embed_type == "text_time":
+            if added_cond is None:
+                raise RuntimeError(f"{cfg.name} needs added_cond (text_embeds, time_ids) for its time embedding")
+            te = added_cond["text_embeds"].to(self.device, F32)
+            ids = added_cond["time_ids"].to(self.device, F32)
+            R = te.shape[0]
+            if R > self.temb_rows or te.shape[1] != cfg.pooled_dim or tuple(ids.shape) != (R, 5):
+                raise RuntimeError(f"added_cond shapes {tuple(te.shape)} / {tuple(ids.shape)} do not fit {cfg.name}")
+            tid = sincos(ids.reshape(-1), cfg.addition_time_embed_dim).reshape(R, -1)
+            a = torch.cat([te, tid], dim=-1).to(F16).contiguous()
+            a = ops.linear(a, w.h["add_embedding.linear_1.w"], w.f["add_embedding.linear_1.b"], out_f32=True)[:R]
+            a = ops.linear(silu(a).to(F16), w.h["add_embedding.linear_2.w"], w.f["add_embedding.linear_2.b"], out_f32=True)[:R]
+            h = (h[:, None, :] + a[None, :, :]).reshape(T * R, -1)                # emb = emb + aug_emb, per image
+            tab = ops.linear(silu(h).to(F16).contiguous(), w.h["temb_proj.w"], w.f["temb_proj.b"], out_f32=True)[:T * R]
+            full = torch.zeros((T, self.temb_rows, w.temb_total), device=self.device, dtype=F32)
+            full[:, :R] = tab.view(T, R, -1)
+            self.temb_table = full.view(T, -1)
+        else:
+            h = silu(h).to(F16)
+            self.temb_table = ops.linear(h, w.h["temb_proj.w"], w.f["temb_proj.b"], out_f32=True)[:T].contiguous()
         return self.temb_table
 
     def set_step(self, index: int):
@@ -636,9 +690,10 @@ class UNetEngine:
         x = ehs.to(self.device, F16).reshape(Bt * T, Cx).contiguous()
         for b in self.blocks:
             for a in b.attns:
-                kv = self.text_kv[a.prefix]
-                ops.linear(x, self.w.h[f"{a.prefix}.transformer_blocks.0.attn2.kv.w"],
-                           out=kv.view(-1, kv.shape[-1])[:Bt * T])
+                for dpt in range(a.depth):
+                    kv = self.text_kv[self.kv_name(a.prefix, dpt)]
+                    ops.linear(x, self.w.h[f"{a.prefix}.transformer_blocks.{dpt}.attn2.kv.w"],
+                               out=kv.view(-1, kv.shape[-1])[:Bt * T])
 
     def prepare_gligen(self, boxes: torch.Tensor, masks: torch.Tensor, positive_embeddings: torch.Tensor):
         """GLIGEN grounding tokens for the run: PositionNet (unet_2d_condition.py:99-114), then per
@@ -664,7 +719,8 @@ class UNetEngine:
         for (prefix, B, toff), cat in self._fuser_cat.items():
             if B not in (Bt, Bt // 2) or toff + B > Bt:
                 continue                   # concat buffer of a plan with another batch size
-            f = f"{prefix}.transformer_blocks.0.fuser"
+            pfx, _, dpt = prefix.partition("@")                     # kv_name(prefix, depth index)
+            f = f"{pfx}.transformer_blocks.{dpt or 0}.fuser"
             C = cat.shape[1]
             S = cat.shape[0] // B - N_OBJ_TOKENS
             o = ops.linear(objs, w.h[f"{f}.linear.w"], w.f[f"{f}.linear.b"])          # [Bt*30, C]

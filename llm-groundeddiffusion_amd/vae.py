@@ -281,3 +281,153 @@ def make_hip_vae(device, seed=0):
     vae = VAEDecoder()
     torch.random.set_rng_state(g)
     return HipVAEDecoder(vae, device)
+
+
+def synth_aekl_state_dict(ch=(128, 256, 512, 512), layers=2, latent_channels=4, seed=0, legacy_attention_names=False):
+    """A full AutoencoderKL state dict (encoder + quant_conv + post_quant_conv + decoder, diffusers key names) with
+    seeded random parameters of the SD / SDXL VAE architecture: there are no checkpoints in the sandbox."""
+    g = torch.Generator().manual_seed(4321 + seed)
+    out = {}
+
+    def conv(name, cout, cin, k):
+        out[f"{name}.weight"] = (torch.rand((cout, cin, k, k), generator=g) * 2 - 1) * (cin * k * k) ** -0.5
+        out[f"{name}.bias"] = 0.05 * torch.randn((cout,), generator=g)
+
+    def norm(name, c):
+        out[f"{name}.weight"] = 1.0 + 0.1 * torch.randn((c,), generator=g)
+        out[f"{name}.bias"] = 0.05 * torch.randn((c,), generator=g)
+
+    def res(name, cin, cout):
+        norm(f"{name}.norm1", cin); conv(f"{name}.conv1", cout, cin, 3)
+        norm(f"{name}.norm2", cout); conv(f"{name}.conv2", cout, cout, 3)
+        if cin != cout:
+            conv(f"{name}.conv_shortcut", cout, cin, 1)
+
+    def attn(name, c):
+        norm(f"{name}.group_norm", c)
+        for n in (("query", "key", "value", "proj_attn") if legacy_attention_names else ("to_q", "to_k", "to_v", "to_out.0")):
+            out[f"{name}.{n}.weight"] = (torch.rand((c, c), generator=g) * 2 - 1) * c ** -0.5
+            out[f"{name}.{n}.bias"] = 0.05 * torch.randn((c,), generator=g)
+
+    conv("encoder.conv_in", ch[0], 3, 3)
+    cin = ch[0]
+    for i, c in enumerate(ch):
+        for j in range(layers):
+            res(f"encoder.down_blocks.{i}.resnets.{j}", cin if j == 0 else c, c)
+        cin = c
+        if i < len(ch) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", c, c, 3)
+    res("encoder.mid_block.resnets.0", cin, cin); attn("encoder.mid_block.attentions.0", cin); res("encoder.mid_block.resnets.1", cin, cin)
+    norm("encoder.conv_norm_out", cin); conv("encoder.conv_out", 2 * latent_channels, cin, 3)
+    conv("quant_conv", 2 * latent_channels, 2 * latent_channels, 1)
+    conv("post_quant_conv", latent_channels, latent_channels, 1)
+    rev = tuple(reversed(ch))
+    conv("decoder.conv_in", rev[0], latent_channels, 3)
+    res("decoder.mid_block.resnets.0", rev[0], rev[0]); attn("decoder.mid_block.attentions.0", rev[0]); res("decoder.mid_block.resnets.1", rev[0], rev[0])
+    cin = rev[0]
+    for i, c in enumerate(rev):
+        for j in range(layers + 1):
+            res(f"decoder.up_blocks.{i}.resnets.{j}", cin if j == 0 else c, c)
+        cin = c
+        if i < len(rev) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", c, c, 3)
+    norm("decoder.conv_norm_out", cin); conv("decoder.conv_out", 3, cin, 3)
+    return out
+
+
+class HipVAEEncoder(HipVAEDecoder):
+    """AutoencoderKL.encode(image).latent_dist on the lgd_hip kernels — the first half of the SDXL-refiner img2img
+    pass (generation/sdxl_refinement.py:29 -> [ext] StableDiffusionXLImg2ImgPipeline.prepare_latents): conv_in 3 -> C0,
+    down blocks (resnets without time embedding, Downsample2D = pad right/bottom by one + 3x3 stride 2), mid block
+    (resnet, one-head attention, resnet), GroupNorm + SiLU, conv_out -> 2 x latent channels, quant_conv (1x1).
+
+    Downsample2D's asymmetric padding: the implicit-GEMM gather pads symmetrically, so the stride-2 output is taken
+    from the ODD positions of the stride-1 'same' convolution (out[o] = sum_k x[2o + k] w[k] = same[2o + 1]; the
+    position past the border reads the zero the asymmetric pad adds) — 4x the flops of three small convolutions,
+    once per image."""
+
+    def __init__(self, state_dict, device, groups: int = 32, eps: float = 1e-6):
+        from . import ops
+        from .weightstore import pack_conv
+        self.ops = ops
+        self.dev = torch.device(device)
+        self.groups, self.eps = groups, eps
+        sd = {k: v.detach().float().cpu() for k, v in dict(state_dict).items() if k.startswith(("encoder.", "quant_conv."))}
+        if "encoder.conv_in.weight" not in sd:
+            raise RuntimeError("not an AutoencoderKL state dict: encoder.conv_in.weight is missing")
+        h16 = lambda t: t.to(self.dev, torch.float16).contiguous()
+        f32 = lambda t: t.to(self.dev, torch.float32).contiguous()
+        conv = lambda n: (h16(pack_conv(sd[f"{n}.weight"])), f32(sd[f"{n}.bias"]))
+        lin = lambda n: (h16(sd[f"{n}.weight"].reshape(sd[f"{n}.weight"].shape[0], -1)), f32(sd[f"{n}.bias"]))
+        norm = lambda n: (f32(sd[f"{n}.weight"]), f32(sd[f"{n}.bias"]))
+
+        def res(n):
+            return dict(n1=norm(f"{n}.norm1"), c1=conv(f"{n}.conv1"), n2=norm(f"{n}.norm2"), c2=conv(f"{n}.conv2"),
+                        sc=lin(f"{n}.conv_shortcut") if f"{n}.conv_shortcut.weight" in sd else None)
+        w_in = sd["encoder.conv_in.weight"]                                          # [C0, 3, 3, 3]
+        ci = w_in.shape[1]
+        if 2 * ci > 8:
+            raise RuntimeError(f"{ci} image channels: the 8-channel conv_in operand holds value + remainder of <= 4")
+        # lgd_nchw_to_nhwc8_f16: channels 0..ci-1 = fp16 value, ci..2ci-1 = its rounding remainder, rest zero
+        self.conv_in = (h16(pack_conv(torch.cat([w_in, w_in, w_in.new_zeros(w_in.shape[0], 8 - 2 * ci, 3, 3)], dim=1))),
+                        f32(sd["encoder.conv_in.bias"]))
+        n_down = 1 + max(int(m.group(1)) for k in sd for m in [re.match(r"encoder\.down_blocks\.(\d+)\.", k)] if m)
+        self.downs = []
+        for i in range(n_down):
+            n_res = 1 + max(int(m.group(1)) for k in sd
+                            for m in [re.match(rf"encoder\.down_blocks\.{i}\.resnets\.(\d+)\.", k)] if m)
+            dn = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+            self.downs.append(([res(f"encoder.down_blocks.{i}.resnets.{j}") for j in range(n_res)],
+                               conv(dn) if f"{dn}.weight" in sd else None))
+        self.mid = [res("encoder.mid_block.resnets.0"), res("encoder.mid_block.resnets.1")]
+        a = "encoder.mid_block.attentions.0"
+        c_mid = sd[f"{a}.group_norm.weight"].shape[0]
+        legacy = f"{a}.query.weight" in sd
+        nq, nk, nv, no = ("query", "key", "value", "proj_attn") if legacy else ("to_q", "to_k", "to_v", "to_out.0")
+        s4 = float(c_mid) ** -0.25
+        wq, wk = sd[f"{a}.{nq}.weight"].reshape(c_mid, -1) * s4, sd[f"{a}.{nk}.weight"].reshape(c_mid, -1) * s4
+        self.attn = dict(n=norm(f"{a}.group_norm"),
+                         qk=(h16(torch.cat([wq, wk])), f32(torch.cat([sd[f"{a}.{nq}.bias"], sd[f"{a}.{nk}.bias"]]) * s4)),
+                         v=h16(sd[f"{a}.{nv}.weight"].reshape(c_mid, -1)), vb=f32(sd[f"{a}.{nv}.bias"]),
+                         o=(h16(sd[f"{a}.{no}.weight"].reshape(c_mid, -1)), f32(sd[f"{a}.{no}.bias"])))
+        self.norm_out = norm("encoder.conv_norm_out")
+        # conv_out (C -> 2z) followed by quant_conv (1x1, 2z -> 2z): composed exactly into one 3x3 convolution
+        w_o, b_o = sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"]
+        if "quant_conv.weight" in sd:
+            wq1 = sd["quant_conv.weight"].reshape(sd["quant_conv.weight"].shape[0], -1)
+            w_o, b_o = torch.einsum("pc,cdkl->pdkl", wq1, w_o), wq1 @ b_o + sd["quant_conv.bias"]
+        self.n_moments = w_o.shape[0]
+        self.conv_out = (h16(pack_conv(w_o)), f32(b_o))
+
+    @torch.no_grad()
+    def encode_moments(self, image):
+        """image [B, 3, H, W] fp32 in [-1, 1] -> (mean, logvar) fp32 [B, z, H/8, W/8]; logvar clamped to [-30, 20]
+        (DiagonalGaussianDistribution)."""
+        ops = self.ops
+        x = image.to(self.dev, torch.float32).contiguous()
+        B, _, H, W = x.shape
+        if H != W:
+            raise RuntimeError("square images only (the refiner pass resizes to 1024 x 1024, sdxl_refinement.py:26)")
+        c0 = self.conv_in[0].shape[0]
+        h = torch.empty((B * H * H, c0), device=self.dev, dtype=torch.float16)
+        ops.gemm_launch(ops.gemm_desc(ops.nchw_to_nhwc8(x), self.conv_in[0], h, B * H * H, c0, 72, c0=8, lda0=8, taps=9,
+                                      hin=H, win=H, hout=H, wout=H, bias=self.conv_in[1], ldc=c0, splits=1))
+        for blk, down in self.downs:
+            for r in blk:
+                h = self._res(r, h, B, H)
+            if down is not None:
+                full = ops.conv3x3(h, down[0], B, H, H, bias=down[1])
+                C = full.shape[1]
+                h = full.view(B, H, H, C)[:, 1::2, 1::2].reshape(B * (H // 2) * (H // 2), C).contiguous()
+                H //= 2
+        h = self._res(self.mid[0], h, B, H)
+        h = self._attn(self.attn, h, B, H)
+        h = self._res(self.mid[1], h, B, H)
+        h = ops.groupnorm(h, B, H * H, self.groups, self.eps, self.norm_out[0], self.norm_out[1], True)
+        m = ops.conv3x3(h, self.conv_out[0], B, H, H, bias=self.conv_out[1])          # [B*H*H, 2z] fp16
+        m = m.view(B, H, H, self.n_moments).permute(0, 3, 1, 2).float()
+        mean, logvar = m.chunk(2, dim=1)
+        return mean.contiguous(), logvar.clamp(-30.0, 20.0).contiguous()
+
+    def decode(self, z):
+        raise RuntimeError("HipVAEEncoder encodes; use HipVAEDecoder for decode")

@@ -35,14 +35,34 @@ class UNetConfig:
     sample_size: int = 64
     prediction_type: str = "epsilon"
     gligen_positive_len: int = 768      # hard-coded at unet_2d_condition.py:572
+    # --- SDXL-refiner topology (generation/sdxl_refinement.py:13-15; [ext] diffusers' SDXL UNet2DConditionModel) ---
+    down_attn: Optional[Tuple[bool, ...]] = None   # per down block: CrossAttnDownBlock2D?  None = all but the last (SD)
+    up_attn: Optional[Tuple[bool, ...]] = None     # per up block: CrossAttnUpBlock2D?      None = all but the first (SD)
+    transformer_depth: int = 1                     # BasicTransformerBlocks per Transformer2DModel (transformer_layers_per_block)
+    addition_embed_type: Optional[str] = None      # "text_time": pooled text embedding + size / crop / score ids
+    addition_time_embed_dim: int = 256
+    projection_class_embeddings_input_dim: int = 0  # pooled width + 5 * addition_time_embed_dim for the refiner
 
     @property
     def time_embed_dim(self):
         return self.block_out_channels[0] * 4
 
+    @property
+    def pooled_dim(self):
+        """Width of `text_embeds` (the projected pooled output of the text tower) of a text_time model."""
+        return self.projection_class_embeddings_input_dim - 5 * self.addition_time_embed_dim
+
     def to_ref_kwargs(self):
         """kwargs for the reference's UNet2DConditionModel(...) (oracle harness)."""
-        return dict(sample_size=self.sample_size, in_channels=self.in_channels,
+        if self.transformer_depth != 1 or self.addition_embed_type is not None:
+            raise ValueError("the reference's UNet (diffusers 0.18 lineage) has neither multi-layer transformer blocks "
+                             "nor text_time conditioning")
+        extra = {}
+        if self.down_attn is not None:
+            extra["down_block_types"] = tuple("CrossAttnDownBlock2D" if a else "DownBlock2D" for a in self.down_attn)
+        if self.up_attn is not None:
+            extra["up_block_types"] = tuple("CrossAttnUpBlock2D" if a else "UpBlock2D" for a in self.up_attn)
+        return dict(**extra, sample_size=self.sample_size, in_channels=self.in_channels,
                     out_channels=self.out_channels, block_out_channels=self.block_out_channels,
                     layers_per_block=self.layers_per_block,
                     cross_attention_dim=self.cross_attention_dim,
@@ -64,6 +84,25 @@ CONFIGS = {
                             attention_head_dim=(1, 2, 4, 4), use_linear_projection=True, sample_size=32),
     "sd15": UNetConfig(name="sd15"),
     "sd14_gligen": UNetConfig(name="sd14_gligen", use_gated_attention=True),
+    # SDXL refiner 1.0 ([ext] stabilityai/stable-diffusion-xl-refiner-1.0 unet/config.json): outer blocks without
+    # attention, four transformer layers per attention block, every head 64 wide, OpenCLIP-bigG text width 1280,
+    # text_time conditioning over the 1280-wide pooled embedding + (orig h, w, crop top, left, aesthetic score)
+    "sdxl_refiner": UNetConfig(name="sdxl_refiner", block_out_channels=(384, 768, 1536, 1536), cross_attention_dim=1280,
+                               attention_head_dim=(6, 12, 24, 24), use_linear_projection=True, sample_size=128,
+                               down_attn=(False, True, True, False), up_attn=(False, True, True, False),
+                               transformer_depth=4, addition_embed_type="text_time", addition_time_embed_dim=256,
+                               projection_class_embeddings_input_dim=2560),
+    # the same topology in small: 64-wide heads, depth 2, pooled width 96 + 5 x 32 ids
+    "tiny_xl": UNetConfig(name="tiny_xl", block_out_channels=(64, 128, 256, 256), cross_attention_dim=128,
+                          attention_head_dim=(1, 2, 4, 4), use_linear_projection=True, sample_size=32,
+                          down_attn=(False, True, True, False), up_attn=(False, True, True, False),
+                          transformer_depth=2, addition_embed_type="text_time", addition_time_embed_dim=32,
+                          projection_class_embeddings_input_dim=256),
+    # topology-only variant the REFERENCE's own UNet class can build (depth 1, no added conditioning): pins the
+    # outer-blocks-without-attention wiring against /root/reference (tests/golden/unet_fwd_tiny_outer.npz)
+    "tiny_outer": UNetConfig(name="tiny_outer", block_out_channels=(64, 128, 256, 256), cross_attention_dim=128,
+                             attention_head_dim=(1, 2, 4, 4), use_linear_projection=True, sample_size=32,
+                             down_attn=(False, True, True, False), up_attn=(False, True, True, False)),
     "sd21": UNetConfig(name="sd21", cross_attention_dim=1024, attention_head_dim=(5, 10, 20, 20),
                        use_linear_projection=True, sample_size=96, prediction_type="v_prediction"),
 }
@@ -90,6 +129,7 @@ class AttnSpec:
     key: Tuple        # ("down", i, j, 0) — the attn_key of pipelines.py:12
     channels: int
     heads: int
+    depth: int = 1    # transformer_blocks.0 .. depth-1; the attn key of layer d is key[:3] + (d,)
 
     @property
     def head_dim(self):
@@ -115,20 +155,22 @@ def unet_blocks(cfg: UNetConfig) -> List[BlockSpec]:
     out_c = boc[0]
     for i in range(n):
         in_c, out_c = out_c, boc[i]
-        has_attn = i < n - 1           # down_block_types default: 3x CrossAttnDownBlock2D + DownBlock2D
+        # down_block_types default: 3x CrossAttnDownBlock2D + DownBlock2D
+        has_attn = cfg.down_attn[i] if cfg.down_attn is not None else i < n - 1
         b = BlockSpec("down", i, channels=out_c, level=i)
         for j in range(cfg.layers_per_block):
             b.resnets.append(ResnetSpec(f"down_blocks.{i}.resnets.{j}", in_c if j == 0 else out_c, 0, out_c))
             if has_attn:
                 b.attns.append(AttnSpec(f"down_blocks.{i}.attentions.{j}", ("down", i, j, 0), out_c,
-                                        cfg.attention_head_dim[i]))
+                                        cfg.attention_head_dim[i], cfg.transformer_depth))
         if i < n - 1:
             b.sampler = f"down_blocks.{i}.downsamplers.0.conv"
         blocks.append(b)
     mid = BlockSpec("mid", 0, channels=boc[-1], level=n - 1)
     mid.resnets = [ResnetSpec("mid_block.resnets.0", boc[-1], 0, boc[-1]),
                    ResnetSpec("mid_block.resnets.1", boc[-1], 0, boc[-1])]
-    mid.attns = [AttnSpec("mid_block.attentions.0", ("mid", 0, 0, 0), boc[-1], cfg.attention_head_dim[-1])]
+    mid.attns = [AttnSpec("mid_block.attentions.0", ("mid", 0, 0, 0), boc[-1], cfg.attention_head_dim[-1],
+                          cfg.transformer_depth)]
     blocks.append(mid)
     rev = list(reversed(boc))
     rev_heads = list(reversed(cfg.attention_head_dim))
@@ -137,7 +179,8 @@ def unet_blocks(cfg: UNetConfig) -> List[BlockSpec]:
         prev_out = out_c
         out_c = rev[i]
         in_c = rev[min(i + 1, n - 1)]
-        has_attn = i > 0               # up_block_types default: UpBlock2D + 3x CrossAttnUpBlock2D
+        # up_block_types default: UpBlock2D + 3x CrossAttnUpBlock2D
+        has_attn = cfg.up_attn[i] if cfg.up_attn is not None else i > 0
         b = BlockSpec("up", i, channels=out_c, level=n - 1 - i)
         nl = cfg.layers_per_block + 1
         for j in range(nl):
@@ -145,7 +188,8 @@ def unet_blocks(cfg: UNetConfig) -> List[BlockSpec]:
             hid = prev_out if j == 0 else out_c
             b.resnets.append(ResnetSpec(f"up_blocks.{i}.resnets.{j}", hid + skip, skip, out_c))
             if has_attn:
-                b.attns.append(AttnSpec(f"up_blocks.{i}.attentions.{j}", ("up", i, j, 0), out_c, rev_heads[i]))
+                b.attns.append(AttnSpec(f"up_blocks.{i}.attentions.{j}", ("up", i, j, 0), out_c, rev_heads[i],
+                                        cfg.transformer_depth))
         if i < n - 1:
             b.sampler = f"up_blocks.{i}.upsamplers.0.conv"
         blocks.append(b)
@@ -192,6 +236,11 @@ def param_shapes(cfg: UNetConfig) -> Dict[str, Tuple[int, ...]]:
     p["time_embedding.linear_1.bias"] = (ted,)
     p["time_embedding.linear_2.weight"] = (ted, ted)
     p["time_embedding.linear_2.bias"] = (ted,)
+    if cfg.addition_embed_type == "text_time":          # [ext] TimestepEmbedding(projection_class_embeddings_input_dim, ted)
+        p["add_embedding.linear_1.weight"] = (ted, cfg.projection_class_embeddings_input_dim)
+        p["add_embedding.linear_1.bias"] = (ted,)
+        p["add_embedding.linear_2.weight"] = (ted, ted)
+        p["add_embedding.linear_2.bias"] = (ted,)
     for b in unet_blocks(cfg):
         for r in b.resnets:
             _norm(p, f"{r.prefix}.norm1", r.cin)
@@ -211,23 +260,24 @@ def param_shapes(cfg: UNetConfig) -> Dict[str, Tuple[int, ...]]:
             proj_shape = (C, C) if cfg.use_linear_projection else (C, C, 1, 1)
             p[f"{a.prefix}.proj_in.weight"] = proj_shape
             p[f"{a.prefix}.proj_in.bias"] = (C,)
-            t = f"{a.prefix}.transformer_blocks.0"
-            _norm(p, f"{t}.norm1", C)
-            _attention_params(p, f"{t}.attn1", C, C, C)
-            _norm(p, f"{t}.norm2", C)
-            _attention_params(p, f"{t}.attn2", C, cfg.cross_attention_dim, C)
-            _norm(p, f"{t}.norm3", C)
-            _ff_params(p, f"{t}.ff", C)
-            if cfg.use_gated_attention:
-                f = f"{t}.fuser"
-                p[f"{f}.linear.weight"] = (C, cfg.cross_attention_dim)
-                p[f"{f}.linear.bias"] = (C,)
-                _attention_params(p, f"{f}.attn", C, C, C)
-                _ff_params(p, f"{f}.ff", C)
-                _norm(p, f"{f}.norm1", C)
-                _norm(p, f"{f}.norm2", C)
-                p[f"{f}.alpha_attn"] = ()
-                p[f"{f}.alpha_dense"] = ()
+            for d in range(a.depth):
+                t = f"{a.prefix}.transformer_blocks.{d}"
+                _norm(p, f"{t}.norm1", C)
+                _attention_params(p, f"{t}.attn1", C, C, C)
+                _norm(p, f"{t}.norm2", C)
+                _attention_params(p, f"{t}.attn2", C, cfg.cross_attention_dim, C)
+                _norm(p, f"{t}.norm3", C)
+                _ff_params(p, f"{t}.ff", C)
+                if cfg.use_gated_attention:
+                    f = f"{t}.fuser"
+                    p[f"{f}.linear.weight"] = (C, cfg.cross_attention_dim)
+                    p[f"{f}.linear.bias"] = (C,)
+                    _attention_params(p, f"{f}.attn", C, C, C)
+                    _ff_params(p, f"{f}.ff", C)
+                    _norm(p, f"{f}.norm1", C)
+                    _norm(p, f"{f}.norm2", C)
+                    p[f"{f}.alpha_attn"] = ()
+                    p[f"{f}.alpha_dense"] = ()
             p[f"{a.prefix}.proj_out.weight"] = proj_shape
             p[f"{a.prefix}.proj_out.bias"] = (C,)
         if b.sampler:

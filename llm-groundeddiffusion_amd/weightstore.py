@@ -117,6 +117,9 @@ class WeightStore:
         self._e32("conv_in.b", (c0,))
         self._lin("time_embedding.linear_1", ted, c0)
         self._lin("time_embedding.linear_2", ted, ted)
+        if cfg.addition_embed_type == "text_time":
+            self._lin("add_embedding.linear_1", ted, cfg.projection_class_embeddings_input_dim)
+            self._lin("add_embedding.linear_2", ted, ted)
         toff = 0
         for b in self.blocks:
             for r in b.resnets:
@@ -132,28 +135,29 @@ class WeightStore:
             for a in b.attns:
                 bw = _needs_bwd(a.prefix)
                 C = a.channels
-                t = f"{a.prefix}.transformer_blocks.0"
                 self._normp(f"{a.prefix}.norm", C)
                 self._lin(f"{a.prefix}.proj_in", C, C, bwd=bw)
-                self._normp(f"{t}.norm1", C)
-                self._lin(f"{t}.attn1.qkv", 3 * C, C, bias=False, bwd=bw)
-                self._lin(f"{t}.attn1.to_out.0", C, C, bwd=bw)
-                self._normp(f"{t}.norm2", C)
-                self._lin(f"{t}.attn2.to_q", C, C, bias=False, bwd=bw)
-                self._lin(f"{t}.attn2.kv", 2 * C, cx, bias=False)
-                self._lin(f"{t}.attn2.to_out.0", C, C, bwd=bw)
-                self._normp(f"{t}.norm3", C)
-                self._lin(f"{t}.ff.net.0.proj", 8 * C, C, bwd=bw)
-                self._lin(f"{t}.ff.net.2", C, 4 * C, bwd=bw)
-                if cfg.use_gated_attention:
-                    f = f"{t}.fuser"
-                    self._lin(f"{f}.linear", C, cx)
-                    self._normp(f"{f}.norm1", C)
-                    self._lin(f"{f}.attn.qkv", 3 * C, C, bias=False, bwd=bw)
-                    self._lin(f"{f}.attn.to_out.0", C, C, bwd=bw)
-                    self._normp(f"{f}.norm2", C)
-                    self._lin(f"{f}.ff.net.0.proj", 8 * C, C, bwd=bw)
-                    self._lin(f"{f}.ff.net.2", C, 4 * C, bwd=bw)
+                for d in range(a.depth):
+                    t = f"{a.prefix}.transformer_blocks.{d}"
+                    self._normp(f"{t}.norm1", C)
+                    self._lin(f"{t}.attn1.qkv", 3 * C, C, bias=False, bwd=bw)
+                    self._lin(f"{t}.attn1.to_out.0", C, C, bwd=bw)
+                    self._normp(f"{t}.norm2", C)
+                    self._lin(f"{t}.attn2.to_q", C, C, bias=False, bwd=bw)
+                    self._lin(f"{t}.attn2.kv", 2 * C, cx, bias=False)
+                    self._lin(f"{t}.attn2.to_out.0", C, C, bwd=bw)
+                    self._normp(f"{t}.norm3", C)
+                    self._lin(f"{t}.ff.net.0.proj", 8 * C, C, bwd=bw)
+                    self._lin(f"{t}.ff.net.2", C, 4 * C, bwd=bw)
+                    if cfg.use_gated_attention:
+                        f = f"{t}.fuser"
+                        self._lin(f"{f}.linear", C, cx)
+                        self._normp(f"{f}.norm1", C)
+                        self._lin(f"{f}.attn.qkv", 3 * C, C, bias=False, bwd=bw)
+                        self._lin(f"{f}.attn.to_out.0", C, C, bwd=bw)
+                        self._normp(f"{f}.norm2", C)
+                        self._lin(f"{f}.ff.net.0.proj", 8 * C, C, bwd=bw)
+                        self._lin(f"{f}.ff.net.2", C, 4 * C, bwd=bw)
                 self._lin(f"{a.prefix}.proj_out", C, C, bwd=bw)
             if b.sampler:
                 self._conv(b.sampler, b.channels, b.channels, _needs_bwd(b.sampler))
@@ -168,7 +172,7 @@ class WeightStore:
             self._lin("position_net.linears.4", cx, 512)
             self._e32("position_net.null_positive_feature", (cfg.gligen_positive_len,))
             self._e32("position_net.null_position_feature", (64,))
-            self._e32("fuser_gates", (2 * sum(len(b.attns) for b in self.blocks),))
+            self._e32("fuser_gates", (2 * sum(a.depth for b in self.blocks for a in b.attns),))
 
     # ------------------------------------------------------------------------------------------
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
@@ -213,6 +217,9 @@ class WeightStore:
         f32["conv_in.b"] = sd["conv_in.bias"]
         lin("time_embedding.linear_1", "time_embedding.linear_1")
         lin("time_embedding.linear_2", "time_embedding.linear_2")
+        if cfg.addition_embed_type == "text_time":
+            lin("add_embedding.linear_1", "add_embedding.linear_1")
+            lin("add_embedding.linear_2", "add_embedding.linear_2")
         tw, tb = [], []
         gates = []
         for b in self.blocks:
@@ -228,34 +235,35 @@ class WeightStore:
                 tb.append(sd[f"{r.prefix}.time_emb_proj.bias"])
             for a in b.attns:
                 bw = _needs_bwd(a.prefix)
-                t = f"{a.prefix}.transformer_blocks.0"
                 normp(f"{a.prefix}.norm")
                 lin(f"{a.prefix}.proj_in", f"{a.prefix}.proj_in", bwd=bw)
-                normp(f"{t}.norm1")
-                qkv = torch.cat([sd[f"{t}.attn1.to_q.weight"], sd[f"{t}.attn1.to_k.weight"],
-                                 sd[f"{t}.attn1.to_v.weight"]], dim=0)
-                lin(f"{t}.attn1.qkv", None, bias=False, bwd=bw, w=qkv)
-                lin(f"{t}.attn1.to_out.0", f"{t}.attn1.to_out.0", bwd=bw)
-                normp(f"{t}.norm2")
-                lin(f"{t}.attn2.to_q", f"{t}.attn2.to_q", bias=False, bwd=bw)
-                kv = torch.cat([sd[f"{t}.attn2.to_k.weight"], sd[f"{t}.attn2.to_v.weight"]], dim=0)
-                lin(f"{t}.attn2.kv", None, bias=False, w=kv)
-                lin(f"{t}.attn2.to_out.0", f"{t}.attn2.to_out.0", bwd=bw)
-                normp(f"{t}.norm3")
-                geglu(f"{t}.ff.net.0.proj", f"{t}.ff.net.0.proj", bw)
-                lin(f"{t}.ff.net.2", f"{t}.ff.net.2", bwd=bw)
-                if cfg.use_gated_attention:
-                    f = f"{t}.fuser"
-                    lin(f"{f}.linear", f"{f}.linear")
-                    normp(f"{f}.norm1")
-                    qkv = torch.cat([sd[f"{f}.attn.to_q.weight"], sd[f"{f}.attn.to_k.weight"],
-                                     sd[f"{f}.attn.to_v.weight"]], dim=0)
-                    lin(f"{f}.attn.qkv", None, bias=False, bwd=bw, w=qkv)
-                    lin(f"{f}.attn.to_out.0", f"{f}.attn.to_out.0", bwd=bw)
-                    normp(f"{f}.norm2")
-                    geglu(f"{f}.ff.net.0.proj", f"{f}.ff.net.0.proj", bw)
-                    lin(f"{f}.ff.net.2", f"{f}.ff.net.2", bwd=bw)
-                    gates += [float(sd[f"{f}.alpha_attn"].tanh()), float(sd[f"{f}.alpha_dense"].tanh())]
+                for d in range(a.depth):
+                    t = f"{a.prefix}.transformer_blocks.{d}"
+                    normp(f"{t}.norm1")
+                    qkv = torch.cat([sd[f"{t}.attn1.to_q.weight"], sd[f"{t}.attn1.to_k.weight"],
+                                     sd[f"{t}.attn1.to_v.weight"]], dim=0)
+                    lin(f"{t}.attn1.qkv", None, bias=False, bwd=bw, w=qkv)
+                    lin(f"{t}.attn1.to_out.0", f"{t}.attn1.to_out.0", bwd=bw)
+                    normp(f"{t}.norm2")
+                    lin(f"{t}.attn2.to_q", f"{t}.attn2.to_q", bias=False, bwd=bw)
+                    kv = torch.cat([sd[f"{t}.attn2.to_k.weight"], sd[f"{t}.attn2.to_v.weight"]], dim=0)
+                    lin(f"{t}.attn2.kv", None, bias=False, w=kv)
+                    lin(f"{t}.attn2.to_out.0", f"{t}.attn2.to_out.0", bwd=bw)
+                    normp(f"{t}.norm3")
+                    geglu(f"{t}.ff.net.0.proj", f"{t}.ff.net.0.proj", bw)
+                    lin(f"{t}.ff.net.2", f"{t}.ff.net.2", bwd=bw)
+                    if cfg.use_gated_attention:
+                        f = f"{t}.fuser"
+                        lin(f"{f}.linear", f"{f}.linear")
+                        normp(f"{f}.norm1")
+                        qkv = torch.cat([sd[f"{f}.attn.to_q.weight"], sd[f"{f}.attn.to_k.weight"],
+                                         sd[f"{f}.attn.to_v.weight"]], dim=0)
+                        lin(f"{f}.attn.qkv", None, bias=False, bwd=bw, w=qkv)
+                        lin(f"{f}.attn.to_out.0", f"{f}.attn.to_out.0", bwd=bw)
+                        normp(f"{f}.norm2")
+                        geglu(f"{f}.ff.net.0.proj", f"{f}.ff.net.0.proj", bw)
+                        lin(f"{f}.ff.net.2", f"{f}.ff.net.2", bwd=bw)
+                        gates += [float(sd[f"{f}.alpha_attn"].tanh()), float(sd[f"{f}.alpha_dense"].tanh())]
                 lin(f"{a.prefix}.proj_out", f"{a.prefix}.proj_out", bwd=bw)
             if b.sampler:
                 conv(b.sampler, _needs_bwd(b.sampler))
@@ -297,10 +305,11 @@ class WeightStore:
             i = 0
             for b in self.blocks:
                 for a in b.attns:
-                    t = f"{a.prefix}.transformer_blocks.0.fuser"
-                    self.scalars[f"{t}.alpha_attn"] = g[i]
-                    self.scalars[f"{t}.alpha_dense"] = g[i + 1]
-                    i += 2
+                    for d in range(a.depth):
+                        t = f"{a.prefix}.transformer_blocks.{d}.fuser"
+                        self.scalars[f"{t}.alpha_attn"] = g[i]
+                        self.scalars[f"{t}.alpha_dense"] = g[i + 1]
+                        i += 2
 
     def nbytes(self):
         return self.arena16.numel() * 2 + self.arena32.numel() * 4
