@@ -7,6 +7,10 @@ A "step" = one pass of the hot path over one batch of cached layouts on every ra
 
   --workload batch4 (default; BASELINE config[1] "batch=4 cached layouts"): `--layouts` (4) two-box layouts
       of the lmd_v0.1 cache per rank per step.
+  --workload sdxl_refiner (BASELINE config[4], generate.py --sdxl --sdxl-step-ratio 0.3): `--layouts` (4) images per rank
+      per step through the SDXL-refiner img2img post-pass at 1024 x 1024 (generation/sdxl_refinement.py: VAE encode,
+      int(50 x 0.3) = 15 CFG + Euler steps of the 2.26 B-parameter refiner UNet, VAE decode), seeded random weights of
+      the real architectures, synthetic input images and text embeddings.
   --workload lmd_v0.1 (BASELINE config[3]): `--prompts` (100) layouts taken evenly from the 400-entry
       lmd_v0.1 cache (0..5 boxes each), partitioned over the ranks by cost (N+1 generations per layout,
       longest-processing-time first; the reference's manual version is generate.py:23-25,243-250), global
@@ -154,12 +158,150 @@ def respawn(n):
     return subprocess.call(cmd, env=env)
 
 
+def main_sdxl(args):
+    """BASELINE config[4]: the SDXL-refiner post-pass (generation/sdxl_refinement.py), `--layouts` images per rank per
+    step; the same contract line.  Images shard over ranks and lanes with no collective in the loop."""
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import lgd_amd  # noqa: F401
+    from lgd_amd import dist as ldist, ops, sdxl, vae, weights
+    from lgd_amd.lanes import LanePool, make_lanes
+    from lgd_amd.unet import UNetEngine
+    cfg = weights.CONFIGS[args.config]
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        ldist.init(backend="nccl")
+    eng = UNetEngine(cfg, dev, weights.synth_state_dict(cfg, 0) if rank == 0 else None, max_text_batch=2)
+    bcast_s = ldist.broadcast_weights(eng.w, src=0) if world > 1 else 0.0
+    tiny = cfg.block_out_channels[0] < 320
+    vsd = vae.synth_aekl_state_dict((64, 128, 128, 128) if tiny else (128, 256, 512, 512), 1 if tiny else 2, seed=0)
+    side = 8 * cfg.sample_size                                          # 1024 for the refiner
+    T, ratio, gs = args.num_inference_steps, args.sdxl_step_ratio, 5.0
+
+    def make(e):
+        return sdxl.SDXLRefiner(e, vae.HipVAEEncoder(vsd, dev), vae.HipVAEDecoder(vsd, dev))
+    lanes = make_lanes(eng, max(1, args.lanes), make)
+    pool = LanePool(lanes, device=dev)
+    g = torch.Generator().manual_seed(1000 + rank)
+    n_img = args.layouts
+    images = [(torch.rand((1, 3, side, side), generator=g) * 2 - 1).to(dev) for _ in range(n_img)]
+    embeds = [(torch.randn((2, 77, cfg.cross_attention_dim), generator=g), torch.randn((2, cfg.pooled_dim), generator=g))
+              for _ in range(n_img)]
+
+    def one(lane, i):
+        return lane.sampler.refine(images[i], embeds[i][0], embeds[i][1], seed=rank * n_img + i, strength=ratio,
+                                   num_inference_steps=T, guidance_scale=gs, output="float")
+    t_pre = time.perf_counter()
+    for k in range(len(lanes)):                                         # plans + graph of every lane, one by one
+        pool.map(one, [0], pin=[k])
+    torch.cuda.synchronize()
+    prebuild_s = time.perf_counter() - t_pre
+    for _ in range(args.warmup):
+        pool.map(one, list(range(n_img)))
+    ldist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs = pool.map(one, list(range(n_img)))
+    torch.cuda.synchronize()
+    busy = time.perf_counter() - t0
+    ldist.barrier()
+    dt = ldist.max_over_ranks(time.perf_counter() - t0)
+    per_rank_busy = ldist.gather_floats(busy)
+    pool.close()
+    ldist.shutdown()
+    if rank != 0:
+        return
+    assert all(bool(torch.isfinite(o).all()) for o in outs)
+    n_images = args.steps * n_img * world
+    n_run = T - lanes[0].sampler.scheduler.img2img_start(T, ratio)
+    # algorithmic work and the dominant kernel: ONE image eagerly (no graph) on lane 0 with HIP events around every launch
+    roofline, tf = None, None
+    if not args.no_roofline:
+        r0 = lanes[0].sampler
+        r0.use_graphs = False
+        r0.refine(images[0], *embeds[0], seed=0, strength=ratio, num_inference_steps=T, output="float")
+        torch.cuda.synchronize()
+        prof = ops.LaunchProfiler(max_records=200000)
+        ops.PROFILER = prof
+        r0.refine(images[0], *embeds[0], seed=0, strength=ratio, num_inference_steps=T, output="float")
+        ops.PROFILER = None
+        agg = prof.summary()
+        tf = sum(v["flops"] for v in agg.values()) / 1e12
+        name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        ach = a["flops"] / (a["ms"] * 1e-3)
+        gem = [v for k, v in agg.items() if k.startswith("gemm")]
+        roofline = dict(bound="mfma", kernel=name, achieved=round(ach / 1e12, 2), peak=MFMA_PEAK_F16 / 1e12, unit="TFLOP/s",
+                        frac=round(ach / MFMA_PEAK_F16, 4), traffic=None, avg_launch_us=round(a["ms"] * 1e3 / a["n"], 2),
+                        launches_per_image=int(a["n"]), est_ms_per_image=round(a["ms"], 1),
+                        traffic_note="no PMC pass for this workload", traffic_source=None,
+                        method="HIP events around each launch of ONE image refined eagerly right after the timed region "
+                               "(the timed region replays one hipGraph per step on config.lanes_per_gpu streams)",
+                        all_gemm_tflops=round(sum(v["flops"] for v in gem) / max(sum(v["ms"] for v in gem) * 1e-3, 1e-12) / 1e12, 1),
+                        all_kernels={k: dict(ms_per_image=round(v["ms"], 1), launches_per_image=int(v["n"]),
+                                             tflops=round(v["flops"] / max(v["ms"] * 1e-3, 1e-12) / 1e12, 1))
+                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]})
+    res = dict(metric=f"images/sec (SDXL refiner img2img, step ratio {ratio}, {side}^2)", value=round(n_images / dt, 4),
+               unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt * 1e3 / args.steps, 1),
+               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="fp16", data="synthetic",
+               config=dict(workload=f"SDXL-refiner post-pass (generation/sdxl_refinement.py), {n_img} images/GPU/step, "
+                                    f"{side}x{side}, {n_run} of {T} Euler steps (ratio {ratio}), guidance {gs}, {args.config} "
+                                    f"({weights.num_params(cfg) / 1e9:.2f} B-parameter UNet, SD/SDXL VAE encoder + decoder, "
+                                    "seeded random weights), VAE encode and decode included",
+                           images_per_gpu=n_img, num_inference_steps=T, steps_run=n_run, parallelism=f"dp{world}",
+                           rccl_ranks=world, lanes_per_gpu=len(lanes), gemm_tuning=ops.TUNING_MODE,
+                           algorithmic_tflop_per_image=round(tf, 2) if tf else None,
+                           weight_broadcast_s=round(bcast_s, 3), prebuild_s=round(prebuild_s, 2),
+                           per_rank_busy_s=[round(b, 3) for b in per_rank_busy],
+                           per_rank_idle_s=[round(max(dt - b, 0.0), 3) for b in per_rank_busy]),
+               roofline=roofline)
+    if tf:
+        res["config"]["whole_path_frac_of_mfma_peak"] = round(tf * 1e12 * (n_images / dt) / world / MFMA_PEAK_F16, 4)
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_sdxl(cfg, vsd, side, n_run, tf)
+    print(json.dumps(res))
+
+
+def cpu_baseline_sdxl(cfg, vsd, side, n_run, tflop_per_image):
+    """oracle/restate_sdxl.py (fp32, host threads) on a bounded sample: ONE UNet call of the CFG pair at a reduced
+    latent size, scaled to the full pass by algorithmic work."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import restate_sdxl as X
+        from lgd_amd import weights
+        n_thr = min(32, os.cpu_count() or 1)
+        torch.set_num_threads(n_thr)
+        sd = weights.synth_state_dict(cfg, 0)
+        Ls = min(cfg.sample_size, 32)
+        x = torch.randn(2, 4, Ls, Ls)
+        ehs, pooled = torch.randn(2, 77, cfg.cross_attention_dim), torch.randn(2, cfg.pooled_dim)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            X.unet_forward_xl(sd, cfg, x, 281.0, ehs, dict(text_embeds=pooled, time_ids=X.add_time_ids(side, side)))
+        dt = time.perf_counter() - t0
+        scale = (cfg.sample_size / Ls) ** 2                     # convolutions / projections; attention grows faster
+        per_image = dt * scale * n_run
+        return dict(value=1.0 / per_image, unit="images/s", cores=n_thr, kind="port",
+                    sample=f"oracle/restate_sdxl.py fp32 on {n_thr} host threads: one CFG-pair UNet call at {Ls}x{Ls} latents "
+                           f"{dt:.1f}s, scaled by pixel count to {cfg.sample_size}x{cfg.sample_size} x {n_run} steps (lower bound: "
+                           "self-attention grows quadratically; VAE excluded)")
+    except Exception as e:   # reported, never gating
+        return dict(value=None, unit="images/s", cores=os.cpu_count(), kind="port", sample=f"failed: {e}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="batch4", choices=["batch4", "lmd_v0.1", "backward_guidance"])
+    ap.add_argument("--workload", default="batch4", choices=["batch4", "lmd_v0.1", "backward_guidance", "sdxl_refiner"])
+    ap.add_argument("--sdxl-step-ratio", type=float, default=0.3, help="sdxl_refiner: img2img strength (generate.py:52)")
     ap.add_argument("--layouts", type=int, default=4, help="batch4: cached layouts per rank per step")
     ap.add_argument("--prompts", type=int, default=100, help="lmd_v0.1: prompts of the cache (whole job)")
     ap.add_argument("--config", default=None, help="default: sd14_gligen (sd21 for --workload backward_guidance)")
@@ -180,7 +322,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn(args.gpus))
     if args.config is None:
-        args.config = "sd21" if args.workload == "backward_guidance" else "sd14_gligen"
+        args.config = {"backward_guidance": "sd21", "sdxl_refiner": "sdxl_refiner"}.get(args.workload, "sd14_gligen")
+    if args.workload == "sdxl_refiner":
+        return main_sdxl(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
