@@ -85,6 +85,10 @@ class HipCLIPTextEncoder:
         cfg = self.cfg
         ids = input_ids.to(self.dev)
         B, S = ids.shape
+        if S > cfg.max_position_embeddings:
+            raise RuntimeError(f"{S} tokens exceed the text tower's {cfg.max_position_embeddings} positions")
+        if attention_mask is not None and not bool(torch.as_tensor(attention_mask).bool().all()):
+            raise NotImplementedError("padding masks are not applied (the reference passes ids only, models/models.py:73-78)")
         C, H = cfg.hidden_size, cfg.num_attention_heads
         d = C // H
         x = (self.tok_emb[ids] + self.pos_emb[:S].unsqueeze(0)).reshape(B * S, C).to(F16).contiguous()

@@ -85,13 +85,17 @@ def load_sd(key="runwayml/stable-diffusion-v1-5", use_fp16=False, load_inverse_s
                               prediction_type=sched_cfg.get("prediction_type", "epsilon"))
     vae = AutoencoderKL.from_pretrained(key, subfolder="vae").to(torch_device)
     tok = CLIPTokenizer.from_pretrained(key, subfolder="tokenizer")
+    import os as _os
     from lgd_amd.clip import from_hf as _hip_text_encoder
-    te = _hip_text_encoder(CLIPTextModel.from_pretrained(key, subfolder="text_encoder"), torch_device)   # HIP kernels
+    te = CLIPTextModel.from_pretrained(key, subfolder="text_encoder")
+    if _os.environ.get("LGD_HF_TEXT", "0") == "1":       # keep the Hugging Face tower (A/B against the fp16-compute HIP one)
+        te = te.to(torch_device)
+    else:
+        te = _hip_text_encoder(te, torch_device)         # HIP kernels: fp16 compute, 2-3e-3 of the fp32 tower's states
 
     class _HFVae:
         def decode(self, z):
             return vae.decode(z.to(vae.dtype)).sample
-    import os as _os
     if _os.environ.get("LGD_HF_VAE", "0") == "1":
         dec = _HFVae()
     else:

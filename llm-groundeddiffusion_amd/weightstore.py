@@ -50,6 +50,9 @@ def pack_conv_dgrad(w: torch.Tensor) -> torch.Tensor:
 
 class WeightStore:
     def __init__(self, cfg: UNetConfig, device):
+        if cfg.in_channels > 4:
+            raise ValueError(f"in_channels = {cfg.in_channels}: conv_in runs as an implicit GEMM over an 8-channel copy of the "
+                             "latents (value + fp16 rounding remainder of <= 4 channels); inpainting UNets are not supported")
         self.cfg = cfg
         self.device = device
         self.blocks = unet_blocks(cfg)
