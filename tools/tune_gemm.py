@@ -18,7 +18,8 @@ cfg_name = sys.argv[1] if len(sys.argv) > 1 else "sd14_gligen"
 out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "llm-groundeddiffusion_amd", "tuning_gfx950.json")
 dev = torch.device("cuda:0")
 cfg = weights.CONFIGS[cfg_name]
-eng = UNetEngine(cfg, dev, None)      # zero weights are fine for timing shapes
+XL = cfg.addition_embed_type == "text_time"        # SDXL-refiner pass: shapes of one CFG UNet call + VAE encode / decode
+eng = UNetEngine(cfg, dev, None, **(dict(max_text_batch=2) if XL else {}))      # zero weights are fine for timing shapes
 eng.w.refresh_scalars()
 L = cfg.sample_size
 
@@ -32,12 +33,24 @@ def rec(d, tag=None, flops=None):
     shapes[key]["count"] += 1
     return orig(d)
 ops.gemm_launch = rec
-sm = LMDSampler(eng, use_graphs=False)
-eng.prepare_timesteps([500]); eng.set_step(0)
-batches = [int(x) for x in os.environ.get("LGD_TUNE_BATCHES", "1,2,4,8").split(",")]
-for kind, fz, nb, fn in sm.profile_passes(L, 50, cfg.use_gated_attention, main_batches=batches,
-                                          guide_batches=[b for b in batches if b <= 4]):
-    fn()
+if XL:
+    from lgd_amd import vae
+    eng.prepare_text(torch.zeros(2, 77, cfg.cross_attention_dim))
+    eng.prepare_timesteps([281.0], dict(text_embeds=torch.zeros(2, cfg.pooled_dim), time_ids=torch.zeros(2, 5)))
+    eng.set_step(0)
+    plan = eng.plan(2, L)
+    for _ in range(15):                      # 15 Euler steps per image against one encode + one decode
+        plan.forward()
+    vsd = vae.synth_aekl_state_dict()
+    vae.HipVAEEncoder(vsd, dev).encode_moments(torch.zeros(1, 3, 8 * L, 8 * L))
+    vae.HipVAEDecoder(vsd, dev).decode(torch.zeros(1, 4, L, L))
+else:
+    sm = LMDSampler(eng, use_graphs=False)
+    eng.prepare_timesteps([500]); eng.set_step(0)
+    batches = [int(x) for x in os.environ.get("LGD_TUNE_BATCHES", "1,2,4,8").split(",")]
+    for kind, fz, nb, fn in sm.profile_passes(L, 50, cfg.use_gated_attention, main_batches=batches,
+                                              guide_batches=[b for b in batches if b <= 4]):
+        fn()
 torch.cuda.synchronize()
 ops.gemm_launch = orig
 print(f"{len(shapes)} distinct GEMM shapes")
