@@ -68,6 +68,28 @@ def test_text_time_multilayer_unet_vs_oracle(dev):
     assert relerr(ref2, ref) > 5e-2
 
 
+def test_refiner_full_width_forward_vs_oracle(dev):
+    """The 2.26 B-parameter refiner configuration itself (384 / 768 / 1536 channels, 4 transformer layers per block, 12 / 24
+    heads of 64, 1280-wide text states, 2560-wide added conditioning) at 32 x 32 latents so that the fp32 oracle finishes
+    in seconds on the host: every weight tensor, packing rule and launch shape family of the 1024^2 pass."""
+    cfg = weights.CONFIGS["sdxl_refiner"]
+    sd = weights.synth_state_dict(cfg, 0)
+    eng = UNetEngine(cfg, dev, sd, max_text_batch=2)
+    x, ehs = rnd(2, 4, L, L, seed=1), rnd(2, 77, cfg.cross_attention_dim, seed=2)
+    added = dict(text_embeds=rnd(2, cfg.pooled_dim, seed=3), time_ids=X.add_time_ids(1024, 1024))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = X.unet_forward_xl(sd, cfg, x, 281.0, ehs, added)
+    plan = eng.plan(2, L)
+    eng.prepare_text(ehs)
+    eng.prepare_timesteps([281.0], added)
+    eng.set_step(0)
+    plan.forward(x.to(dev))
+    gate("sdxl_refiner (full width) eps vs oracle", relerr(plan.eps_out, ref), 1.5e-2)
+    del eng, plan
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("c0,c1", [(384, 0), (768, 0), (1536, 1536), (1536, 768), (768, 384), (384, 384)])
 def test_groupnorm_refiner_widths(dev, c0, c1):
     """32 groups over 384 ... 3072 channels (12 ... 96 per group, two-source concat): the refiner's resnets."""
