@@ -74,13 +74,10 @@ def refine(image, spec, refine_seed, refinement_step_ratio=0.5):
     """sdxl_refinement.py:24-30.  image: uint8 [H, W, 3]; returns a PIL image like the reference."""
     if pipe is None:
         raise RuntimeError("call init() (or init_synthetic()) first")
-    overall_prompt = spec["prompt"]
-    extra_neg_prompt = spec["extra_neg_prompt"]
-    image = Image.fromarray(image).resize((REFINE_SIZE, REFINE_SIZE), Image.LANCZOS)
-    negative_prompt = extra_neg_prompt + ", " + sdxl_negative_prompt
-    kw = {}
+    # sdxl_refinement.py:24-29: LANCZOS resize to 1024 x 1024, the layout's own negative prompt in front of the style list
+    resized = np.asarray(Image.fromarray(image).resize((REFINE_SIZE,) * 2, Image.LANCZOS))
+    text = dict(prompt=spec["prompt"], negative_prompt=", ".join([spec["extra_neg_prompt"], sdxl_negative_prompt]))
     if "sdxl_prompt_embeds" in spec:          # cached text side (no tokenizer / text tower offline)
-        kw = dict(prompt_embeds=spec["sdxl_prompt_embeds"], pooled=spec["sdxl_pooled"])
-    out = pipe.refine(np.asarray(image), prompt=overall_prompt, negative_prompt=negative_prompt, seed=refine_seed,
-                      strength=refinement_step_ratio, **kw)
+        text.update(prompt_embeds=spec["sdxl_prompt_embeds"], pooled=spec["sdxl_pooled"])
+    out = pipe.refine(resized, seed=refine_seed, strength=refinement_step_ratio, **text)
     return Image.fromarray(out)
