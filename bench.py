@@ -366,15 +366,31 @@ def main():
         bcast_s = ldist.broadcast_weights(ws, src=0, chunk_bytes=8 << 20)
         ldist.barrier()
         t0 = time.perf_counter()
-        my_cost = sum(layout_cost(l.n_boxes, args.num_inference_steps) for l in lays)
-        time.sleep(1e-4 * my_cost)
+        # the rank's lanes as host threads: the same hand-out as the GPU path (whole steps, or one cost-balanced share
+        # of the rank's layouts per lane), each job "running" for a time proportional to its algorithmic cost
+        from lgd_amd.lanes import Lane, LanePool
+        costs = [layout_cost(l.n_boxes, args.num_inference_steps) for l in lays]
+        my_cost = sum(costs)
+        n_lanes = max(1, args.lanes)
+        if args.workload == "lmd_v0.1" and n_lanes > 1:
+            jobs = [[costs[j] for j in sh] for sh in partition_by_cost(costs, n_lanes)]
+        else:
+            jobs = [costs] * max(1, args.steps)
+        lane_cost = [0.0] * n_lanes
+
+        def dry(lane, job):
+            time.sleep(1e-4 * sum(job))
+            lane_cost[lane.index] += sum(job)
+        with LanePool([Lane(i, None) for i in range(n_lanes)]) as lp:
+            lp.map(dry, jobs)
         dt = ldist.max_over_ranks(time.perf_counter() - t0)
         loads = ldist.gather_floats(float(my_cost))
         csum = ldist.sum_over_ranks(float(ws.arena16.float().abs().sum()))
         ldist.shutdown()
         if rank == 0:
             print(json.dumps(dict(metric="dryrun", n_gpus=world, rccl_ranks=world, images=n_total,
-                                  weight_broadcast_s=round(bcast_s, 4), per_rank_cost=loads,
+                                  weight_broadcast_s=round(bcast_s, 4), per_rank_cost=loads, lanes_per_gpu=n_lanes,
+                                  rank0_lane_cost=[round(c, 1) for c in lane_cost],
                                   weights_identical=abs(csum / world - float(ws.arena16.float().abs().sum())) < 1e-3,
                                   max_s=dt)))
         return

@@ -89,6 +89,9 @@ def test_bench_self_spawns_ranks_and_balances_the_prompt_set():
     assert r["weight_broadcast_s"] > 0 and r["weights_identical"]
     a, b = r["per_rank_cost"]
     assert abs(a - b) / max(a, b) <= 0.05                     # cost = algorithmic TFLOP per layout, LPT-balanced
+    # inside a rank the layouts are shared out over its lanes (host threads here, HIP streams on the GPU) the same way
+    lc = r["rank0_lane_cost"]
+    assert r["lanes_per_gpu"] == len(lc) == 4 and abs(sum(lc) - a) < 1.0 and max(lc) / (sum(lc) / 4) <= 1.25
 
 
 def test_cost_partition_is_complete_balanced_and_deterministic():
