@@ -335,6 +335,13 @@ def synth_aekl_state_dict(ch=(128, 256, 512, 512), layers=2, latent_channels=4, 
     return out
 
 
+def fold_pointwise_after(w, b, w1, b1):
+    """A 1x1 convolution (w1 [P, C, 1, 1], b1) applied AFTER a k x k convolution (w [C, D, k, k], b) is one k x k
+    convolution: weights sum_c w1[p, c] w[c, d, ky, kx], bias w1 b + b1 (exact: no padding interaction on this side)."""
+    m = w1.reshape(w1.shape[0], -1)
+    return torch.einsum("pc,cdkl->pdkl", m, w), m @ b + b1
+
+
 class HipVAEEncoder(HipVAEDecoder):
     """AutoencoderKL.encode(image).latent_dist on the lgd_hip kernels — the first half of the SDXL-refiner img2img
     pass (generation/sdxl_refinement.py:29 -> [ext] StableDiffusionXLImg2ImgPipeline.prepare_latents): conv_in 3 -> C0,
@@ -394,8 +401,7 @@ class HipVAEEncoder(HipVAEDecoder):
         # conv_out (C -> 2z) followed by quant_conv (1x1, 2z -> 2z): composed exactly into one 3x3 convolution
         w_o, b_o = sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"]
         if "quant_conv.weight" in sd:
-            wq1 = sd["quant_conv.weight"].reshape(sd["quant_conv.weight"].shape[0], -1)
-            w_o, b_o = torch.einsum("pc,cdkl->pdkl", wq1, w_o), wq1 @ b_o + sd["quant_conv.bias"]
+            w_o, b_o = fold_pointwise_after(w_o, b_o, sd["quant_conv.weight"], sd["quant_conv.bias"])
         self.n_moments = w_o.shape[0]
         self.conv_out = (h16(pack_conv(w_o)), f32(b_o))
 

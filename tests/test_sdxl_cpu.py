@@ -106,3 +106,24 @@ def test_dropin_module_surface_matches_the_reference():
         assert mod.sdxl_negative_prompt == consts["sdxl_negative_prompt"]
         fns = {n.name: [a.arg for a in n.args.args] for n in tree.body if isinstance(n, ast.FunctionDef)}
         assert fns["refine"] == ["image", "spec", "refine_seed", "refinement_step_ratio"] and "init" in fns
+
+
+def test_vae_encoder_host_algebra():
+    """The two rewrites HipVAEEncoder relies on, in plain torch: quant_conv folded into conv_out, and Downsample2D's
+    right / bottom padding as the odd positions of the stride-1 'same' convolution."""
+    import torch.nn.functional as F
+    from lgd_amd.vae import fold_pointwise_after, synth_aekl_state_dict
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 16, 10, 10, generator=g)
+    w, b = torch.randn(8, 16, 3, 3, generator=g), torch.randn(8, generator=g)
+    w1, b1 = torch.randn(8, 8, 1, 1, generator=g), torch.randn(8, generator=g)
+    wf, bf = fold_pointwise_after(w, b, w1, b1)
+    ref = F.conv2d(F.conv2d(x, w, b, padding=1), w1, b1)
+    assert float((F.conv2d(x, wf, bf, padding=1) - ref).abs().max()) < 1e-4
+    wd = torch.randn(16, 16, 3, 3, generator=g)
+    ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), wd, stride=2)
+    assert torch.allclose(F.conv2d(x, wd, padding=1)[:, :, 1::2, 1::2], ref, atol=1e-5)
+    sd = synth_aekl_state_dict((32, 64), 1)
+    assert sd["encoder.conv_out.weight"].shape == (8, 64, 3, 3) and sd["quant_conv.weight"].shape == (8, 8, 1, 1)
+    assert "encoder.down_blocks.0.downsamplers.0.conv.weight" in sd and "encoder.down_blocks.1.downsamplers.0.conv.weight" not in sd
+    assert sd["decoder.up_blocks.0.resnets.1.conv1.weight"].shape[0] == 64            # decoder mirrors the encoder widths
