@@ -548,6 +548,10 @@ def main():
                             avg_launch_us=round(a["raw_ms"] * 1e3 / a["raw_n"], 2),
                             launches_per_image=round(a["n"]), est_ms_per_image=round(a["ms"], 1),
                             traffic_note=traffic_note, traffic_source=traffic_source,
+                            rocprof_summary="profiles/r03a_bench_4layouts_kernel_stats.csv (one launch sequence alone: its "
+                                            "per-launch averages are the ones comparable with avg_launch_us); "
+                                            "profiles/r03b_bench_4lanes_kernel_stats.csv (this command with 4 lanes: "
+                                            "durations of kernels that overlap each other)",
                             method="HIP events around each launch, eager replay of the benchmark's plans right after "
                                    "the timed region, ONE launch sequence alone on the GPU (the timed region itself "
                                    "replays hipGraphs, on config.lanes_per_gpu streams side by side — kernels of "
