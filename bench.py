@@ -125,7 +125,7 @@ def cpu_baseline(cfg, generations, n_steps, beta, iters_on, iters_off):
         t0 = time.time()
         R.latent_backward_guidance(sd, cd, sched, cond, 0, boxes, [[1, 2, 3], [5, 6, 7]], sched.timesteps[0], x[:1],
                                    torch.tensor(1e4), loss_scale=5, loss_threshold=0.0, max_iter=1, max_index_step=30,
-                                   guidance_attn_keys=R.DEFAULT_GUIDANCE_ATTN_KEYS, fg_top_p=0.2, bg_top_p=0.2,
+                                   guidance_attn_keys=R.DEFAULT_GUIDANCE_ATTN_KEYS, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2,
                                    fg_weight=1.0, bg_weight=4.0, fuser_enabled=on,
                                    gligen=dict(boxes=gl["boxes"][:1], positive_embeddings=gl["positive_embeddings"][:1],
                                                masks=gl["masks"][:1]) if gl else None)

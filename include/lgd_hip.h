@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LGD_ABI_VERSION 6
+#define LGD_ABI_VERSION 7
 int lgd_abi_version(void);
 /* Kernel-variant switches of the library (A/B timing and tests; the defaults are what the benchmark runs).  No
  * counterpart in the reference.  "attn32": self-attention forward without map capture — 0 = the 16x16x32 kernel,
@@ -264,14 +264,16 @@ int lgd_sam_window_merge_f16(const void* oa, void* out, int B, int Hs, int Ws, i
 
 /* ---------------------------------------------------------------------------------------------
  * Cross-attention energy of LMD / LMD+ and its gradient on the probability maps, one launch for
- * all (key, object, token, head) items: utils/guidance.py:91-148 (max-based fg/bg top-k box loss),
+ * all (key, object, token, head) items: utils/guidance.py:91-148 (box loss, both branches: max-based fg/bg
+ * top-k :131-145 and the ratio-based default :118-130 that generation/backward_guidance.py runs),
  * :150-242 (reference-attention L1 transfer), :244-286 (compute_ca_lossv3), times loss_scale
  * (pipelines.py:48).
- *   items: int32 [n_items][8] = {map_id, kind(0 topk, 1 ref), token, mask_id, k_fg, k_bg, ref_id, image},
+ *   items: int32 [n_items][8] = {map_id, kind(0 topk, 1 ref, 2 ratio), token, mask_id, k_fg, k_bg, ref_id, image},
  *          sorted so that the items of one (map, image, token) column are adjacent;
  *   groups: int32 [n_groups][2] = {first item, item count} of each column — one workgroup per (group, head)
  *          sums the column's map gradients in a fixed order and stores them once (no atomics)
- *   coefs: fp32  [n_items][4] = {fg_coef, bg_coef, ref_coef, 0} (all normalisations folded in)
+ *   coefs: fp32  [n_items][4] = {fg_coef, bg_coef, ref_coef, ratio_coef} (all normalisations folded in;
+ *          kind 2: term = ratio_coef * (1 - sum(A*M)/sum(A))^2 per head, ABI v7)
  *   maps:  device array of n_maps pointers to fp32 [n_samples][H][HW][T]; gmaps likewise (pre-zeroed)
  *          or NULL; loss: fp32 [n_samples] (one value per image of the batch)
  *   map_hw: int32[n_maps]; masks: fp32 [n_masks][max_hw] (1 inside the box); refs: fp32

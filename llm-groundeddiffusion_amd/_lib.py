@@ -14,7 +14,7 @@ import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgd_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 

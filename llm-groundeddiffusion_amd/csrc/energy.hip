@@ -1,9 +1,11 @@
 // Cross-attention energy of LMD/LMD+ and its gradient on the probability maps — one launch.
 //
 // Reference (Python loops over keys x objects x tokens, two torch.topk + a mask build each, plus
-// the autograd graph through them): utils/guidance.py:91-148 (add_ca_loss_per_attn_map_to_loss,
-// max-based branch), :150-242 (add_ref_ca_loss_per_attn_map_to_lossv2), :244-286
-// (compute_ca_lossv3), scaled by loss_scale at models/pipelines.py:48.
+// the autograd graph through them): utils/guidance.py:91-148 (add_ca_loss_per_attn_map_to_loss:
+// item kind 0 = max-based branch :131-145, kind 2 = ratio-based branch :118-130 — the branch the
+// signature defaults to and generation/backward_guidance.py:99-112 therefore runs), :150-242
+// (add_ref_ca_loss_per_attn_map_to_lossv2, kind 1), :244-286 (compute_ca_lossv3), scaled by
+// loss_scale at models/pipelines.py:48.
 //
 // grid = (heads, n_groups); one workgroup evaluates, for one head, all items that touch the same column
 // (map, image, token) of <= 1024 spatial positions, one after the other, accumulating their map gradients in
@@ -78,6 +80,23 @@ __global__ __launch_bounds__(256) void ca_energy_kernel(
       bg_sum = block_sum_256(bg_sum, s_red);
       if (tid == 0)
         partial[item * H + h] = c_fg * (1.f - fg_sum / (float)k_fg) + c_bg * (bg_sum / (float)k_bg);
+    } else if (kind == 2) {
+      // ratio-based term (guidance.py:124-126): r = sum(A*M) / sum(A) per head, term (1 - r)^2, the mean over
+      // heads and the 1/len(tokens), 1/(n_obj*n_keys), loss_scale factors are folded into coefs[3] by the host.
+      // d term / d A_i = -2 c (1 - r) (M_i * sum(A) - sum(A*M)) / sum(A)^2.  No epsilon, as in the reference.
+      const float c_rat = coefs[item * 4 + 3];
+      float sa = 0.f, sm = 0.f;
+      for (int i = tid; i < HW; i += 256) {
+        const float a = A[(long)i * T];
+        sa += a;
+        sm += a * M[i];
+      }
+      sa = block_sum_256(sa, s_red);
+      sm = block_sum_256(sm, s_red);
+      const float r = sm / sa;
+      const float gk = -2.f * c_rat * (1.f - r) / (sa * sa) * gscale;
+      for (int i = tid; i < HW; i += 256) s_g[i] += gk * (M[i] * sa - sm);
+      if (tid == 0) partial[item * H + h] = c_rat * (1.f - r) * (1.f - r);
     } else {
       const float* R = refs + (long)dyn[0] * refs_step_stride + ((long)ref_id * H + h) * max_hw;
       float sa = 0.f, sr = 0.f;

@@ -238,7 +238,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& ga, f32x4 (&acc)[N
 // epilogue_value4, unchanged; the residual is still fetched in the fragment layout (reads of 32-byte pieces are served
 // by L1 / L2 at 4 TB/s; it is the WRITES of partial lines that were slow).
 //   `lds`: a STAGE_B-byte region nobody else touches (the stage consumed last: no DMA in flight into it, all fragment
-//   reads of it retired before the K loop's last barrier) — valid for one-tile and persistent workgroups alike.
+//   reads of it retired before the K loop's last barrier) on ENTRY, for one-tile and persistent workgroups alike; on
+//   EXIT a persistent workgroup closes the last round with a barrier (see the end of the round loop).
 //   Bare s_barrier + lgkmcnt(0): a __syncthreads() would drain the DMA queue of a persistent workgroup.
 template <int MI, int NI, int WM, int WN, int STAGE_B, bool GEGLU, bool RES_PREFETCH>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& ga, f32x4 (&acc)[NI][MI], int m0, int n0, int wm,
@@ -326,7 +327,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& ga, f32x4 (&ac
         *reinterpret_cast<uint4*>(cbase + (long)m * d.ldc + n) = val;
       }
     }
-    if (r + 1 < R) {
+    // Between rounds the staging rows are rewritten; behind the LAST round of a persistent workgroup (RES_PREFETCH ==
+    // !PERSIST) the next output tile's K loop issues LDS-DMA into this very stage before its first barrier — every
+    // wave's staged-row reads must have retired before any wave gets there.
+    if (r + 1 < R || !RES_PREFETCH) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }

@@ -22,10 +22,10 @@ def _sampler(model_dict):
 
 
 def _guidance_dict(bboxes, object_positions, kwargs):
+    # `use_ratio_based_loss` travels on to the energy tables; when the caller leaves it out the reference's default
+    # (True, utils/guidance.py:91) applies there, exactly as it does behind pipelines.py:48.
     g = dict(kwargs or {})
-    for drop in ("verbose", "use_ratio_based_loss", "clear_cache"):
-        if drop == "use_ratio_based_loss" and g.get(drop, False):
-            raise RuntimeError("ratio-based loss is deprecated in the reference and not implemented")
+    for drop in ("verbose", "clear_cache"):
         g.pop(drop, None)
     ref = g.pop("ref_ca_saved_attns", None)
     g.update(bboxes=bboxes, object_positions=object_positions)
@@ -87,7 +87,6 @@ def latent_backward_guidance(scheduler, unet, cond_embeddings, index, bboxes, ob
     g = dict(kwargs, bboxes=bboxes, object_positions=object_positions, loss_scale=loss_scale,
              loss_threshold=loss_threshold, max_iter=max_iter, max_index_step=max_index_step,
              guidance_attn_keys=keys, ref_maps=_ref_maps_from_saved(sm, ref_ca_saved_attns, bboxes, keys, L, T))
-    g.pop("use_ratio_based_loss", None)
     gl = (cross_attention_kwargs or {}).get("gligen")
     gs = sm.make_guidance(L, g.pop("bboxes"), g.pop("object_positions"), **g)
     if gs is not None:

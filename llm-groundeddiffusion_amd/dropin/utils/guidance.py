@@ -70,17 +70,16 @@ class _EnergyFn(torch.autograd.Function):
 def compute_ca_lossv3(saved_attn, bboxes, object_positions, guidance_attn_keys, ref_ca_saved_attns=None,
                       ref_ca_last_token_only=True, ref_ca_word_token_only=False, word_token_indices=None, index=None,
                       ref_ca_loss_weight=1.0, verbose=False, **kwargs):
-    """guidance.py:244-286 (max-based loss; the deprecated ratio-based branch is not provided)."""
+    """guidance.py:244-286.  `use_ratio_based_loss` (in **kwargs, forwarded to add_ca_loss_per_attn_map_to_loss in
+    the reference) defaults to True as at guidance.py:91: ratio-based branch :118-130; False: max-based :131-145."""
     keys = [tuple(k) for k in guidance_attn_keys]
     dev = saved_attn[keys[0]].device if keys else "cuda"
     if len(bboxes) == 0:
         return torch.tensor(0., device=dev)
-    if kwargs.get("use_ratio_based_loss", False):
-        raise RuntimeError("ratio-based loss is deprecated in the reference and not implemented here")
     maps = [saved_attn[k] for k in keys]
     heads = maps[0].shape[-3]
     hw = {k: m.shape[-2] for k, m in zip(keys, maps)}
-    ekw = {k: kwargs[k] for k in ("fg_top_p", "bg_top_p", "fg_weight", "bg_weight") if k in kwargs}
+    ekw = {k: kwargs[k] for k in ("use_ratio_based_loss", "fg_top_p", "bg_top_p", "fg_weight", "bg_weight") if k in kwargs}
     tables = EnergyTables(dev, bboxes, object_positions, keys, hw, heads, maps[0].shape[-1], loss_scale=1.0,
                           ref_boxes=ref_ca_saved_attns is not None, ref_ca_loss_weight=ref_ca_loss_weight,
                           ref_ca_word_token_only=ref_ca_word_token_only,

@@ -31,10 +31,14 @@ class EnergyTables:
 
     def __init__(self, device, bboxes, object_positions, guidance_attn_keys: Sequence[Tuple],
                  map_hw: Dict[Tuple, int], heads: int, text_len: int = 77, *, loss_scale=30.0,
-                 fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=1.0,
+                 use_ratio_based_loss=True, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=1.0,
                  ref_boxes: bool = False, ref_ca_loss_weight=1.0, ref_ca_word_token_only=False,
                  ref_ca_last_token_only=True, word_token_indices=None):
+        # `use_ratio_based_loss` defaults to True because the reference's add_ca_loss_per_attn_map_to_loss does
+        # (guidance.py:91): LMD / LMD+ switch it off explicitly (lmd_plus.py:315,487; lmd.py:349,521), the
+        # backward_guidance plugin does not (backward_guidance.py:99-112) and runs the ratio branch (:118-130).
         self.device = device
+        self.use_ratio_based_loss = bool(use_ratio_based_loss)
         self.keys = [tuple(k) for k in guidance_attn_keys]
         self.heads, self.T = heads, text_len
         self.n_obj = len(bboxes)
@@ -56,6 +60,10 @@ class EnergyTables:
                 masks.append(torch.nn.functional.pad(m.reshape(-1), (0, self.max_hw - hw)))
                 toks = object_positions[o]
                 for p in toks:
+                    if use_ratio_based_loss:                 # guidance.py:124-126: mean over heads of (1 - r)^2
+                        items.append([ki, 2, int(p), mid, 1, 1, 0, 0])
+                        coefs.append([0.0, 0.0, 0.0, loss_scale / (heads * len(toks) * denom)])
+                        continue
                     items.append([ki, 0, int(p), mid, k_fg, k_bg, 0, 0])
                     coefs.append([loss_scale * fg_weight / (len(toks) * denom),
                                   loss_scale * bg_weight / (len(toks) * denom), 0.0, 0.0])

@@ -205,7 +205,7 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
                     guid = dict(bboxes=[list(box)], object_positions=[lay.so_object_positions[i]],
                                 loss_scale=loss_scale, loss_threshold=loss_threshold,
                                 max_iter=max_iter or DEFAULT_MAX_ITER, max_index_step=max_index_step,
-                                guidance_attn_keys=keys)
+                                use_ratio_based_loss=False, guidance_attn_keys=keys)
                 jobs.append(Job(prep[li][0][i], torch.cat([lay.so_uncond, lay.so_cond[i:i + 1]]),
                                 gligen=prepare_gligen_condition([list(box)], lay.phrase_embeddings[i:i + 1], dev),
                                 guidance=guid, token=lay.so_word_token_index[i]))
@@ -241,7 +241,7 @@ def lmd_plus_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, nu
                         fg_top_p=overall_fg_top_p, bg_top_p=overall_bg_top_p, fg_weight=overall_fg_weight,
                         bg_weight=overall_bg_weight, ref_ca_word_token_only=True, ref_ca_last_token_only=True,
                         word_token_indices=lay.overall_word_token_indices, ref_ca_loss_weight=ref_ca_loss_weight,
-                        guidance_attn_keys=keys,
+                        use_ratio_based_loss=False, guidance_attn_keys=keys,   # lmd_plus.py:487 / lmd.py:521
                         ref_maps=_ref_maps(sampler, d["saved"], keys, L, T) if use_ref_ca else None)
         gl = prepare_gligen_condition([list(lay.boxes[i]) for i in flat], lay.phrase_embeddings[flat], dev)
         start = composed
@@ -304,7 +304,7 @@ def lmd_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, num_inf
             guid = dict(bboxes=[list(box)], object_positions=[lay.so_object_positions[i]], loss_scale=loss_scale,
                         loss_threshold=loss_threshold, max_iter=max_iter or DEFAULT_MAX_ITER,
                         max_index_step=max_index_step, fg_top_p=fg_top_p, bg_top_p=bg_top_p, fg_weight=fg_weight,
-                        bg_weight=bg_weight, guidance_attn_keys=keys)
+                        bg_weight=bg_weight, use_ratio_based_loss=False, guidance_attn_keys=keys)   # lmd.py:349
             jobs.append(Job(prep[li][0][i], torch.cat([lay.so_uncond, lay.so_cond[i:i + 1]]), guidance=guid,
                             token=lay.so_word_token_index[i]))
             owner.append((li, i))
@@ -339,7 +339,7 @@ def lmd_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, num_inf
                         fg_top_p=overall_fg_top_p, bg_top_p=overall_bg_top_p, fg_weight=overall_fg_weight,
                         bg_weight=overall_bg_weight, ref_ca_word_token_only=True, ref_ca_last_token_only=True,
                         word_token_indices=lay.overall_word_token_indices, ref_ca_loss_weight=ref_ca_loss_weight,
-                        guidance_attn_keys=keys,
+                        use_ratio_based_loss=False, guidance_attn_keys=keys,   # lmd_plus.py:487 / lmd.py:521
                         ref_maps=_ref_maps(sampler, d["saved"], keys, L, T) if use_ref_ca else None)
         jobs_b.append(Job(composed, torch.cat([lay.overall_uncond, lay.overall_cond]), guidance=guid,
                           frozen_mask=(fg_idx != 0)))
@@ -360,16 +360,24 @@ def backward_guidance_generate(sampler: LMDSampler, lay: CachedLayout, **kw):
 def backward_guidance_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, num_inference_steps=50,
                                      guidance_scale=7.5, loss_scale=30, loss_threshold=0.2, max_iter=5,
                                      max_index_step=10, height=512, width=512, decode=True,
-                                     guidance_attn_keys=None, **energy_kw):
+                                     guidance_attn_keys=None, first_step=0, n_steps=None, start=None, trace=None,
+                                     **energy_kw):
     """Layout-guidance baseline (generation/backward_guidance.py:46-49,99-120; BASELINE config 3 runs it on
     SD2.1-768): one generate_semantic_guidance call per layout on seeded noise, no per-box stage.  The layouts of
-    a batch share UNet calls; each keeps its own guidance loop exit."""
+    a batch share UNet calls; each keeps its own guidance loop exit.
+
+    The energy is the RATIO-based branch of add_ca_loss_per_attn_map_to_loss (utils/guidance.py:118-130): the plugin's
+    guidance kwargs (backward_guidance.py:99-112) do not carry `use_ratio_based_loss`, so the signature default (True,
+    guidance.py:91) applies; `ref_ca_saved_attns=None` means no reference-attention term.  `energy_kw` may override
+    (`use_ratio_based_loss=False, fg_top_p=...`) for experiments; nothing in the reference's plugin does.
+    `first_step` / `n_steps` / `start` (one latent tensor per layout, the state BEFORE step first_step) / `trace` run a
+    slice of the schedule from given latents: the teacher-forced parity tests."""
     L = height // 8
     C = sampler.eng.cfg.in_channels
     keys = [tuple(k) for k in (guidance_attn_keys or DEFAULT_GUIDANCE_ATTN_KEYS)]
     jobs = []
     for lay in lays:
-        lat = seeded_noise(lay.bg_seed, C, L, L)
+        lat = seeded_noise(lay.bg_seed, C, L, L) if start is None else torch.as_tensor(start[len(jobs)]).float()
         overall_bboxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
         guid = None
         if overall_bboxes:
@@ -377,7 +385,8 @@ def backward_guidance_generate_batch(sampler: LMDSampler, lays: List[CachedLayou
                         loss_threshold=loss_threshold, max_iter=max_iter, max_index_step=max_index_step,
                         guidance_attn_keys=keys, **energy_kw)
         jobs.append(Job(lat, torch.cat([lay.overall_uncond, lay.overall_cond]), guidance=guid))
-    res = sampler.denoise_batch(jobs, num_inference_steps, guidance_scale=guidance_scale, save_all_latents=False)
+    res = sampler.denoise_batch(jobs, num_inference_steps, guidance_scale=guidance_scale, save_all_latents=False,
+                                first_step=first_step, n_steps=n_steps, trace=trace)
     images = sampler.decode(torch.cat([r["latents"] for r in res])) if decode else [None] * len(lays)
     return [dict(image=images[i], latents=r["latents"], guidance_iters=r["guidance_iters"],
                  guidance_iters_fuser_on=0) for i, r in enumerate(res)]

@@ -155,13 +155,14 @@ class LMDSampler:
     def make_guidance(self, L, bboxes, object_positions, *, loss_scale=30, loss_threshold=0.2, max_iter=5,
                       max_index_step=10, guidance_attn_keys=None, ref_maps=None, **kw) -> Optional[GuidanceState]:
         """kwargs as latent_backward_guidance / compute_ca_lossv3 receive them (pipelines.py:16,
-        guidance.py:244).  ref_maps: fp32 [T][n_boxes_flat][n_keys][heads][max_hw] or None."""
+        guidance.py:244) — including the reference's default `use_ratio_based_loss=True` (guidance.py:91) when the
+        caller does not switch it off.  ref_maps: fp32 [T][n_boxes_flat][n_keys][heads][max_hw] or None."""
         if not bboxes or max_index_step <= 0:
             return None
         keys = [tuple(k) for k in (guidance_attn_keys or DEFAULT_GUIDANCE_ATTN_KEYS)]
         heads = self.heads_of(keys[0])
         assert all(self.heads_of(k) == heads for k in keys), "guidance keys with different head counts"
-        ekw = {k: kw[k] for k in ("fg_top_p", "bg_top_p", "fg_weight", "bg_weight", "ref_ca_loss_weight",
+        ekw = {k: kw[k] for k in ("use_ratio_based_loss", "fg_top_p", "bg_top_p", "fg_weight", "bg_weight", "ref_ca_loss_weight",
                                   "ref_ca_word_token_only", "ref_ca_last_token_only", "word_token_indices")
                if k in kw}
         en = EnergyTables(self.dev, bboxes, object_positions, keys, self.map_hw(L), heads,

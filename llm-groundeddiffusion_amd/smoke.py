@@ -55,7 +55,7 @@ def run():
     # ---- 2. one backward-guidance iteration (energy + latent gradient) vs the oracle
     sm = LMDSampler(eng, DDIMScheduler())
     guid = dict(bboxes=boxes, object_positions=pos, loss_scale=5, loss_threshold=0.0, max_iter=1, max_index_step=10,
-                guidance_attn_keys=keys, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+                guidance_attn_keys=keys, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
     tr = []
     sm.guidance_only(x[:1], cond, 10, 1, guid, gligen=gl, fuser=True, trace=tr)
     rs = R.DDIM()
@@ -63,7 +63,7 @@ def run():
     tr_ref = []
     R.latent_backward_guidance(sd, cd, rs, cond, 1, boxes, pos, rs.timesteps[1], x[:1].clone(), torch.tensor(1e4),
                                loss_scale=5, loss_threshold=0.0, max_iter=1, max_index_step=10,
-                               guidance_attn_keys=keys, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0,
+                               guidance_attn_keys=keys, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0,
                                gligen=dict(boxes=gl[0][:1].cpu(), positive_embeddings=gl[1][:1].cpu(),
                                            masks=gl[2][:1].cpu()), trace=tr_ref)
     a, b = tr[0]["grad"].cpu().double().reshape(-1), tr_ref[0]["grad"].double().reshape(-1)

@@ -143,7 +143,7 @@ def main():
         rgl = None if gl is None else dict(boxes=gl["boxes"][:1], positive_embeddings=gl["positive_embeddings"][:1],
                                            masks=gl["masks"][:1])
         tr = []
-        rkw = {k: v for k, v in gkw.items() if k != "use_ratio_based_loss"}
+        rkw = dict(gkw)
         lat2, loss2 = R.latent_backward_guidance(sd, cd, rs, cond, 1, BBOXES, OBJ_POS, rs.timesteps[1], lat.clone(),
                                                  torch.tensor(10000.), gligen=rgl, trace=tr, **rkw)
         report[f"{name}/guidance_latents"] = maxrel(lat2, lat_out)
@@ -169,7 +169,7 @@ def main():
                 warnings.simplefilter("ignore")
                 lat_pf, _ = pipelines.generate_partial_frozen(md, lat_all_in, fm, inp, steps, 2, bboxes=BBOXES,
                                                               object_positions=OBJ_POS, semantic_guidance_kwargs=sg)
-            rsg = {k: v for k, v in sg.items() if k not in ("use_ratio_based_loss", "verbose")}
+            rsg = {k: v for k, v in sg.items() if k != "verbose"}
             lat_pf2 = R.generate_partial_frozen(sd, cd, R.DDIM(), lat_all_in, fm, inp, steps, 2, bboxes=BBOXES,
                                                 object_positions=OBJ_POS, semantic_guidance_kwargs=rsg)
             report[f"{name}/partial_frozen"] = maxrel(lat_pf2, lat_pf)
@@ -211,7 +211,7 @@ def main():
                     semantic_guidance_bboxes=BBOXES, semantic_guidance_object_positions=OBJ_POS,
                     semantic_guidance_kwargs=sg, save_all_latents=True, show_progress=False)
             lat_g, _, saved_g, lat_all_g = ret
-            rsg = {k: v for k, v in sg.items() if k not in ("use_ratio_based_loss", "verbose")}
+            rsg = {k: v for k, v in sg.items() if k != "verbose"}
             lat_g2, saved_g2, lat_all_g2 = R.generate_gligen(
                 sd, cd, R.DDIM(), lat_all_in, inp, steps, BBOXES, pe, gligen_scheduled_sampling_beta=0.5,
                 frozen_steps=2, frozen_mask=fm, return_saved_cross_attn=True, saved_cross_attn_keys=[OBJ_KEY, *KEYS],
@@ -242,7 +242,7 @@ def main():
         loss = guidance.compute_ca_lossv3(saved_attn=maps, bboxes=BBOXES, object_positions=OBJ_POS,
                                           guidance_attn_keys=KEYS, **rkw, **ekw)
         grads = torch.autograd.grad(loss, [maps[k] for k in KEYS])
-        rk = {k: v for k, v in {**rkw, **ekw}.items() if k != "use_ratio_based_loss"}
+        rk = {**rkw, **ekw}
         loss2 = R.compute_ca_lossv3(maps, BBOXES, OBJ_POS, KEYS, **rk)
         grads2 = torch.autograd.grad(loss2, [maps[k] for k in KEYS])
         report[f"energy/{tag}/loss"] = maxrel(loss2, loss)

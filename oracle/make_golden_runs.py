@@ -167,6 +167,75 @@ def run_lmd():
     print("wrote run_lmd_tiny.npz", {k: getattr(v, "shape", None) for k, v in outs.items()})
 
 
+def run_backward_guidance():
+    """The reference's own, unmodified `generation/backward_guidance.run` (backward_guidance.py:43-137): ONE guided
+    generation whose energy is the RATIO-based branch of add_ca_loss_per_attn_map_to_loss (utils/guidance.py:118-130) —
+    the plugin's kwargs (:99-112) carry no `use_ratio_based_loss`, so the function's default (True, :91) applies — and no
+    reference-attention term (`ref_ca_saved_attns=None`).  Recorded: the latents entering every
+    `latent_backward_guidance` call (teacher-forcing points), every value `compute_ca_lossv3` returned (one per guidance
+    iteration, unscaled), the iteration count per step, the final latents."""
+    cfg, md = build("tiny")
+    import generation.backward_guidance as g
+    g.height = g.width = 256
+    g.H = g.W = 32
+    g.num_inference_steps = 8
+    outs = {}
+    o_bg, o_loss, o_sg = g.pipelines.latent_backward_guidance, g.guidance.compute_ca_lossv3, g.pipelines.generate_semantic_guidance
+    starts, losses, finals = [], [], []
+
+    def bg(scheduler, unet, cond_embeddings, index, bboxes, object_positions, t, latents, loss, **k):
+        starts.append(latents.detach().clone())
+        n0 = len(losses)
+        out = o_bg(scheduler, unet, cond_embeddings, index, bboxes, object_positions, t, latents, loss, **k)
+        iters.append(len(losses) - n0)
+        ends.append(out[0].detach().clone())
+        return out
+
+    def closs(*a, **k):
+        assert "use_ratio_based_loss" not in k          # what this golden is about: the default branch runs
+        out = o_loss(*a, **k)
+        losses.append(float(out.detach()))
+        return out
+
+    def sg(*a, **k):
+        call.update(latents_in=a[1].detach().clone(), text_embeddings=a[2][0].detach().clone(), bboxes=k["bboxes"],
+                    object_positions=k["object_positions"])
+        out = o_sg(*a, **k)
+        finals.append(out[0].detach().clone())
+        return out
+    g.pipelines.latent_backward_guidance, g.guidance.compute_ca_lossv3, g.pipelines.generate_semantic_guidance = bg, closs, sg
+    phrase_calls, call = [], {}
+    o_phr = record_phrase_calls(g.guidance, phrase_calls)
+    import warnings
+    for tag, spec, kw in (("a", SPEC, dict(bg_seed=3, overall_loss_scale=30, overall_loss_threshold=0.2,
+                                           overall_max_iter=5, overall_max_index_step=3)),
+                          ("b", SPEC3, dict(bg_seed=11, overall_loss_scale=30, overall_loss_threshold=0.0,
+                                            overall_max_iter=2, overall_max_index_step=2))):
+        starts.clear(), losses.clear(), finals.clear(), phrase_calls.clear(), call.clear()
+        iters, ends = [], []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r = g.run(spec, **kw)
+        assert len(starts) == 8 and len(finals) == 1
+        outs[f"{tag}_starts"] = torch.stack(starts).numpy()
+        outs[f"{tag}_guided"] = torch.stack(ends).numpy()          # latents leaving the guidance loop of each step
+        outs[f"{tag}_iters"] = np.array(iters)
+        outs[f"{tag}_losses"] = np.array(losses, dtype=np.float64)  # unscaled, in call order
+        outs[f"{tag}_final_latents"] = finals[0].numpy()
+        outs[f"{tag}_image_shape"] = np.array(r.image.shape)
+        outs[f"{tag}_kwargs"] = np.array(json.dumps(kw))
+        outs[f"{tag}_phrase_calls"] = np.array(json.dumps(phrase_calls))
+        outs[f"{tag}_latents_in"] = call["latents_in"].numpy()
+        outs[f"{tag}_text_embeddings"] = call["text_embeddings"].numpy()          # [uncond; cond] of the overall prompt
+        outs[f"{tag}_bboxes"] = np.array(json.dumps(call["bboxes"]))
+        outs[f"{tag}_object_positions"] = np.array(json.dumps(call["object_positions"]))
+        print(tag, "iterations per step", iters, "losses", [round(x, 4) for x in losses])
+    g.pipelines.latent_backward_guidance, g.guidance.compute_ca_lossv3, g.pipelines.generate_semantic_guidance = o_bg, o_loss, o_sg
+    g.guidance.get_phrase_indices = o_phr
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "run_backward_guidance_tiny.npz"), **outs)
+    print("wrote run_backward_guidance_tiny.npz", {k: getattr(v, "shape", None) for k, v in outs.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -174,3 +243,5 @@ if __name__ == "__main__":
         run_lmd_plus()
     if which in ("all", "lmd"):
         run_lmd()
+    if which in ("all", "backward_guidance"):
+        run_backward_guidance()

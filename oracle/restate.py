@@ -281,9 +281,12 @@ def box_mask(obj_boxes, H, W):
     return mask
 
 
-def ca_loss_per_map(loss, attn_map, bboxes, object_positions, fg_top_p=0.2, bg_top_p=0.2,
-                    fg_weight=1.0, bg_weight=1.0):
-    """add_ca_loss_per_attn_map_to_loss, max-based branch (guidance.py:91-148)."""
+def ca_loss_per_map(loss, attn_map, bboxes, object_positions, use_ratio_based_loss=True, fg_top_p=0.2,
+                    bg_top_p=0.2, fg_weight=1.0, bg_weight=1.0):
+    """add_ca_loss_per_attn_map_to_loss (guidance.py:91-148), both branches.  `use_ratio_based_loss` defaults to True
+    exactly as the reference's signature does (:91): LMD / LMD+ pass False explicitly (lmd_plus.py:315,487,
+    lmd.py:349,521), the `backward_guidance` plugin passes nothing (backward_guidance.py:99-112) and so runs the
+    ratio branch (:118-130): per token and head r = sum(A*M)/sum(A), term mean_heads((1-r)^2)."""
     b, i, _ = attn_map.shape
     H = W = int(math.sqrt(i))
     for obj_idx in range(len(bboxes)):
@@ -291,11 +294,15 @@ def ca_loss_per_map(loss, attn_map, bboxes, object_positions, fg_top_p=0.2, bg_t
         mask = box_mask(bboxes[obj_idx], H, W)
         for pos in object_positions[obj_idx]:
             ca = attn_map[:, :, pos]
-            k_fg = (mask.sum() * fg_top_p).long().clamp_(min=1)
-            k_bg = ((1 - mask).sum() * bg_top_p).long().clamp_(min=1)
             m1 = mask.view(1, -1)
-            obj_loss += (1 - (ca * m1).topk(k=k_fg).values.mean(dim=1)).sum(dim=0) * fg_weight
-            obj_loss += ((ca * (1 - m1)).topk(k=k_bg).values.mean(dim=1)).sum(dim=0) * bg_weight
+            if use_ratio_based_loss:
+                activation = (ca * m1).sum(dim=-1) / ca.sum(dim=-1)
+                obj_loss += torch.mean((1 - activation) ** 2)
+            else:
+                k_fg = (mask.sum() * fg_top_p).long().clamp_(min=1)
+                k_bg = ((1 - mask).sum() * bg_top_p).long().clamp_(min=1)
+                obj_loss += (1 - (ca * m1).topk(k=k_fg).values.mean(dim=1)).sum(dim=0) * fg_weight
+                obj_loss += ((ca * (1 - m1)).topk(k=k_bg).values.mean(dim=1)).sum(dim=0) * bg_weight
         loss += obj_loss / len(object_positions[obj_idx])
     return loss
 
@@ -344,7 +351,7 @@ def compute_ca_lossv3(saved_attn, bboxes, object_positions, guidance_attn_keys, 
     n_obj = len(bboxes)
     if n_obj == 0:
         return loss
-    kw = {k: v for k, v in kw.items() if k in ("fg_top_p", "bg_top_p", "fg_weight", "bg_weight")}
+    kw = {k: v for k, v in kw.items() if k in ("use_ratio_based_loss", "fg_top_p", "bg_top_p", "fg_weight", "bg_weight")}
     for key in guidance_attn_keys:
         loss = ca_loss_per_map(loss, saved_attn[key].squeeze(dim=0), bboxes, object_positions, **kw)
     n_attn = len(guidance_attn_keys)

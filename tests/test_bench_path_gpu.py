@@ -291,7 +291,7 @@ def test_fullsize_guidance_iteration_vs_oracle(dev):
     x, _, cond, gl = _inputs(cfg, dev)
     sm = LMDSampler(eng, DDIMScheduler())
     guid = dict(bboxes=BOXES, object_positions=OBJ_POS, loss_scale=5, loss_threshold=0.0, max_iter=1,
-                max_index_step=30, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+                max_index_step=30, guidance_attn_keys=KEYS, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
     tr = []
     sm.guidance_only(x[:1], cond, 50, 1, guid, gligen=gl, fuser=True, trace=tr)
     rs = R.DDIM()
@@ -299,7 +299,7 @@ def test_fullsize_guidance_iteration_vs_oracle(dev):
     tr_ref = []
     R.latent_backward_guidance(f["sd"], f["cd"], rs, cond, 1, BOXES, OBJ_POS, rs.timesteps[1], x[:1].clone(),
                                torch.tensor(1e4), loss_scale=5, loss_threshold=0.0, max_iter=1, max_index_step=30,
-                               guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0,
+                               guidance_attn_keys=KEYS, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0,
                                gligen=dict(boxes=gl[0][:1].cpu(), positive_embeddings=gl[1][:1].cpu(),
                                            masks=gl[2][:1].cpu()), trace=tr_ref)
     a, b = tr[0]["grad"].cpu().double().reshape(-1), tr_ref[0]["grad"].double().reshape(-1)
@@ -331,7 +331,7 @@ def test_fullsize_guided_gligen_loop_vs_oracle(dev):
     torch.randn((2, 4, 64, 64), generator=g0)
     pe = torch.randn((2, cfg.gligen_positive_len), generator=g0)
     guid = dict(bboxes=BOXES, object_positions=OBJ_POS, loss_scale=5, loss_threshold=0.0, max_iter=[1, 1],
-                max_index_step=2, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+                max_index_step=2, guidance_attn_keys=KEYS, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
     sm = LMDSampler(eng, DDIMScheduler())
     out = sm.denoise(hist_in, ehs, T, gligen=gl, gligen_scheduled_sampling_beta=0.5, guidance=guid, frozen_steps=1,
                      frozen_mask=fm)
@@ -351,13 +351,12 @@ def test_fullsize_guided_gligen_loop_vs_oracle(dev):
 
 
 def test_fullsize_sd21_guidance_iteration_vs_oracle(dev):
-    """BASELINE config 3 closed at full width: one latent_backward_guidance iteration (pipelines.py:16-82 as
-    generation/backward_guidance.py:99-120 calls it, loss_scale 30) on the SD2.1-768 topology at 96x96 latents.
-    The loss (HW = 144 / 576 energy maps) must match; the latent gradient is checked in two parts, because the
-    energy's top-k selection (utils/guidance.py:91-176) is discontinuous: (a) the map gradients — same number of
-    selected positions, and all but a handful identical (fp16 maps vs fp32 maps flip near-ties); (b) the network
-    backward — the ORACLE's map gradients fed through the HIP dgrad plan of the 96^2 network must reproduce the
-    oracle's latent gradient to fp16 accuracy.  End to end the few flipped selections cost a few percent."""
+    """BASELINE config 3 closed at full width: one latent_backward_guidance iteration (pipelines.py:16-82) exactly as
+    generation/backward_guidance.py:99-120 drives it — loss_scale 30 and NO `use_ratio_based_loss` in the kwargs, i.e.
+    the ratio-based energy (utils/guidance.py:91,118-130) — on the SD2.1-768 topology at 96x96 latents (energy maps
+    HW = 144 / 576).  Checked: the loss, the energy's direct map gradients (dense and smooth: no top-k selection in
+    this branch), the latent gradient end to end, and the network backward alone (the ORACLE's map gradients fed
+    through the HIP dgrad plan of the 96^2 network)."""
     import restate as R
     cfg = weights.CONFIGS["sd21"]
     sd = weights.synth_state_dict(cfg, 0)
@@ -369,32 +368,31 @@ def test_fullsize_sd21_guidance_iteration_vs_oracle(dev):
     L = cfg.sample_size
     x = torch.randn((1, 4, L, L), generator=torch.Generator().manual_seed(0))
     _, cond = weights.synth_embeddings(cfg, 1, seed=1)
-    kw = dict(fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
     rs = R.DDIM(prediction_type=cfg.prediction_type)
     rs.set_timesteps(50)
     lat = x.clone().requires_grad_(True)
     saved = {}
     R.unet_forward(sd, cd, lat, rs.timesteps[1], cond, saved=saved, save_keys=KEYS, stop_after=KEYS[-1])
-    loss = R.compute_ca_lossv3(saved, BOXES, OBJ_POS, KEYS, index=1, **kw) * 30
+    loss = R.compute_ca_lossv3(saved, BOXES, OBJ_POS, KEYS, index=1) * 30          # default kwargs = ratio branch
     g_lat_ref = torch.autograd.grad(loss, [lat])[0].double().reshape(-1)
     # the energy's own (direct) map gradients: the maps as leaves, without the network paths between the keys
     leaves = {k: saved[k].detach().clone().requires_grad_(True) for k in KEYS}
-    g_maps_ref = torch.autograd.grad(R.compute_ca_lossv3(leaves, BOXES, OBJ_POS, KEYS, index=1, **kw) * 30,
+    g_maps_ref = torch.autograd.grad(R.compute_ca_lossv3(leaves, BOXES, OBJ_POS, KEYS, index=1) * 30,
                                      [leaves[k] for k in KEYS])
     sm = LMDSampler(eng, DDIMScheduler(prediction_type=cfg.prediction_type), use_graphs=False)
     guid = dict(bboxes=BOXES, object_positions=OBJ_POS, loss_scale=30, loss_threshold=0.0, max_iter=1,
-                max_index_step=25, guidance_attn_keys=KEYS, **kw)
+                max_index_step=25, guidance_attn_keys=KEYS)
     tr = []
     sm.guidance_only(x, cond, 50, 1, guid, trace=tr)
     cos = lambda a, b: float(a @ b / (a.norm() * b.norm()))
-    gate("[sd21 full] guidance loss rel. error", abs(tr[0]["loss"] - float(loss)) / float(loss), 7e-5)
+    gate("[sd21 full, ratio energy] guidance loss rel. error", abs(tr[0]["loss"] - float(loss)) / float(loss), 3e-4)
     pg = eng.plan(1, L, grad=True, fuser=False, stop_key=eng.last_key(KEYS), save_keys=KEYS, text_batch_offset=1)
     for k, gm in zip(KEYS, g_maps_ref):
-        gh = pg.gmaps[k].float().cpu() / sm.grad_scale
-        assert int((gh != 0).sum()) == int((gm != 0).sum()), k           # the same number of selected positions
-        gate(f"[sd21 full] map-gradient support mismatch {k}", float(((gh != 0) != (gm != 0)).float().mean()) + 1e-9, 2.9e-4)
+        gh = (pg.gmaps[k].float().cpu() / sm.grad_scale).double().reshape(-1)
+        gate(f"[sd21 full, ratio energy] direct map gradient {k}: rel-L2", rel_l2(gh, gm.double().reshape(-1)), 2e-2)
     a = tr[0]["grad"].cpu().double().reshape(-1)
-    gate("[sd21 full] latent-gradient cosine end to end (incl. flipped top-k selections)", cos(a, g_lat_ref), 0.99, at_least=True)
+    gate("[sd21 full, ratio energy] latent-gradient cosine end to end", cos(a, g_lat_ref), 0.9995, at_least=True)
+    gate("[sd21 full, ratio energy] latent-gradient rel-L2 end to end", rel_l2(a, g_lat_ref), 4e-2)
     for k, gm in zip(KEYS, g_maps_ref):
         pg.gmaps[k].copy_((gm * sm.grad_scale).to(dev))
     g2 = pg.backward(sm.grad_scale).cpu().double().reshape(-1)

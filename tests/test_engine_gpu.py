@@ -96,7 +96,7 @@ def test_energy_kernel_vs_reference_golden(dev):
     hw = {k: maps[k].shape[1] for k in KEYS}
     for tag in ("noref", "ref"):
         gmaps = {k: torch.zeros_like(v) for k, v in maps.items()}
-        kw = dict(loss_scale=1.0, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+        kw = dict(loss_scale=1.0, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
         if tag == "ref":
             kw.update(ref_boxes=True, ref_ca_loss_weight=2.0, ref_ca_word_token_only=True,
                       ref_ca_last_token_only=True, word_token_indices=WORD_TOK)
@@ -115,6 +115,53 @@ def test_energy_kernel_vs_reference_golden(dev):
             assert relerr(gmaps[k], g[f"grad_{tag}_{ks(k)}"][0]) < 1e-4, (tag, k)
 
 
+def test_ratio_energy_kernel_vs_reference_golden(dev):
+    """The ratio-based branch (utils/guidance.py:118-130; the default of add_ca_loss_per_attn_map_to_loss and what
+    generation/backward_guidance.py runs) against value + map gradients of the reference's OWN compute_ca_lossv3 called
+    without the flag (oracle/make_golden_ratio.py -> energy_ratio.npz): one box per phrase (0.6933 on the canonical
+    layout), several boxes per phrase (union mask), and next to a reference-attention term."""
+    dyn = torch.tensor([1, 0, 0, 0], dtype=torch.int32, device=dev)
+    g, gr = np.load(os.path.join(GOLD, "energy.npz")), np.load(os.path.join(GOLD, "energy_ratio.npz"))
+    maps = {k: torch.from_numpy(g["map_" + ks(k)])[0].to(dev).contiguous() for k in KEYS}
+    hw = {k: maps[k].shape[1] for k in KEYS}
+    bboxes3 = [[BBOXES[0], [0.05, 0.05, 0.3, 0.35]], [BBOXES[1]]]
+    assert abs(float(gr["loss_two_level"]) - 0.6933) < 1e-4
+    for tag, boxes, kw in (("two_level", BBOXES, {}), ("three_level", bboxes3, {}),
+                           ("with_ref", BBOXES, dict(use_ratio_based_loss=True, ref_boxes=True, ref_ca_loss_weight=0.5,
+                                                     ref_ca_word_token_only=True, ref_ca_last_token_only=True,
+                                                     word_token_indices=WORD_TOK))):
+        gmaps = {k: torch.zeros_like(v) for k, v in maps.items()}
+        en = EnergyTables(dev, boxes, OBJ_POS, KEYS, hw, 8, 77, loss_scale=1.0, **kw)   # no flag = the reference default
+        assert en.use_ratio_based_loss
+        if tag == "with_ref":
+            refs = torch.zeros(2, en.n_refs, 8, en.max_hw)
+            for rid, (o, bi, ki) in enumerate(en.ref_slots):
+                r = torch.from_numpy(g[f"ref_{o}_{ks(KEYS[ki])}"])[0, :, :, 0]
+                refs[1, rid, :, :r.shape[1]] = r
+            en.set_refs(refs)
+        en.bind(maps, gmaps)
+        loss = en.run(dyn, grad_scale=1.0)
+        torch.cuda.synchronize()
+        gate(f"[ratio energy {tag}] value", relerr(loss, gr[f"loss_{tag}"]), 1e-5)
+        for k in KEYS:
+            gate(f"[ratio energy {tag}] map gradient {k}", relerr(gmaps[k], gr[f"grad_{tag}_{ks(k)}"][0]), 1e-4)
+    # a batch of images (merged tables, one loss per image) gives each image its single-image value
+    single = [EnergyTables(dev, b, OBJ_POS, KEYS, hw, 8, 77, loss_scale=30.0) for b in (BBOXES, bboxes3)]
+    both = EnergyTables.merged(single)
+    maps2 = {k: torch.cat([v[None], v[None].flip(1)]).contiguous() for k, v in maps.items()}     # image 1: heads reversed
+    gm2 = {k: torch.zeros_like(v) for k, v in maps2.items()}
+    both.bind(maps2, gm2)
+    l2 = both.run(dyn).clone()
+    want = []
+    for i, en in enumerate(single):
+        gm = {k: torch.zeros_like(maps2[k][i]) for k in KEYS}
+        en.bind({k: maps2[k][i].contiguous() for k in KEYS}, gm)
+        want.append(en.run(dyn).clone())
+        for k in KEYS:
+            assert torch.equal(gm[k], gm2[k][i]), k
+    assert torch.equal(l2, torch.cat(want))
+
+
 @pytest.mark.parametrize("name", ["tiny", "tiny_gligen"])
 def test_backward_guidance_vs_reference_golden(dev, name):
     """One latent_backward_guidance call, loss_threshold=0 (iteration count pinned to max_iter=3)."""
@@ -126,7 +173,7 @@ def test_backward_guidance_vs_reference_golden(dev, name):
         f = np.load(os.path.join(GOLD, f"unet_fwd_{name}.npz"))
         gl = (torch.from_numpy(f["gl_boxes"]), torch.from_numpy(f["gl_emb"]), torch.from_numpy(f["gl_masks"]))
     guid = dict(bboxes=BBOXES, object_positions=OBJ_POS, loss_scale=5, loss_threshold=0.0, max_iter=3,
-                max_index_step=10, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0,
+                max_index_step=10, guidance_attn_keys=KEYS, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0,
                 bg_weight=4.0)
     tr = []
     lat, loss, gs = sm.guidance_only(torch.from_numpy(g["latents_in"]), torch.from_numpy(g["cond"]), 10, 1, guid,
@@ -155,7 +202,7 @@ def test_partial_frozen_and_semantic_guidance_loops(dev):
     sm = LMDSampler(eng, DDIMScheduler())
     ehs = torch.from_numpy(g["ehs"])
     guid = dict(bboxes=BBOXES, object_positions=OBJ_POS, loss_scale=5, loss_threshold=0.0, max_iter=[2, 1],
-                max_index_step=2, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0,
+                max_index_step=2, guidance_attn_keys=KEYS, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0,
                 bg_weight=4.0)
     out = sm.denoise(torch.from_numpy(g["lat_all_in"]), ehs, 4, guidance=guid, frozen_steps=2,
                      frozen_mask=torch.from_numpy(g["frozen_mask"]))
@@ -184,7 +231,7 @@ def test_gligen_loop(dev):
     sm = LMDSampler(eng, DDIMScheduler())
     ehs = torch.from_numpy(g["ehs"])
     guid = dict(bboxes=BBOXES, object_positions=OBJ_POS, loss_scale=5, loss_threshold=0.0, max_iter=[2, 1],
-                max_index_step=3, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0,
+                max_index_step=3, guidance_attn_keys=KEYS, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0,
                 bg_weight=4.0)
     gl = prepare_gligen_condition(BBOXES, torch.from_numpy(g["phrase_emb"]), dev)
     out = sm.denoise(torch.from_numpy(g["lat_all_in"]), ehs, 4, gligen=gl, gligen_scheduled_sampling_beta=0.5,
@@ -217,7 +264,7 @@ def test_teacher_forced_guided_steps_vs_reference_golden(dev, which):
     sm = LMDSampler(eng, DDIMScheduler())
     ehs = torch.from_numpy(g["ehs"])
     guid = dict(bboxes=BBOXES, object_positions=OBJ_POS, loss_scale=5, loss_threshold=0.0, max_iter=mi,
-                max_index_step=mis, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0,
+                max_index_step=mis, guidance_attn_keys=KEYS, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0,
                 bg_weight=4.0)
     # per-step limits = 3x the measured errors.  Step 0 runs TWO guidance iterations: the second one's top-k selection
     # is taken on maps of already-updated latents, and the fp32 oracle itself amplifies a 1e-3 input perturbation of
@@ -301,7 +348,7 @@ def test_batched_denoise_matches_single(dev):
 
     def guid(thr, iters):
         return dict(bboxes=BBOXES, object_positions=OBJ_POS, loss_scale=5, loss_threshold=thr, max_iter=iters,
-                    max_index_step=3, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+                    max_index_step=3, guidance_attn_keys=KEYS, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
     jobs = [Job(lat_all, ehs, gligen=gl, guidance=guid(0.0, [2, 1]), frozen_mask=fm, token=7),
             Job(lat_all.flip(-1).contiguous(), ehs.flip(0).contiguous(), gligen=gl, guidance=guid(1e9, [2, 1]),
                 frozen_mask=fm, token=3),
@@ -488,7 +535,7 @@ def test_plans_alias_one_arena_and_do_not_depend_on_stale_data(dev):
     ehs = torch.from_numpy(g["ehs"])
     gl = prepare_gligen_condition(BBOXES, torch.from_numpy(g["phrase_emb"]), dev)
     guid = dict(bboxes=BBOXES, object_positions=OBJ_POS, loss_scale=5, loss_threshold=0.0, max_iter=[2, 1],
-                max_index_step=3, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+                max_index_step=3, guidance_attn_keys=KEYS, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
     kw = dict(gligen=gl, gligen_scheduled_sampling_beta=0.5, guidance=guid, frozen_steps=2,
               frozen_mask=torch.from_numpy(g["frozen_mask"]), saved_cross_attn_keys=[OBJ_KEY, *KEYS],
               return_cond_ca_only=True, return_token_ca_only=7)
@@ -556,7 +603,7 @@ def test_guidance_keys_in_any_order(dev):
     res = []
     for keys in (KEYS, [KEYS[3], KEYS[0], KEYS[2], KEYS[1]]):
         guid = dict(bboxes=BBOXES, object_positions=OBJ_POS, loss_scale=5, loss_threshold=0.0, max_iter=1,
-                    max_index_step=10, guidance_attn_keys=keys, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+                    max_index_step=10, guidance_attn_keys=keys, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
         tr = []
         sm.guidance_only(torch.from_numpy(g["latents_in"]), torch.from_numpy(g["cond"]), 10, 1, guid, trace=tr)
         res.append(tr[0])

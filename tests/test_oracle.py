@@ -91,7 +91,7 @@ def test_backward_guidance(model):
     lat, loss = R.latent_backward_guidance(
         sd, cd, sched, torch.from_numpy(g["cond"]), 1, BBOXES, OBJ_POS, sched.timesteps[1],
         torch.from_numpy(g["latents_in"]), torch.tensor(10000.), loss_scale=5, loss_threshold=0.0, max_iter=3,
-        max_index_step=10, guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0,
+        max_index_step=10, guidance_attn_keys=KEYS, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0,
         gligen=gl)
     assert maxrel(lat, g["latents_out"]) < TOL
     assert maxrel(loss, g["loss_out"]) < TOL
@@ -101,7 +101,7 @@ def test_energy_value_and_map_gradients():
     g = np.load(os.path.join(GOLD, "energy.npz"))
     maps = {k: torch.from_numpy(g["map_" + ks(k)]).requires_grad_(True) for k in KEYS}
     refs = [[None, {k: torch.from_numpy(g[f"ref_{o}_{ks(k)}"]) for k in KEYS}] for o in range(2)]
-    base = dict(fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+    base = dict(use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
     for tag, kw in (("noref", {}), ("ref", dict(ref_ca_saved_attns=refs, ref_ca_word_token_only=True,
                                                  ref_ca_last_token_only=True, word_token_indices=WORD_TOK, index=1,
                                                  ref_ca_loss_weight=2.0))):
@@ -112,6 +112,55 @@ def test_energy_value_and_map_gradients():
             assert maxrel(gr, g[f"grad_{tag}_{ks(k)}"]) < 1e-6
 
 
+def test_ratio_energy_value_and_map_gradients():
+    """The oracle's ratio branch against the reference's own compute_ca_lossv3 called WITHOUT `use_ratio_based_loss`
+    (its default, guidance.py:91; what generation/backward_guidance.py runs): oracle/make_golden_ratio.py."""
+    g, gr = np.load(os.path.join(GOLD, "energy.npz")), np.load(os.path.join(GOLD, "energy_ratio.npz"))
+    refs = [[None, {k: torch.from_numpy(g[f"ref_{o}_{ks(k)}"]) for k in KEYS}] for o in range(2)]
+    bboxes3 = [[BBOXES[0], [0.05, 0.05, 0.3, 0.35]], [BBOXES[1]]]
+    assert abs(float(gr["loss_two_level"]) - 0.6933) < 1e-4
+    for tag, boxes, kw in (("two_level", BBOXES, {}), ("three_level", bboxes3, {}),
+                           ("with_ref", BBOXES, dict(use_ratio_based_loss=True, ref_ca_saved_attns=refs,
+                                                     ref_ca_word_token_only=True, ref_ca_last_token_only=True,
+                                                     word_token_indices=WORD_TOK, index=1, ref_ca_loss_weight=0.5))):
+        maps = {k: torch.from_numpy(g["map_" + ks(k)]).requires_grad_(True) for k in KEYS}
+        loss = R.compute_ca_lossv3(maps, boxes, OBJ_POS, KEYS, **kw)
+        grads = torch.autograd.grad(loss, [maps[k] for k in KEYS])
+        assert maxrel(loss, gr[f"loss_{tag}"]) < 1e-6
+        for k, gd in zip(KEYS, grads):
+            assert maxrel(gd, gr[f"grad_{tag}_{ks(k)}"]) < 1e-6
+
+
+def test_backward_guidance_plugin_loop_vs_reference_run():
+    """The oracle's generate_semantic_guidance with the kwargs generation/backward_guidance.py:99-112 builds (no
+    `use_ratio_based_loss` -> ratio branch) against the reference's OWN, unmodified `generation/backward_guidance.run`
+    (oracle/make_golden_runs.py -> run_backward_guidance_tiny.npz): per-iteration losses, the data-dependent iteration
+    counts (case a: threshold 0.2, never reached -> 5 per guided step; case b: threshold 0 -> max_iter), the latents
+    entering every step and the final latents."""
+    import json
+    cfg = weights.CONFIGS["tiny"]
+    cd, sd = cfg_dict(cfg), weights.synth_state_dict(cfg, 0)
+    g = np.load(os.path.join(GOLD, "run_backward_guidance_tiny.npz"))
+    for tag in ("a", "b"):
+        kw = json.loads(str(g[f"{tag}_kwargs"]))
+        ehs = torch.from_numpy(g[f"{tag}_text_embeddings"])
+        sg = dict(loss_scale=kw["overall_loss_scale"], loss_threshold=kw["overall_loss_threshold"],
+                  max_iter=kw["overall_max_iter"], max_index_step=kw["overall_max_index_step"],
+                  guidance_attn_keys=KEYS, ref_ca_word_token_only=True, ref_ca_last_token_only=True,
+                  ref_ca_saved_attns=None, ref_ca_loss_weight=0.5)
+        tr = []
+        lat, _, lat_all = R.generate_semantic_guidance(
+            sd, cd, R.DDIM(), torch.from_numpy(g[f"{tag}_latents_in"]), (ehs, ehs[:1], ehs[1:]), 8,
+            json.loads(str(g[f"{tag}_bboxes"])), json.loads(str(g[f"{tag}_object_positions"])),
+            semantic_guidance_kwargs=sg, trace=tr)
+        iters = [sum(1 for x in tr if x["index"] == i) for i in range(8)]
+        assert iters == g[f"{tag}_iters"].tolist(), (iters, g[f"{tag}_iters"])
+        losses = np.array([x["loss"] for x in tr]) / sg["loss_scale"]
+        assert np.abs(losses - g[f"{tag}_losses"]).max() < 2e-4 * np.abs(g[f"{tag}_losses"]).max()
+        assert maxrel(lat_all[:8], g[f"{tag}_starts"]) < TOL
+        assert maxrel(lat, g[f"{tag}_final_latents"]) < TOL
+
+
 def test_sampler_loops_tiny():
     cfg = weights.CONFIGS["tiny"]
     cd, sd = cfg_dict(cfg), weights.synth_state_dict(cfg, 0)
@@ -119,7 +168,7 @@ def test_sampler_loops_tiny():
     ehs = torch.from_numpy(g["ehs"])
     inp = (ehs, ehs[:1], ehs[1:])
     sg = dict(loss_scale=5, loss_threshold=0.0, max_iter=[2, 1], max_index_step=2, guidance_attn_keys=KEYS,
-              fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+              use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
     out = R.generate_partial_frozen(sd, cd, R.DDIM(), torch.from_numpy(g["lat_all_in"]),
                                     torch.from_numpy(g["frozen_mask"]), inp, 4, 2, bboxes=BBOXES,
                                     object_positions=OBJ_POS, semantic_guidance_kwargs=sg)
@@ -138,7 +187,7 @@ def test_sampler_loop_gligen():
     ehs = torch.from_numpy(g["ehs"])
     inp = (ehs, ehs[:1], ehs[1:])
     sg = dict(loss_scale=5, loss_threshold=0.0, max_iter=[2, 1], max_index_step=3, guidance_attn_keys=KEYS,
-              fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+              use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
     _, saved, lat_all = R.generate_gligen(
         sd, cd, R.DDIM(), torch.from_numpy(g["lat_all_in"]), inp, 4, BBOXES, torch.from_numpy(g["phrase_emb"]),
         gligen_scheduled_sampling_beta=0.5, frozen_steps=2, frozen_mask=torch.from_numpy(g["frozen_mask"]),
@@ -162,7 +211,7 @@ def test_guided_step_amplifies_input_perturbations():
     ehs = torch.from_numpy(g["ehs"])
     inp = (ehs, ehs[:1], ehs[1:])
     sg = dict(loss_scale=5, loss_threshold=0.0, max_iter=[2, 1], max_index_step=3, guidance_attn_keys=KEYS,
-              fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+              use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
 
     def run(lat_all_in):
         per_step = []

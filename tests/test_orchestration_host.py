@@ -29,13 +29,15 @@ def _calls():
     g = np.load(os.path.join(GOLD, "run_lmd_plus_tiny.npz"))
     out += json.loads(str(g["a_phrase_calls"])) + json.loads(str(g["b_phrase_calls"]))
     out += json.loads(str(np.load(os.path.join(GOLD, "run_lmd_tiny.npz"))["phrase_calls"]))
+    g = np.load(os.path.join(GOLD, "run_backward_guidance_tiny.npz"))       # generation/backward_guidance.run
+    out += json.loads(str(g["a_phrase_calls"])) + json.loads(str(g["b_phrase_calls"]))
     return out
 
 
 def test_phrase_indices_match_every_reference_call():
     guidance = _load(os.path.join(ROOT, "llm-groundeddiffusion_amd", "dropin", "utils", "guidance.py"), "dropin_guidance")
     calls = _calls()
-    assert len(calls) >= 9
+    assert len(calls) >= 11
     for c in calls:
         got = guidance.get_phrase_indices(FakeTokenizer(), c["prompt"], c["phrases"], words=c["words"] or None,
                                           return_word_token_indices=True, add_suffix_if_not_found=c["add_suffix"])

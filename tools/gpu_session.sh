@@ -1,0 +1,21 @@
+#!/bin/bash
+# One gpurun session = one stage of this script (kept as ONE file; per-session scratch scripts are not committed).
+#   gpurun --timeout 1500 -- 'bash tools/gpu_session.sh <stage> [args]'
+R=${GRAFT_REPO_ROOT:-/root/repo}
+STAGE=${1:-tests}; shift
+OUT=$R/gpurun_out/$STAGE
+rm -rf $OUT; mkdir -p $OUT
+cd $R
+case $STAGE in
+  tests)      # full GPU suite + smoke
+    timeout 900 python -m pytest tests -q -m gpu -x -rP "$@" > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+    grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -n 3
+    timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -n 1 $OUT/smoke.log ;;
+  pick)       # selected tests: args = pytest selection
+    timeout 900 python -m pytest -q -m gpu -x -rP "$@" > $OUT/pytest.log 2>&1; echo "pytest rc=$?"
+    grep -E "passed|failed|error|^\[" $OUT/pytest.log | tail -n 60 ;;
+  bench)      # args = bench.py flags; writes bench.json
+    timeout 900 python bench.py "$@" > $OUT/bench.log 2>&1; echo "bench rc=$?"
+    grep '^{' $OUT/bench.log | tail -1 > $OUT/bench.json; cut -c1-400 $OUT/bench.json ;;
+  *) echo "unknown stage $STAGE"; exit 2 ;;
+esac

@@ -29,7 +29,7 @@ for name, L in [(c, int(l)) for c, l in (x.split(":") for x in os.environ.get("C
         rs = R.DDIM(prediction_type=cfg.prediction_type); rs.set_timesteps(50)
         tr_ref, tr = [], []
         kw = dict(loss_scale=30, loss_threshold=0.0, max_iter=1, max_index_step=25, guidance_attn_keys=keys,
-                  fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+                  use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
         R.latent_backward_guidance(sd, cd, rs, cond, 1, BOXES, OBJ_POS, rs.timesteps[1], x.clone(), torch.tensor(1e4),
                                    trace=tr_ref, **kw)
         sm = LMDSampler(eng, DDIMScheduler(prediction_type=cfg.prediction_type), use_graphs=False)

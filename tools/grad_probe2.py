@@ -26,7 +26,7 @@ x = torch.randn((1, 4, L, L), generator=torch.Generator().manual_seed(0))
 _, cond = weights.synth_embeddings(cfg, 1, seed=1)
 rs = R.DDIM(prediction_type=cfg.prediction_type); rs.set_timesteps(50)
 t = rs.timesteps[1]
-kw = dict(fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+kw = dict(use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
 lat = x.clone().requires_grad_(True)
 saved = {}
 R.unet_forward(sd, cd, lat, t, cond, saved=saved, save_keys=keys, stop_after=keys[-1])

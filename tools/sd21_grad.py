@@ -27,14 +27,14 @@ rs = R.DDIM(prediction_type=cfg.prediction_type); rs.set_timesteps(50)
 tr_ref = []
 R.latent_backward_guidance(sd, cd, rs, cond, 1, BOXES, OBJ_POS, rs.timesteps[1], x.clone(), torch.tensor(1e4),
                            loss_scale=30, loss_threshold=0.0, max_iter=1, max_index_step=25, guidance_attn_keys=KEYS,
-                           fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0, trace=tr_ref)
+                           use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0, trace=tr_ref)
 b = tr_ref[0]["grad"].double().reshape(-1)
 print("oracle loss", tr_ref[0]["loss"], "grad absmax", float(b.abs().max()), flush=True)
 for ls in (30, 5):
     for gs in (1024.0, 128.0, 16.0, 2.0):
         sm = LMDSampler(eng, DDIMScheduler(prediction_type=cfg.prediction_type), grad_scale=gs, use_graphs=False)
         guid = dict(bboxes=BOXES, object_positions=OBJ_POS, loss_scale=ls, loss_threshold=0.0, max_iter=1, max_index_step=25,
-                    guidance_attn_keys=KEYS, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
+                    guidance_attn_keys=KEYS, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0)
         tr = []
         sm.guidance_only(x, cond, 50, 1, guid, trace=tr)
         a = tr[0]["grad"].cpu().double().reshape(-1) * (30.0 / ls)
