@@ -254,7 +254,7 @@ def main_sdxl(args):
                                     f"({weights.num_params(cfg) / 1e9:.2f} B-parameter UNet, SD/SDXL VAE encoder + decoder, "
                                     "seeded random weights), VAE encode and decode included",
                            images_per_gpu=n_img, num_inference_steps=T, steps_run=n_run, parallelism=f"dp{world}",
-                           rccl_ranks=world, lanes_per_gpu=len(lanes), gemm_tuning=ops.TUNING_MODE,
+                           rccl_ranks=world, lanes_per_gpu=len(lanes), gemm_tuning=lanes[0].engine.tuning_mode or ops.current_tuning_mode(),
                            algorithmic_tflop_per_image=round(tf, 2) if tf else None,
                            weight_broadcast_s=round(bcast_s, 3), prebuild_s=round(prebuild_s, 2),
                            per_rank_busy_s=[round(b, 3) for b in per_rank_busy],
@@ -593,7 +593,7 @@ def main():
                            guidance_iters_per_image=round(iters_on + iters_off, 2),
                            guidance_iters_fuser_on=round(iters_on, 2),
                            algorithmic_tflop_per_image=round(tf, 3) if tf else None,
-                           lanes_per_gpu=len(lanes), gemm_tuning=ops.TUNING_MODE,
+                           lanes_per_gpu=len(lanes), gemm_tuning=lanes[0].engine.tuning_mode or ops.current_tuning_mode(),
                            weight_broadcast_s=round(bcast_s, 3), prebuild_s=round(prebuild_s, 2),
                            per_rank_busy_s=[round(b, 3) for b in per_rank_busy],
                            per_rank_idle_s=[round(max(dt - b, 0.0), 3) for b in per_rank_busy]),

@@ -8,6 +8,8 @@ network is re-hosted on the HIP kernels (UNet -> UNetEngine, VAE -> HipVAEEncode
 HipCLIPTextEncoder); `offload_model` has nothing to offload (288 GB of HBM) and is accepted for call compatibility.
 Offline (this sandbox, the benchmark) `init_synthetic()` builds the same networks with seeded random parameters and
 `refine()` then takes the prompt embeddings from `spec["sdxl_prompt_embeds"]` / `spec["sdxl_pooled"]`."""
+import os as _os
+
 import numpy as np
 import torch
 from PIL import Image
@@ -55,6 +57,14 @@ def from_diffusers(hf_pipe, device="cuda"):
                              projection_class_embeddings_input_dim=c.projection_class_embeddings_input_dim)
     eng = UNetEngine(cfg, device, {k: v.float().cpu() for k, v in hf_pipe.unet.state_dict().items()}, max_text_batch=2)
     vsd = hf_pipe.vae.state_dict()
+    if getattr(hf_pipe.vae.config, "force_upcast", False) and not _os.environ.get("LGD_SDXL_VAE_FP16"):
+        # The SDXL VAE is exported with force_upcast=true: its activations overflow fp16, so the reference pipeline runs
+        # encode and decode in fp32.  HipVAEEncoder / HipVAEDecoder keep every activation in fp16 -> inf / NaN latents
+        # or black images with the real checkpoint.  Refuse instead of producing them silently; a checkpoint with the
+        # fp16-safe VAE weights (config.force_upcast = false) loads, and LGD_SDXL_VAE_FP16=1 overrides (refine() then
+        # still checks that the moments and the decoded image are finite).
+        raise RuntimeError("this VAE sets config.force_upcast (fp16 overflow): the fp16 HIP VAE would produce non-finite "
+                           "latents; load an fp16-safe VAE (force_upcast=false) or set LGD_SDXL_VAE_FP16=1 to try anyway")
     sch = hf_pipe.scheduler.config
     return _sdxl.SDXLRefiner(eng, vae.HipVAEEncoder(vsd, device), vae.HipVAEDecoder(vsd, device),
                              text_encoder=clip.from_hf(hf_pipe.text_encoder_2, device), tokenizer=hf_pipe.tokenizer_2,

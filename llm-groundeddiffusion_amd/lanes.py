@@ -127,7 +127,9 @@ class LanePool:
         self._threads: List[threading.Thread] = []
         self._closed = False
         self._map_lock = threading.Lock()                 # one map() at a time: it owns every lane while it runs
+        self._switch_interval = None
         if len(self.lanes) > 1 and sys.getswitchinterval() > 2e-4:
+            self._switch_interval = sys.getswitchinterval()      # restored by close()
             sys.setswitchinterval(2e-4)
         for k, lane in enumerate(self.lanes):
             t = threading.Thread(target=self._worker, args=(k, lane), name=f"lgd-lane-{lane.index}", daemon=True)
@@ -141,6 +143,12 @@ class LanePool:
     def _worker(self, k: int, lane: Lane):
         if self.device is not None:
             torch.cuda.set_device(self.device)            # the current device is per host thread
+        from . import ops
+        mode = getattr(getattr(lane.sampler, "eng", None), "tuning_mode", None)
+        with ops.tuning(mode):                            # launches the lane describes outside plans (VAE, text)
+            self._serve(k, lane)
+
+    def _serve(self, k: int, lane: Lane):
         while True:
             task = self._inbox[k].get()
             if task is None:
@@ -214,6 +222,9 @@ class LanePool:
             q.put(None)
         for t in self._threads:
             t.join(timeout=30)
+        if self._switch_interval is not None:
+            sys.setswitchinterval(self._switch_interval)
+            self._switch_interval = None
 
     def __enter__(self):
         return self
@@ -225,14 +236,15 @@ class LanePool:
 def make_lanes(engine, n_lanes: int, make_sampler: Callable[[Any], Any]) -> List[Lane]:
     """Lane 0 drives `engine` itself; lanes 1.. get engines that share its parameters.  make_sampler(engine) builds
     the lane's LMDSampler (scheduler, VAE, batch limits: whatever the caller wants, one fresh set per lane)."""
-    from . import ops
     from .unet import UNetEngine
-    if int(n_lanes) > 1:
-        ops.set_tuning_mode("throughput")       # plans built from here on: GEMM tiles chosen for a shared GPU
     lanes = []
     for i in range(max(1, int(n_lanes))):
         eng = engine if i == 0 else UNetEngine(engine.cfg, engine.device, text_len=engine.text_len,
                                                max_text_batch=engine.max_text_batch, weights=engine.w)
+        if int(n_lanes) > 1:
+            # GEMM tiles / split-K chosen for a shared GPU: a property of the lane's ENGINE (its plans), not of the
+            # process — an engine built later for single-sequence use still gets the "latency" table
+            eng.tuning_mode = "throughput"
         stream = torch.cuda.Stream(device=engine.device) if engine.device.type == "cuda" else None
         lanes.append(Lane(i, make_sampler(eng), stream))
     return lanes

@@ -5,6 +5,7 @@ torch is used for device memory and the current HIP stream only.  Every function
 call raises RuntimeError (the error convention of the reference's plugin boundary,
 generate.py:391-396).
 """
+import contextlib
 import ctypes as C
 
 import torch
@@ -53,7 +54,7 @@ def workspace(device) -> torch.Tensor:
     return ws
 
 
-COUNTERS = {}             # device -> int32 zeros: split-K arrival counters (left at zero by every launch)
+COUNTERS = {}             # (device, host thread) -> int32 zeros: split-K arrival counters (left at zero by every launch)
 N_COUNTERS = 1 << 16
 import os as _os
 # In-launch split-K combine ("last arriver reduces", LgdGemmDesc.cnt): implemented, bit-identical, and MEASURED SLOWER on
@@ -63,10 +64,12 @@ SPLITK_IN_LAUNCH = _os.environ.get("LGD_SPLITK_IN_LAUNCH", "0") == "1"
 
 
 def splitk_counters(device):
-    dev = torch.device(device)
-    if dev not in COUNTERS:
-        COUNTERS[dev] = torch.zeros(N_COUNTERS, device=dev, dtype=torch.int32)
-    return COUNTERS[dev]
+    # one buffer per host thread = per lane = per stream: the header allows one counter buffer to serve the GEMMs of ONE
+    # stream only (concurrent launches of one shape on two streams would share ticket slots)
+    key = (torch.device(device), _threading.get_ident())
+    if key not in COUNTERS:
+        COUNTERS[key] = torch.zeros(N_COUNTERS, device=key[0], dtype=torch.int32)
+    return COUNTERS[key]
 
 
 def choose_splits(M, N, K, batches=1):
@@ -122,6 +125,9 @@ def gemm_desc(a0, w, c, M, N, K, *, a1=None, lda0=None, lda1=0, c0=None, c1=0, t
             raise RuntimeError(f"split-K workspace too small for {splits}x{M}x{N}")
     d.splits, d.ws = splits, ptr(ws)
     d.tile = tile
+    log = getattr(_TUNING_TLS, "log", None)
+    if log is not None:                                  # tests: which table entries a plan was built from
+        log.append((shape_key(d), tile, splits))
     d.cnt = 0
     if splits > 1 and SPLITK_IN_LAUNCH and torch.is_tensor(c) and c.is_cuda:
         # the smallest tile of the library is 32 rows x 64 columns: an upper bound of the launch's output tiles
@@ -184,9 +190,12 @@ _TUNING = {}
 # idle, another lane fills them.  Plans read the table when they are BUILT.
 TUNING_MODE = _os.environ.get("LGD_TUNING_MODE", "latency")
 _TUNING_FILES = {"latency": ("tuning_gfx950.json",), "throughput": ("tuning_gfx950.json", "tuning_gfx950_lanes.json")}
+_TUNING_TLS = _threading.local()
 
 
 def set_tuning_mode(mode: str):
+    """Process-wide DEFAULT (tools / A-B runs).  Engines and lanes do not use it: a lane engine carries its own
+    `tuning_mode` and a lane thread selects the table with `tuning(...)` for the launches it describes itself."""
     global TUNING_MODE
     if mode not in _TUNING_FILES:
         raise ValueError(f"tuning mode {mode!r}: expected one of {sorted(_TUNING_FILES)}")
@@ -195,8 +204,39 @@ def set_tuning_mode(mode: str):
     TUNING_MODE = mode
 
 
+def current_tuning_mode() -> str:
+    if _os.environ.get("LGD_TUNING_MODE"):
+        return TUNING_MODE
+    return getattr(_TUNING_TLS, "mode", None) or TUNING_MODE
+
+
+@contextlib.contextmanager
+def tuning(mode):
+    """Table selection for the GEMM descriptors built by THIS thread inside the block (None = leave as is): plan
+    construction of an engine, the body of a lane thread.  Nothing process-wide changes."""
+    if mode is not None and mode not in _TUNING_FILES:
+        raise ValueError(f"tuning mode {mode!r}: expected one of {sorted(_TUNING_FILES)}")
+    prev = getattr(_TUNING_TLS, "mode", None)
+    if mode is not None:
+        _TUNING_TLS.mode = mode
+    try:
+        yield
+    finally:
+        _TUNING_TLS.mode = prev
+
+
+@contextlib.contextmanager
+def desc_log():
+    """Collects (shape key, tile, splits) of every GEMM descriptor this thread builds inside the block."""
+    prev, _TUNING_TLS.log = getattr(_TUNING_TLS, "log", None), []
+    try:
+        yield _TUNING_TLS.log
+    finally:
+        _TUNING_TLS.log = prev
+
+
 def tuning_table():
-    mode = TUNING_MODE
+    mode = current_tuning_mode()
     if mode not in _TUNING:
         import json
         tab = {}

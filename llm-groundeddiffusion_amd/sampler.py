@@ -433,6 +433,10 @@ class LMDSampler:
         st.lat.copy_(torch.cat([s.to(dev, F32) for s in starts]))
         first_step = max(0, min(int(first_step), Tr))
         last_step = Tr if n_steps is None else min(Tr, first_step + int(n_steps))
+        if multistep and first_step > 0:
+            # row `first_step` of a second-order schedule mixes in the data prediction of step first_step - 1, which a
+            # run that starts here does not have (st.x0_prev holds whatever run used this state last)
+            raise RuntimeError("partial schedules (first_step > 0) are not defined for the multistep scheduler")
         st.hist[first_step].copy_(st.lat)
         st.mask.zero_()
         if frozen_steps > 0:

@@ -111,7 +111,9 @@ class SDXLRefiner:
             st["graph"] = HipGraph(one_step)     # the capture's warm-up run advanced the latents: restore them
             lat.copy_(keep)
         run = st["graph"] if self.use_graphs else one_step
+        from .lanes import GATE
         for i in range(n):
+            GATE.checkpoint()                    # a safe point per step: another lane's graph capture may proceed
             eng.set_step(i)
             run()
             if trace is not None:
@@ -151,11 +153,16 @@ class SDXLRefiner:
         if first >= num_inference_steps:
             raise ValueError(f"strength {strength} leaves no denoising step")
         lat = self.prepare_latents(image, seed, float(sch.timesteps[first]))
+        if not bool(torch.isfinite(lat).all()):
+            # fp16 activations of the HIP VAE encoder overflowed (the real SDXL VAE needs fp32: config.force_upcast)
+            raise RuntimeError("non-finite latents from the VAE encoder (fp16 overflow; this VAE needs an fp32 / fp16-safe variant)")
         lat = self.refine_latents(lat, prompt_embeds, pooled, first_index=first, num_inference_steps=num_inference_steps,
                                   guidance_scale=guidance_scale, height=H, width=W)
         if output == "latent":
             return lat
         img = self.dec.decode(lat / self.scaling_factor)
+        if not bool(torch.isfinite(img).all()):
+            raise RuntimeError("non-finite image from the VAE decoder (fp16 overflow; this VAE needs an fp32 / fp16-safe variant)")
         if output == "float":
             return img
         return ((img[0] / 2 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8).permute(1, 2, 0).cpu().numpy()

@@ -546,6 +546,9 @@ class UNetEngine:
         concurrently on two HIP streams (lanes.LanePool)."""
         self.cfg = cfg
         self.device = torch.device(device)
+        # GEMM tuning table of this engine's plans ("latency" | "throughput" | None = ops.current_tuning_mode() at
+        # plan-build time); lanes.make_lanes sets "throughput" on the engines it hands to lanes.  Part of the plan key.
+        self.tuning_mode: Optional[str] = None
         self.blocks = unet_blocks(cfg)
         if weights is not None:
             if weights.cfg != cfg or torch.device(weights.device) != self.device or state_dict is not None:
@@ -730,14 +733,16 @@ class UNetEngine:
     # ---- plans ---------------------------------------------------------------------------------
     def plan(self, B: int, L: int, *, grad=False, fuser=False, stop_key=None, save_keys=(),
              text_batch_offset=0, obj_batch_offset=0) -> Plan:
+        mode = self.tuning_mode or ops.current_tuning_mode()
         key = (B, L, grad, fuser, tuple(stop_key) if stop_key else None, tuple(map(tuple, save_keys)),
-               text_batch_offset, obj_batch_offset)
+               text_batch_offset, obj_batch_offset, mode)
         if B + text_batch_offset > self.max_text_batch:
             raise RuntimeError(f"plan batch {B} (+{text_batch_offset}) exceeds max_text_batch={self.max_text_batch}")
         if key not in self._plans:
-            self._plans[key] = Plan(self, B, L, grad=grad, fuser=fuser, stop_key=stop_key,
-                                    save_keys=save_keys, text_batch_offset=text_batch_offset,
-                                    obj_batch_offset=obj_batch_offset)
+            with ops.tuning(mode):                        # descriptors are tuned when they are built
+                self._plans[key] = Plan(self, B, L, grad=grad, fuser=fuser, stop_key=stop_key,
+                                        save_keys=save_keys, text_batch_offset=text_batch_offset,
+                                        obj_batch_offset=obj_batch_offset)
             while len(self._plans) > self.MAX_PLANS:
                 self._plans.popitem(last=False)       # a dropped plan's graphs stay valid: the arena never moves
         self._plans.move_to_end(key)

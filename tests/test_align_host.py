@@ -58,3 +58,42 @@ def test_alignment_off_is_identity():
     d = dict(latents_all=list(lat), masks=[proportion_to_mask(b, 64, 64).bool() for b in BBOXES], saved=[{}, {}, {}])
     pipeline._align_stage_a(d, Lay, KEYS, False, False)
     assert all(a is b for a, b in zip(d["latents_all"], lat))
+
+
+def _dropin_attn():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("dropin_utils_attn", os.path.join(root, "llm-groundeddiffusion_amd", "dropin", "utils", "attn.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_get_token_attnv2_known_answers_from_the_reference_function():
+    """utils/attn.py:9-38 (row H3): mean over the steps from `attn_aggregation_step_start` on and over heads of one
+    token's map — the reference's own outputs on seeded inputs (oracle/make_golden_token_attn.py).  The drop-in sums in
+    a different order (per step, then heads), hence 1e-6 instead of bit equality."""
+    g = np.load(os.path.join(os.path.dirname(GOLD), "token_attn.npz"))
+    attn = _dropin_attn()
+    key = ("down", 2, 1, 0)
+    pair = [{key: torch.from_numpy(x)} for x in g["pair"]]
+    cond = [{key: torch.from_numpy(x)} for x in g["cond"]]
+    for start in (0, 2, 5):
+        for tok in (0, 3, 8):
+            got = attn.get_token_attnv2(tok, pair, key, attn_aggregation_step_start=start, return_np=True)
+            want = g[f"pair_s{start}_t{tok}"]
+            assert isinstance(got, np.ndarray) and got.shape == want.shape == (8, 8)
+            assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
+        got = attn.get_token_attnv2(0, cond, key, attn_aggregation_step_start=start, input_ca_has_condition_only=True)
+        assert isinstance(got, torch.Tensor)
+        assert (got - torch.from_numpy(g[f"cond_s{start}"])).abs().max() <= 1e-6 * float(np.abs(g[f"cond_s{start}"]).max())
+        # the pipeline's own form of the same rule (lgd_amd.pipeline._token_attn: device tensor [T, 1, heads, HW, 1])
+        got2 = pipeline._token_attn({pipeline.OBJ_ATTN_KEY: torch.from_numpy(g["cond"])}, start)
+        assert np.abs(got2 - g[f"cond_s{start}"]).max() <= 1e-6 * np.abs(g[f"cond_s{start}"]).max()
+    # the reference asserts on the batch layout (attn.py:25-30) and cannot aggregate an empty tail
+    with pytest.raises(AssertionError):
+        attn.get_token_attnv2(0, pair, key, attn_aggregation_step_start=0, input_ca_has_condition_only=True)
+    with pytest.raises(AssertionError):
+        attn.get_token_attnv2(0, cond, key, attn_aggregation_step_start=0)
+    with pytest.raises(RuntimeError):
+        attn.get_token_attnv2(0, pair, key, attn_aggregation_step_start=6)

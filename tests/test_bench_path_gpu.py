@@ -118,13 +118,9 @@ def test_tuned_gemm_mode_on_its_table_shape(dev, s):
     assert relerr(out, ref) < 3e-3
     # what the engine would pick for this shape (tile=0 / splits=None) is this very table entry ("@lanes": of the
     # table used when several launch sequences share the GPU, ops.TUNING_MODE == "throughput")
-    mode0 = ops.TUNING_MODE
-    ops.TUNING_MODE = "throughput" if s.key.endswith("@lanes") else "latency"
-    try:
+    with ops.tuning("throughput" if s.key.endswith("@lanes") else "latency"):
         d2 = ops.gemm_desc(x0, w, out, M, N, K, a1=x1, c0=s.c0, c1=s.c1, lda0=s.c0, lda1=s.c1,
                            epi=ops.EPI_GEGLU if s.geglu else 0, ldc=out.shape[1], **kw)
-    finally:
-        ops.TUNING_MODE = mode0
     assert (d2.tile, d2.splits) == (s.tile, s.splits)
 
 
@@ -249,6 +245,51 @@ def test_fullsize_cfg_forward_vs_oracle(dev, fuser):
         gate(f"[full, fuser={fuser}] map {k} rel-L2", el2, 1.2e-2)
     _FULL[("eps", fuser)] = eps
     _FULL[("maps", fuser)] = {k: plan.maps[k].clone() for k in keys}
+
+
+def test_fullsize_cfg_forward_throughput_table_vs_oracle(dev):
+    """The timed region of bench.py runs 4 lanes, whose engines build their plans from the SHARED-GPU GEMM table
+    (`tuning_mode = "throughput"`: tuning_gfx950_lanes.json over tuning_gfx950.json, 86 entries with other tiles / fewer
+    split-K slabs).  Same full-width network, same inputs, same oracle comparison as above, on an engine in that mode
+    (sharing the parameters, as lane engines do); also: the two tables really give different launch plans, and the
+    results differ only by accumulation order."""
+    import restate as R
+    f = full(dev)
+    cfg = f["cfg"]
+    eng = UNetEngine(cfg, dev, weights=f["eng"].w)
+    eng.tuning_mode = "throughput"
+    x, ehs, _, gl = _inputs(cfg, dev)
+    keys = [OBJ_KEY, *KEYS]
+    with ops.tuning("latency"):
+        lat_tab = dict(ops.tuning_table())
+    for B, fuser in ((2, True), (8, True), (2, False)):
+        with ops.desc_log() as log:
+            plan = eng.plan(B, 64, fuser=fuser, save_keys=keys)
+        # launches whose (tile, split-K) differs from what the single-sequence table gives the same shape
+        n_diff = sum(1 for key, tile, splits in log
+                     if key in lat_tab and (lat_tab[key]["tile"], lat_tab[key]["splits"]) != (tile, splits))
+        print(f"[throughput table] B={B} fuser={fuser}: {n_diff} of {len(log)} GEMM launches use another tile / split-K")
+        if B == 8:
+            assert n_diff > 0, "the throughput table did not change a single launch of the B = 8 plan"
+            continue
+        eng.prepare_timesteps([501])
+        eng.set_step(0)
+        eng.prepare_text(ehs)
+        eng.prepare_gligen(boxes=gl[0], positive_embeddings=gl[1], masks=gl[2])
+        eps = plan.forward(x.to(dev)).cpu()
+        saved = {}
+        with torch.no_grad():
+            ref = R.unet_forward(f["sd"], f["cd"], x, 501, ehs, saved=saved, save_keys=keys, fuser_enabled=fuser,
+                                 gligen=dict(boxes=gl[0].cpu(), positive_embeddings=gl[1].cpu(), masks=gl[2].cpu()))
+        gate(f"[full, throughput table, fuser={fuser}] eps relerr", relerr(eps, ref), 5e-3)
+        gate(f"[full, throughput table, fuser={fuser}] eps rel-L2", rel_l2(eps, ref), 6e-3)
+        for k in keys:
+            gate(f"[full, throughput table, fuser={fuser}] map {k} relerr", relerr(plan.maps[k], saved[k]), 2.7e-2)
+            gate(f"[full, throughput table, fuser={fuser}] map {k} rel-L2", rel_l2(plan.maps[k], saved[k]), 1.2e-2)
+        if ("eps", fuser) in _FULL:
+            gate(f"[full, throughput vs latency table, fuser={fuser}] eps relerr", relerr(eps, _FULL[("eps", fuser)]), 3e-3)
+    del eng
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("nb", [4, 8])

@@ -477,3 +477,74 @@ def test_backward_guidance_run_vs_reference_run_golden(dev):
 def seeded_noise_of(seed, cfg):
     from lgd_amd.hostprep import seeded_noise
     return seeded_noise(seed, cfg.in_channels, 32, 32)
+
+
+def test_unet_wrapper_is_differentiable_wrt_sample_as_the_guidance_loop_drives_it(dropin, dev):
+    """SURVEY.md 8(b) `model_dict` row: the replacement UNet must "be differentiable w.r.t. `sample` under
+    torch.enable_grad()".  Driven exactly as models/pipelines.py:31-56 does — latents.requires_grad_(True); unet(...)
+    with `save_attn_to_dict` / `save_keys`; guidance.compute_ca_lossv3(saved_attn) * loss_scale;
+    torch.autograd.grad(loss.requires_grad_(True), [latents]) — through the drop-in
+    models.unet_2d_condition.UNet2DConditionModel (`_MapsFn`: the engine's explicit backward plan behind an autograd
+    node) and utils.guidance.compute_ca_lossv3 (`_EnergyFn`: the energy kernel's map gradients).  Reference values:
+    (max-based loss) the gradient of the first iteration of the reference's OWN latent_backward_guidance call,
+    tests/golden/guidance_tiny_gligen.npz `grad0` / `losses[0]`; (ratio loss = the default) the oracle on this box."""
+    if os.path.join(ROOT, "oracle") not in sys.path:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import restate as R
+    from lgd_amd import weights
+    from models import pipelines
+    from utils import guidance
+    md = dropin.model_dict
+    g = np.load(os.path.join(GOLD, "guidance_tiny_gligen.npz"))
+    f = np.load(os.path.join(GOLD, "unet_fwd_tiny_gligen.npz"))
+    cond = torch.from_numpy(g["cond"]).to(dev)
+    t = torch.tensor(int(g["t"]))
+    gl = dict(boxes=torch.from_numpy(f["gl_boxes"])[:1], positive_embeddings=torch.from_numpy(f["gl_emb"])[:1],
+              masks=torch.from_numpy(f["gl_masks"])[:1])
+    pipelines.gligen_enable_fuser(md.unet, True)
+    cos = lambda a, b: float(a.double().reshape(-1) @ b.double().reshape(-1) / (a.double().norm() * b.double().norm()))
+
+    def hip_grad(loss_kw, loss_scale):
+        latents = torch.from_numpy(g["latents_in"]).to(dev)
+        with torch.enable_grad():
+            latents.requires_grad_(True)
+            saved_attn = {}
+            kw = {'save_attn_to_dict': saved_attn, 'save_keys': KEYS, 'offload_cross_attn_to_cpu': False,
+                  'enable_flash_attn': False, 'gligen': gl}
+            out = md.unet(latents, t, encoder_hidden_states=cond, return_cross_attention_probs=False, cross_attention_kwargs=kw)
+            assert set(saved_attn) == set(KEYS) and all(m.requires_grad for m in saved_attn.values())
+            loss = guidance.compute_ca_lossv3(saved_attn=saved_attn, bboxes=BBOXES, object_positions=OBJ_POS,
+                                              guidance_attn_keys=KEYS, index=1, **loss_kw) * loss_scale
+            grad = torch.autograd.grad(loss.requires_grad_(True), [latents])[0]
+        latents.requires_grad_(False)
+        assert grad.shape == latents.shape and out.sample is None        # forward stops behind the last guidance key
+        return float(loss), grad.float().cpu()
+
+    # max-based loss, as LMD / LMD+ call it: against the reference's own first-iteration gradient
+    loss, grad = hip_grad(dict(use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0), 5)
+    want = torch.from_numpy(g["grad0"])
+    gate("[unet wrapper autograd, max-based] loss vs the reference's", abs(loss - float(g["losses"][0])) / float(g["losses"][0]), 2e-3)
+    gate("[unet wrapper autograd, max-based] latent-gradient cosine vs the reference's", cos(grad, want), 0.9998, at_least=True)
+    gate("[unet wrapper autograd, max-based] latent-gradient rel-L2", float((grad - want).norm() / want.norm()), 3e-2)
+    # the default (ratio-based, what generation/backward_guidance.py runs): against the oracle's autograd on this box
+    cfg = weights.CONFIGS["tiny_gligen"]
+    cd = dict(block_out_channels=cfg.block_out_channels, layers_per_block=cfg.layers_per_block,
+              attention_head_dim=cfg.attention_head_dim, norm_num_groups=cfg.norm_num_groups, norm_eps=cfg.norm_eps,
+              gligen_positive_len=cfg.gligen_positive_len)
+    sd = weights.synth_state_dict(cfg, 0)
+    lat = torch.from_numpy(g["latents_in"]).clone().requires_grad_(True)
+    saved = {}
+    R.unet_forward(sd, cd, lat, int(g["t"]), torch.from_numpy(g["cond"]), saved=saved, save_keys=KEYS, gligen=gl,
+                   fuser_enabled=True, stop_after=KEYS[-1])
+    loss_o = R.compute_ca_lossv3(saved, BBOXES, OBJ_POS, KEYS, index=1) * 30
+    want = torch.autograd.grad(loss_o, [lat])[0]
+    loss, grad = hip_grad({}, 30)
+    gate("[unet wrapper autograd, ratio default] loss vs oracle", abs(loss - float(loss_o)) / float(loss_o), 2e-3)
+    gate("[unet wrapper autograd, ratio default] latent-gradient cosine vs oracle", cos(grad, want), 0.9998, at_least=True)
+    gate("[unet wrapper autograd, ratio default] latent-gradient rel-L2", float((grad - want).norm() / want.norm()), 3e-2)
+    # without grad mode the same call is a plain forward with detached maps
+    with torch.no_grad():
+        saved_attn = {}
+        out = md.unet(torch.from_numpy(g["latents_in"]).to(dev), t, encoder_hidden_states=cond,
+                      cross_attention_kwargs={'save_attn_to_dict': saved_attn, 'save_keys': KEYS, 'gligen': gl})
+        assert out.sample is not None and not any(m.requires_grad for m in saved_attn.values())
