@@ -172,6 +172,7 @@ def main_sdxl(args):
     from lgd_amd.lanes import LanePool, make_lanes
     from lgd_amd.unet import UNetEngine
     cfg = weights.CONFIGS[args.config]
+    ldist.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), lanes=max(1, args.lanes))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -258,7 +259,8 @@ def main_sdxl(args):
                            algorithmic_tflop_per_image=round(tf, 2) if tf else None,
                            weight_broadcast_s=round(bcast_s, 3), prebuild_s=round(prebuild_s, 2),
                            per_rank_busy_s=[round(b, 3) for b in per_rank_busy],
-                           per_rank_idle_s=[round(max(dt - b, 0.0), 3) for b in per_rank_busy]),
+                           per_rank_idle_s=[round(max(dt - b, 0.0), 3) for b in per_rank_busy],
+                           host=dict(torch_threads=1, rank0_cpu_affinity=(f"{pinned[0]}-{pinned[-1]}" if pinned else "unpinned"))),
                roofline=roofline)
     if tf:
         res["config"]["whole_path_frac_of_mfma_peak"] = round(tf * 1e12 * (n_images / dt) / world / MFMA_PEAK_F16, 4)
@@ -358,6 +360,7 @@ def main():
 
     if args.cpu_dryrun:
         from lgd_amd.weightstore import WeightStore
+        pinned = ldist.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), lanes=max(1, args.lanes))
         if world > 1:
             ldist.init(backend="gloo")
         ws = WeightStore(cfg, "cpu")
@@ -391,10 +394,12 @@ def main():
             print(json.dumps(dict(metric="dryrun", n_gpus=world, rccl_ranks=world, images=n_total,
                                   weight_broadcast_s=round(bcast_s, 4), per_rank_cost=loads, lanes_per_gpu=n_lanes,
                                   rank0_lane_cost=[round(c, 1) for c in lane_cost],
+                                  rank0_cpus=pinned, torch_threads=torch.get_num_threads(),
                                   weights_identical=abs(csum / world - float(ws.arena16.float().abs().sum())) < 1e-3,
                                   max_s=dt)))
         return
 
+    pinned = ldist.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), lanes=max(1, args.lanes))
     from lgd_amd import ops
     from lgd_amd.pipeline import backward_guidance_generate_batch, lmd_plus_generate_batch
     from lgd_amd.sampler import LMDSampler
@@ -596,7 +601,8 @@ def main():
                            lanes_per_gpu=len(lanes), gemm_tuning=lanes[0].engine.tuning_mode or ops.current_tuning_mode(),
                            weight_broadcast_s=round(bcast_s, 3), prebuild_s=round(prebuild_s, 2),
                            per_rank_busy_s=[round(b, 3) for b in per_rank_busy],
-                           per_rank_idle_s=[round(max(dt - b, 0.0), 3) for b in per_rank_busy]),
+                           per_rank_idle_s=[round(max(dt - b, 0.0), 3) for b in per_rank_busy],
+                           host=dict(torch_threads=1, rank0_cpu_affinity=(f"{pinned[0]}-{pinned[-1]}" if pinned else "unpinned"))),
                roofline=roofline)
     if tf:
         res["config"]["whole_path_frac_of_mfma_peak"] = round(tf * 1e12 * (n_images / dt) / world / MFMA_PEAK_F16, 4)

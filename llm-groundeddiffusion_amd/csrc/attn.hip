@@ -1013,8 +1013,7 @@ void launch_attn_dp(const AttnArgs& a, hipStream_t st) {
     if constexpr (DP <= 96) {
       // 8-wave workgroups (256 queries share each staged K / V^T tile) pay where the head is narrow: measured
       // +15 % at d = 40 (S = 4096), +4 % at d = 80, -15 % at d = 64 (S = 9216).  LGD_ATTN_NW=4 / 8 overrides (tools).
-      static int nw_env = -1;
-      if (nw_env < 0) { const char* e = getenv("LGD_ATTN_NW"); nw_env = e ? atoi(e) : 0; }
+      static const int nw_env = [] { const char* e = getenv("LGD_ATTN_NW"); return e ? atoi(e) : 0; }();
       const bool nw8 = nw_env ? nw_env == 8 : ((DP == 64 && a.d < 48) || DP == 96);
       if (qt2 && nw8 && (long)((a.Sq + 255) / 256) * a.H * a.B >= 512) {
         dim3 g8((a.Sq + 255) / 256, a.H, a.B);

@@ -717,12 +717,12 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_mfma_kernel(const CrossBwd
 template <int DP>
 int launch_cross_bwd_mfma(const CrossBwdArgs& a, hipStream_t st) {
   const size_t smem = (size_t)(2 * XM_KEYS * (DP + 16) + DP * XM_LD) * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [smem] {      // thread-safe one-time initialisation (lane threads launch concurrently)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn_bwd_mfma_kernel<DP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   hipLaunchKernelGGL((cross_attn_bwd_mfma_kernel<DP>), dim3((a.Sq + 255) / 256, a.H, a.B), dim3(256), smem, st, a);
   return lgd_check_launch();
 }
@@ -733,14 +733,14 @@ int launch_bwd_nt(const AttnBwdArgs& a, hipStream_t st) {
   constexpr int NST = DB ? 2 : 1;
   const size_t smem_dq = (size_t)NST * (2 * T64 * K_LD + DP * TR_LD) * 2;
   const size_t smem_dkv = (size_t)NST * ((2 * T64 * K_LD + 2 * DP * TR_LD) * 2 + 2 * T64 * 4);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [smem_dq, smem_dkv] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DP, NK, NDT, NW, DB>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dkv);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DP, NQ, NDT, NW, DB>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dq);
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, NQ, NDT, NW, DB>), dim3((a.Sq + 16 * NW * NQ - 1) / (16 * NW * NQ), a.H, a.B),
                      dim3(64 * NW), smem_dq, st, a);
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, NK, NDT, NW, DB>), dim3((a.Sk + 16 * NW * NK - 1) / (16 * NW * NK), a.H, a.B),
@@ -756,8 +756,7 @@ int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
   // Measured (tools/attn_bwd_quick.py, same box): d = 40, S = 4096: 607 -> 587 (1) -> 547 us (2); with the fuser's
   // 4126 keys 679 -> 653 -> 655; d = 80 and d = 160 unchanged; d = 64 at S = 9216 (SD2.1): 1067 -> 1199 us with two stages
   // (79 KB of LDS per workgroup halves the resident workgroups) — so only the narrow-head case takes the new variants.
-  static int env = -1;
-  if (env == -1) { const char* e = getenv("LGD_ATTN_BWD"); env = e ? atoi(e) : -2; }
+  static const int env = [] { const char* e = getenv("LGD_ATTN_BWD"); return e ? atoi(e) : -2; }();
   const bool narrow = env == -2;           // default: new variants for d <= 48 only
   const int mode = narrow ? 0 : env;
   if constexpr (DP == 64) {
@@ -844,12 +843,12 @@ extern "C" int lgd_cross_attn_bwd_f16(const void* q, int64_t ldq, int64_t q_bs, 
   const int ld = d + 2;
   size_t smem = (size_t)(2 * Sk * ld + 2) * 2 + (size_t)4 * 2 * XB_MAXD * 4 + (size_t)4 * XB_MAXSK * 4;
   smem = (smem + 15) & ~(size_t)15;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn_bwd_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3((Sq + 4 * XB_ROWS - 1) / (4 * XB_ROWS), H, B), dim3(256), smem,
                      reinterpret_cast<hipStream_t>(stream), a);
   return lgd_check_launch();

@@ -1202,18 +1202,19 @@ int launch_gemm_pipe_cm(const GemmArgs& ga, hipStream_t st) {
   constexpr int BM = WM * 16 * MI, BN = WN * 16 * NI;
   constexpr int SMEM = NS * (BM + BN) * BK * 2;
   const LgdGemmDesc& d = ga.d;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // function-local statics with initialisers: C++11 guarantees one thread runs the initialiser while the others wait
+  // (several lane threads launch GEMMs concurrently, lgd_amd/lanes.py)
+  static const bool attr_set = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   long tiles = (long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
   // persistent launch: as many workgroups as the chip holds at once (a multiple of 8, one share per XCD); each walks
   // tiles b, b + grid, ... with its DMA ring running across tile boundaries.  LGD_GEMM_PERSIST=0 = one tile per
   // workgroup (A/B timing).  Split-K / batched launches already spread over blockIdx.z and keep one tile each.
-  static long resident = -1;
-  if (resident < 0) {
+  static const long resident = [] {
     const char* e = getenv("LGD_GEMM_PERSIST");
     int per_cu = 0, cus = 0, dev = 0;
     (void)hipGetDevice(&dev);
@@ -1222,15 +1223,14 @@ int launch_gemm_pipe_cm(const GemmArgs& ga, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &per_cu, reinterpret_cast<const void*>(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, true>), 64 * WM * WN, SMEM);
-    resident = (e && e[0] == '0') ? 0 : (long)(cus / 8) * 8 * (per_cu > 0 ? per_cu : 1);
-  }
+    return (e && e[0] == '0') ? 0L : (long)(cus / 8) * 8 * (per_cu > 0 ? per_cu : 1);
+  }();
   // measured (tools/gemm_ab.py, LGD_GEMM_PERSIST=0 vs 1): +4..9 % where K <= 640 (5-10 K tiles per output tile: the
   // pipeline fill is a visible share of a tile), neutral to -8 % from K = 1280 up — enabled for short K walks only
   const bool persist = resident > 0 && d.nb_o * d.nb_i * d.splits == 1 && tiles > resident && d.K <= 10 * BK;
   dim3 grid((unsigned)(persist ? resident : tiles), 1, (unsigned)(d.nb_o * d.nb_i * d.splits));
 #ifdef LGD_GEMM_ABLATION
-  static int abl = -1;
-  if (abl < 0) { const char* e = getenv("LGD_GEMM_ABL"); abl = e ? atoi(e) : 0; }
+  static const int abl = [] { const char* e = getenv("LGD_GEMM_ABL"); return e ? atoi(e) : 0; }();
   if (abl) {
     auto go = [&](auto kern) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -1259,8 +1259,7 @@ int launch_gemm_pipe_cm(const GemmArgs& ga, hipStream_t st) {
 template <int MI, int NI, int WM, int WN, int NS>
 int launch_gemm_pipe(const GemmArgs& ga, hipStream_t st) {
   const LgdGemmDesc& d = ga.d;
-  static int no_cm = -1;
-  if (no_cm < 0) { const char* e = getenv("LGD_GEMM_NO_CM"); no_cm = (e && e[0] == '1') ? 1 : 0; }
+  static const int no_cm = [] { const char* e = getenv("LGD_GEMM_NO_CM"); return (e && e[0] == '1') ? 1 : 0; }();
   const bool cm = d.taps == 9 && d.stride == 1 && d.ups == 0 && d.c1 == 0 && !no_cm;
   return cm ? launch_gemm_pipe_cm<MI, NI, WM, WN, NS, true>(ga, st) : launch_gemm_pipe_cm<MI, NI, WM, WN, NS, false>(ga, st);
 }

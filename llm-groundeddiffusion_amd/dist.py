@@ -15,15 +15,53 @@ import torch
 import torch.distributed as dist
 
 
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def init(backend=None):
     if dist.is_initialized():
         return
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29500")
+    if "MASTER_PORT" not in os.environ:
+        # No fixed default port (two jobs on one host would collide on it).  A launcher (torch.distributed.run, the
+        # driver, bench.respawn) always names the port; only a single-process group can pick its own.
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise RuntimeError("MASTER_PORT is not set: ranks of one job must be given the same rendezvous port by "
+                               "their launcher (python -m torch.distributed.run --master-port P ...)")
+        os.environ["MASTER_PORT"] = str(_free_port())
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     dist.init_process_group(backend=backend)
+
+
+def pin_rank(local_rank: int, local_world: int, lanes: int = 1):
+    """Host-side hygiene of one rank among `local_world` on a node: (1) torch intra-op threads = 1 — the host code of
+    a rank is launch-bound Python plus tiny ATen CPU ops, and 8 ranks x 4 lane threads x an OpenMP pool of every core
+    would thrash the host; (2) CPU affinity = this rank's contiguous share of the cores it was allowed to use (at
+    least lanes + 1: one per lane thread + the main thread), so ranks do not migrate over each other's caches / NUMA
+    nodes.  Returns the core list (None where the platform has no sched_setaffinity).  The CPU-baseline leg of
+    bench.py (rank 0, N = 1 only) widens the thread count again for itself."""
+    torch.set_num_threads(1)
+    if not hasattr(os, "sched_setaffinity") or local_world <= 1:
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    per = len(cpus) // local_world
+    if per < 1:
+        return None                                           # fewer cores than ranks: leave the scheduler alone
+    mine = cpus[local_rank * per:(local_rank + 1) * per]
+    if len(mine) < min(lanes + 1, len(cpus)):
+        # not enough cores for lane threads + main thread in an exclusive share: overlap with the neighbours
+        lo = max(0, min(local_rank * per, len(cpus) - (lanes + 1)))
+        mine = cpus[lo:lo + lanes + 1]
+    os.sched_setaffinity(0, mine)
+    return mine
 
 
 def shutdown():

@@ -119,3 +119,56 @@ def test_cost_partition_is_complete_balanced_and_deterministic():
         assert parts == bench.partition_by_cost(costs, world)
     # per-image work of the default 2-box LMD+ image with all 65 iterations: SURVEY.md 8(d) "<= 359.8 TF"
     assert abs(bench.algorithmic_tflop(2, 50, 0.4, 55, 10) - 359.8) < 0.2
+
+
+def test_eight_rank_dryrun_balances_ranks_and_pins_hosts():
+    """BASELINE config[3] shape without a node: 8 ranks x 4 lanes over the 100-prompt lmd_v0.1 selection through
+    `bench.py --gpus 8 --cpu-dryrun` (gloo): every rank's algorithmic load within 5 % of the mean (the >= 6x of the
+    north star needs >= 0.75), lanes inside a rank balanced as far as ~3 layouts per lane allow, one torch intra-op
+    thread per rank and a private CPU share when the host has enough cores."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--cpu-dryrun", "--workload",
+                          "lmd_v0.1", "--prompts", "100", "--lanes", "4"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 8 and r["images"] == 100 and r["weights_identical"]
+    loads = r["per_rank_cost"]
+    assert len(loads) == 8 and max(loads) / (sum(loads) / 8) <= 1.05, loads
+    lc = r["rank0_lane_cost"]
+    assert len(lc) == 4 and abs(sum(lc) - loads[0]) < 1.0 and max(lc) / (sum(lc) / 4) <= 1.3, lc
+    assert r["torch_threads"] == 1
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= 8:
+        assert r["rank0_cpus"] is not None and len(r["rank0_cpus"]) >= min(ncpu // 8, 5) and r["rank0_cpus"][0] == sorted(os.sched_getaffinity(0))[0]
+
+
+def test_pin_rank_shares_are_disjoint_when_cores_suffice(monkeypatch):
+    from lgd_amd import dist as ldist
+    got = {}
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(64)))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: got.__setitem__("cpus", list(cpus)))
+    n0 = torch.get_num_threads()
+    try:
+        shares = [ldist.pin_rank(r, 8, lanes=4) for r in range(8)]
+        assert torch.get_num_threads() == 1
+        assert all(len(s) == 8 for s in shares) and sorted(c for s in shares for c in s) == list(range(64))
+        # fewer cores than lanes + 1 per rank: overlapping windows of lanes + 1 cores, never an empty set
+        monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(8)))
+        shares = [ldist.pin_rank(r, 8, lanes=4) for r in range(8)]
+        assert all(len(s) == 5 and set(s) <= set(range(8)) for s in shares)
+        assert ldist.pin_rank(0, 1, lanes=4) is None                 # one rank per node: the scheduler is left alone
+    finally:
+        torch.set_num_threads(n0)
+
+
+def test_init_needs_a_port_from_the_launcher(monkeypatch):
+    from lgd_amd import dist as ldist
+    import pytest
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        ldist.init(backend="gloo")
