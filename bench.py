@@ -314,6 +314,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--shape-profile", default=None, metavar="PATH",
+                    help="also write the per-launch-shape table of the roofline replay (ms / launches / TF/s per image) to PATH")
     ap.add_argument("--sam", action="store_true",
                     help="refine every per-box mask with SAM (sam-vit-base architecture, seeded random weights, "
                          "device-side processor) as real runs do; the default uses box masks (SURVEY.md 8d)")
@@ -505,7 +507,7 @@ def main():
     if not args.no_roofline and pass_counts:
         counts = pass_counts
         my_images = max(args.steps * len(lays), 1)
-        agg, tag_agg = {}, {}
+        agg, tag_agg, shape_agg = {}, {}, {}
         reps = 2
         mains = sorted({nb for (k, f, nb) in counts if k == "main"})
         guides = sorted({nb for (k, f, nb) in counts if k == "guide"})
@@ -522,7 +524,8 @@ def main():
                 fn()
             ops.PROFILER = None
             w = n_runs / reps / my_images                                 # per image of this rank
-            for dst, summ in ((agg, prof.summary()), (tag_agg, prof.summary(by_tag=True))):
+            for dst, summ in ((agg, prof.summary()), (tag_agg, prof.summary(by_tag=True)),
+                              (shape_agg, prof.summary(by_shape=True) if args.shape_profile else {})):
                 for k, v in summ.items():
                     a = dst.setdefault(k, dict(ms=0.0, flops=0.0, n=0.0, raw_ms=0.0, raw_n=0))
                     a["ms"] += v["ms"] * w
@@ -530,6 +533,13 @@ def main():
                     a["n"] += v["n"] * w
                     a["raw_ms"] += v["ms"]
                     a["raw_n"] += v["n"]
+        if args.shape_profile and shape_agg:
+            os.makedirs(os.path.dirname(os.path.abspath(args.shape_profile)), exist_ok=True)
+            with open(args.shape_profile, "w") as fh:
+                json.dump({k: dict(ms_per_image=round(v["ms"], 3), launches_per_image=round(v["n"], 1),
+                                   us_per_launch=round(v["raw_ms"] * 1e3 / max(v["raw_n"], 1), 2),
+                                   tflops=round(v["flops"] / max(v["ms"] * 1e-3, 1e-12) / 1e12, 1))
+                           for k, v in sorted(shape_agg.items(), key=lambda kv: -kv[1]["ms"])}, fh, indent=1)
         if agg:
             name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
             ach = a["flops"] / (a["ms"] * 1e-3)

@@ -257,24 +257,26 @@ class LaunchProfiler:
         self.max = max_records
         self.enabled = True
 
-    def wrap(self, name, flops, nbytes, fn, tag=None):
+    def wrap(self, name, flops, nbytes, fn, tag=None, shape=None):
         if not self.enabled or len(self.recs) >= self.max:
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         r = fn()
         e1.record()
-        self.recs.append((name, flops, nbytes, e0, e1, tag))
+        self.recs.append((name, flops, nbytes, e0, e1, tag, shape))
         return r
 
-    def summary(self, by_tag=False):
-        """Per kernel name (or per caller tag, e.g. "attn_path"): ms, algorithmic flops / bytes, launches."""
+    def summary(self, by_tag=False, by_shape=False):
+        """Per kernel name (or per caller tag, e.g. "attn_path"; or per launch shape "kernel | shape key"): ms,
+        algorithmic flops / bytes, launches."""
         torch.cuda.synchronize()
         agg = {}
-        for name, fl, nb, e0, e1, tag in self.recs:
+        for name, fl, nb, e0, e1, tag, shape in self.recs:
             if by_tag and tag is None:
                 continue
-            a = agg.setdefault(tag if by_tag else name, dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
+            key = tag if by_tag else (f"{name} | {shape}" if by_shape else name)
+            a = agg.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
             a["ms"] += e0.elapsed_time(e1)
             a["flops"] += fl
             a["bytes"] += nb
@@ -293,7 +295,8 @@ def gemm_launch(desc, tag=None, flops=None):
             flops = 2.0 * desc.M * desc.N * desc.K * nb
         nbytes = 2.0 * nb * (desc.M * desc.K / max(desc.taps, 1) + desc.N * desc.K + desc.M * desc.N)
         return PROFILER.wrap(TILE_NAMES.get(desc.tile, "gemm"), flops, nbytes,
-                             lambda: _call("lgd_gemm_f16", C.byref(desc), _stream()), tag)
+                             lambda: _call("lgd_gemm_f16", C.byref(desc), _stream()), tag,
+                             shape=f"{shape_key(desc)} splits={desc.splits}")
     _call("lgd_gemm_f16", C.byref(desc), _stream())
 
 
@@ -447,7 +450,7 @@ def attn_fwd(q, k, v, o, B, H, Sq, Sk, d, scale, *, lse=None, q_view=None, k_vie
                        _p(o), ov[0], ov[1], _p(lse), B, H, Sq, Sk, d, float(scale), _stream())
     if PROFILER is not None:
         PROFILER.wrap(f"attn_self_kernel d={d}", 4.0 * B * H * Sq * Sk * d, 2.0 * B * H * d * (2 * Sq + 2 * Sk), fn,
-                      "attn_path")
+                      "attn_path", shape=f"B{B}_H{H}_Sq{Sq}_Sk{Sk}")
     else:
         fn()
     return o

@@ -425,7 +425,9 @@ def test_backward_guidance_run_vs_reference_run_golden(dev):
             lay = build_layout(spec, kw["bg_seed"], kw["bg_seed"], DEFAULT_SO_NEGATIVE_PROMPT, DEFAULT_OVERALL_NEGATIVE_PROMPT, 256, 256)
             assert lay.overall_object_positions == json.loads(str(gold[f"{tag}_object_positions"]))
             boxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
-            assert np.allclose(np.array(boxes, dtype=np.float64).reshape(-1), np.array(json.loads(str(gold[f"{tag}_bboxes"]))).reshape(-1))
+            flat = lambda groups: [c for grp in groups for b in grp for c in b]
+            assert np.allclose(flat(boxes), flat(json.loads(str(gold[f"{tag}_bboxes"]))))
+            assert [len(g_) for g_ in boxes] == [len(g_) for g_ in json.loads(str(gold[f"{tag}_bboxes"]))]
             emb = torch.cat([lay.overall_uncond, lay.overall_cond])
             assert relerr(emb, gold[f"{tag}_text_embeddings"]) < 1e-6
             gkw = dict(num_inference_steps=8, loss_scale=kw["overall_loss_scale"], loss_threshold=kw["overall_loss_threshold"],
