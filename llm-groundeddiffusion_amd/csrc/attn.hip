@@ -18,6 +18,7 @@
 // pass 2 normalised probabilities, which are written to the fp32 map and fed to the PV product.
 #include "common.h"
 #include "../../include/lgd_hip.h"
+#include "attn_w4.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -34,6 +35,12 @@ int g_attn32 = -1;
 int attn32_mode() {
   if (g_attn32 < 0) { const char* e = getenv("LGD_ATTN32"); g_attn32 = e ? atoi(e) : 1; }
   return g_attn32;
+}
+
+int g_attn_w4 = -1;        // round-4 kernel for d = 40 (attn_w4.hip): 1 = default, 0 = never (A/B timing), 2 = for every size (tests)
+int attn_w4_mode() {
+  if (g_attn_w4 < 0) { const char* e = getenv("LGD_ATTN_W4"); g_attn_w4 = e ? atoi(e) : 1; }
+  return g_attn_w4;
 }
 
 constexpr int KV_T = 64;         // keys per tile
@@ -1038,6 +1045,19 @@ void launch_attn_dp(const AttnArgs& a, hipStream_t st) {
 template <bool SAVE_P>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
   const int d = a.d;
+  if constexpr (!SAVE_P) {
+    // d = 40 (SD1.x 64x64 level): the one-wave-per-SIMD kernel of attn_w4.hip once a launch has enough 256-query
+    // workgroups to occupy the chip (it holds ONE workgroup per CU); smaller problems keep the 4-waves-per-SIMD kernel
+    const int w4 = attn_w4_mode();
+    if (w4 && d == 40) {
+      AttnW4Args w;
+      w.q = a.q; w.ldq = a.ldq; w.q_bs = a.q_bs; w.k = a.k; w.ldk = a.ldk; w.k_bs = a.k_bs;
+      w.v = a.v; w.ldv = a.ldv; w.v_bs = a.v_bs; w.o = a.o; w.ldo = a.ldo; w.o_bs = a.o_bs; w.lse = a.lse;
+      w.B = a.B; w.H = a.H; w.Sq = a.Sq; w.Sk = a.Sk; w.d = a.d; w.scale_log2 = a.scale_log2;
+      const long wgs = (long)((a.Sq + 255) / 256) * a.H * a.B;
+      if (lgd_attn_w4_supported(w) && (w4 == 2 || (wgs >= 256 && a.Sk >= 256))) return lgd_attn_w4_launch(w, st);
+    }
+  }
   if (d <= 32) launch_attn_dp<32, SAVE_P>(a, st);
   else if (d <= 64) launch_attn_dp<64, SAVE_P>(a, st);
   else if (d <= 96) launch_attn_dp<96, SAVE_P>(a, st);
@@ -1055,6 +1075,7 @@ bool bad_view(int64_t ld, int d) { return (ld % 8) != 0 || (d % 8) != 0; }
 extern "C" int lgd_set_option(const char* name, int value) {
   if (!name) return LGD_ERR_ARG;
   if (!strcmp(name, "attn32")) { g_attn32 = value; return LGD_OK; }
+  if (!strcmp(name, "attn_w4") && value >= 0 && value <= 2) { g_attn_w4 = value; return LGD_OK; }
   if (!strcmp(name, "attn32_nw") && (value == 4 || value == 8)) { g_attn32_nw = value; return LGD_OK; }
   if (!strcmp(name, "attn32_var") && value >= 0 && value <= 2) { g_attn32_var = value; return LGD_OK; }
   return LGD_ERR_ARG;
