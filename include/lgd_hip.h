@@ -30,7 +30,10 @@ int lgd_abi_version(void);
 /* Kernel-variant switches of the library (A/B timing and tests; the defaults are what the benchmark runs).  No
  * counterpart in the reference.  "attn32": self-attention forward without map capture — 0 = the 16x16x32 kernel,
  * 1 = (default) the 32x32x16 software-pipelined kernel where it applies (d + 2 <= 96, enough work to fill the chip),
- * 2 = that kernel for every problem size.  Returns 0, or LGD_ERR_ARG for an unknown name. */
+ * 2 = that kernel for every problem size.  "attn_w4": the d = 40 kernel of round 4 (csrc/attn_w4.hip: 4-wave
+ * workgroups, LDS-DMA K / V, transposing V reads) — 0 = never, 1 = (default) once a launch has >= 256 workgroups of
+ * 256 queries and >= 256 keys, 2 = for every problem size; "attn_w4_pipe": 1 = (default) one wave per SIMD with the
+ * in-wave software pipeline, 0 = two waves per SIMD.  Returns 0, or LGD_ERR_ARG for an unknown name. */
 int lgd_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------------------------------------

@@ -1006,7 +1006,8 @@ void launch_attn_dp(const AttnArgs& a, hipStream_t st) {
           if (dk == 48) { go(&attn_self32_kernel<48, 2, 8, 4, true>, 8); return; }
           if (dk == 96) { go(&attn_self32_kernel<96, 3, 8, 4, true>, 8); return; }
         } else if (var == 2) {
-          if (dk == 48) { go(&attn_self32_kernel<48, 2, 8, 1, true, 4>, 8); return; }     // <= 128 VGPRs: two workgroups per CU
+          // (the <= 128-VGPR, two-workgroups-per-CU build of the dk = 48 kernel spilled 76 registers and is gone)
+          if (dk == 48) { go(&attn_self32_kernel<48, 2, 8, 2, false>, 8); return; }
           if (dk == 96) { go(&attn_self32_kernel<96, 3, 8, 2, false>, 8); return; }
         } else {
           if (dk == 48) { go(&attn_self32_kernel<48, 2, 8>, 8); return; }
@@ -1076,6 +1077,7 @@ extern "C" int lgd_set_option(const char* name, int value) {
   if (!name) return LGD_ERR_ARG;
   if (!strcmp(name, "attn32")) { g_attn32 = value; return LGD_OK; }
   if (!strcmp(name, "attn_w4") && value >= 0 && value <= 2) { g_attn_w4 = value; return LGD_OK; }
+  if (!strcmp(name, "attn_w4_pipe") && (value == 0 || value == 1)) { lgd_attn_w4_set_pipe(value); return LGD_OK; }
   if (!strcmp(name, "attn32_nw") && (value == 4 || value == 8)) { g_attn32_nw = value; return LGD_OK; }
   if (!strcmp(name, "attn32_var") && value >= 0 && value <= 2) { g_attn32_var = value; return LGD_OK; }
   return LGD_ERR_ARG;

@@ -771,7 +771,9 @@ int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
   }
   if constexpr (DP <= 96) {
     if (wgs >= 512) {
-      if (mode == 2 && wgs >= 1024) return launch_bwd_nt<DP, 2, 2, DP / 16, 8, true>(a, st);
+      // (8-wave double-buffered kernels exist for DP = 64 only: at DP = 96 the dK/dV kernel spilled 92 registers)
+      if constexpr (DP == 64)
+        if (mode == 2 && wgs >= 1024) return launch_bwd_nt<DP, 2, 2, DP / 16, 8, true>(a, st);
       if (mode >= 1) return launch_bwd_nt<DP, 2, 2, DP / 16, 4, true>(a, st);
       return launch_bwd_nt<DP, 2, 2, DP / 16>(a, st);
     }

@@ -15,3 +15,4 @@ struct AttnW4Args {
 
 int lgd_attn_w4_supported(const AttnW4Args& a);
 int lgd_attn_w4_launch(const AttnW4Args& a, hipStream_t st);
+void lgd_attn_w4_set_pipe(int v);          // 1: one wave per SIMD, in-wave software pipeline; 0: two waves per SIMD

@@ -131,8 +131,11 @@ __device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, I...>)
 
 // ABL (tools only; results are wrong by design): 1 = no DMA in the loop, 2 = no barrier / DMA wait, 4 = no exponentials,
 // 8 = no V fragment reads, 16 = no MFMA, 32 = no row max — the cost of each ingredient by removal.
-template <int ABL>
-__global__ __launch_bounds__(256, 1) void attn_w4_kernel(const AttnW4Args a) {
+// PIPE = true: ONE wave per SIMD, the wave software-pipelines S(t+1) against P(t) / PV(t) itself (28-slot schedule below).
+// PIPE = false: TWO waves per SIMD (two workgroups per CU, <= 256 registers per lane): a wave runs QK^T, softmax, PV of
+// a key tile one after the other and the SIMD's other wave fills the pipe it leaves idle.
+template <int ABL, bool PIPE>
+__global__ __launch_bounds__(256, PIPE ? 1 : 2) void attn_w4_kernel(const AttnW4Args a) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_B];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,48 +174,46 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const AttnW4Args a) {
     else { src[n] = reinterpret_cast<const char*>(g_w4_lines + ((sg == 5 && !pad) ? 0 : 16)); inc[n] = 0; }
     dst[n] = lds0 + (pad ? DUMMY_B : (isk ? 0 : V0_B) + j * 1024);
   }
-  // `RAGGED`: compile-time switch between the hot form and the form that zeroes the padded keys of a ragged last tile
-  auto issue_one = [&](int n, bool isk, bool live, unsigned stage, auto RAGGED) {
-    const bool pad = (n & 1) && pad_hi;
-    const char* p = src[n];
-    if constexpr (decltype(RAGGED)::value) {
-      const int x = (wid + 4 * (n & 1)) * 64 + lane;
-      const int r = x / SEGS, sg = x - r * SEGS;
-      if (r >= rem_last && !pad)                                           // padded key: zeros, K slot 41 = 1
-        p = reinterpret_cast<const char*>(g_w4_lines + ((sg == 5 && isk) ? 8 : 16));
-    }
-    if (!live) p = reinterpret_cast<const char*>(g_w4_lines + 16);        // past the last tile: padding instruction
-    dma16(p, (live && !pad) ? dst[n] + stage * TILE_B : lds0 + DUMMY_B);
-    src[n] += inc[n];
-  };
+  unsigned smul[N_PER_WAVE];    // bytes per ring stage (0 for a padding slot: it always writes the dummy KiB)
+#pragma unroll
+  for (int n = 0; n < N_PER_WAVE; ++n) smul[n] = ((n & 1) && pad_hi) ? 0u : (unsigned)TILE_B;
   // ring positions of the next V / K tile to be issued
   int tv_next = 0, tk_next = 0;
   unsigned vs_next = 0, ks_next = 0;
   const int t_ragged = rem_last < 64 ? n_tiles - 1 : n_tiles;          // the tile with padded keys, if any
-  auto issue_v = [&]() {                   // the wave's two instructions of the next V tile
-    const bool live = tv_next < n_tiles;
-    if (__builtin_expect(tv_next == t_ragged, 0)) {
-      issue_one(0, false, live, vs_next, std::true_type{});
-      issue_one(1, false, live, vs_next, std::true_type{});
+  // One DMA instruction (slot n: 0, 1 = V pieces, 2, 3 = K pieces) of the next V / K tile.  STEADY = the tile is an
+  // interior one (exists, no padded keys): no condition at all — with ONE wave per SIMD every taken branch is an exposed
+  // instruction-fetch bubble, so the steady-state loop below is branch-free apart from the (not taken) vote.
+  auto issue_one = [&](auto N_, auto STEADY) {
+    constexpr int n = decltype(N_)::value;
+    constexpr bool isk = n >= 2;
+    const unsigned stage = isk ? ks_next : vs_next;
+    if constexpr (decltype(STEADY)::value) {
+      dma16(src[n], dst[n] + stage * smul[n]);
     } else {
-      issue_one(0, false, live, vs_next, std::false_type{});
-      issue_one(1, false, live, vs_next, std::false_type{});
+      const int T = isk ? tk_next : tv_next;
+      const bool pad = (n & 1) && pad_hi;
+      const char* p = src[n];
+      if (T == t_ragged) {                                                 // ragged last tile (uniform branch)
+        const int x = (wid + 4 * (n & 1)) * 64 + lane;
+        const int r = x / SEGS, sg = x - r * SEGS;
+        if (r >= rem_last && !pad)                                         // padded key: zeros, K slot 41 = 1
+          p = reinterpret_cast<const char*>(g_w4_lines + ((sg == 5 && isk) ? 8 : 16));
+      }
+      const bool live = T < n_tiles;
+      if (!live) p = reinterpret_cast<const char*>(g_w4_lines + 16);      // past the last tile: padding instruction
+      dma16(p, live ? dst[n] + stage * smul[n] : lds0 + DUMMY_B);
     }
-    ++tv_next;
-    vs_next = vs_next == V_STAGES - 1 ? 0 : vs_next + 1;
+    src[n] += inc[n];
   };
-  auto issue_k = [&]() {
-    const bool live = tk_next < n_tiles;
-    if (__builtin_expect(tk_next == t_ragged, 0)) {
-      issue_one(2, true, live, ks_next, std::true_type{});
-      issue_one(3, true, live, ks_next, std::true_type{});
-    } else {
-      issue_one(2, true, live, ks_next, std::false_type{});
-      issue_one(3, true, live, ks_next, std::false_type{});
-    }
-    ++tk_next;
-    ks_next = ks_next == K_STAGES - 1 ? 0 : ks_next + 1;
-  };
+  auto advance_v = [&]() { ++tv_next; vs_next = vs_next == V_STAGES - 1 ? 0 : vs_next + 1; };
+  auto advance_k = [&]() { ++tk_next; ks_next = ks_next == K_STAGES - 1 ? 0 : ks_next + 1; };
+  using I0_ = std::integral_constant<int, 0>;
+  using I1_ = std::integral_constant<int, 1>;
+  using I2_ = std::integral_constant<int, 2>;
+  using I3_ = std::integral_constant<int, 3>;
+  auto issue_v = [&]() { issue_one(I0_{}, std::false_type{}); issue_one(I1_{}, std::false_type{}); advance_v(); };
+  auto issue_k = [&]() { issue_one(I2_{}, std::false_type{}); issue_one(I3_{}, std::false_type{}); advance_k(); };
 
   // ---- claim the asm-owned AGPRs (the clobber list makes them part of the kernel's register allocation) and clear O
   asm volatile("" ::: LGD_W4_AGPR_CLOBBERS);
@@ -296,169 +297,238 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const AttnW4Args a) {
     return pair_max(mx);
   };
 
-  // ---- prologue: K(0..3), V(0), V(1) on their way; S(0) referenced to its own row max; fragments of K(1) requested
-  issue_v(); issue_v();
-  issue_k(); issue_k(); issue_k(); issue_k();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  read_k(0);
-  for_seq([&](auto I) { qk_mfma(I, sA); }, std::make_integer_sequence<int, 12>{});
-  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sA[0][0]), "+v"(sA[0][1]), "+v"(sA[1][0]), "+v"(sA[1][1]));
-  auto first_ref = [&](auto QB) {
-    constexpr int qb = decltype(QB)::value;
-    const float m = (float)(half_t)tile_max(sA[qb]);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sA[qb][kb][r] -= m;
-    set_ref(QB, m);
-  };
-  first_ref(std::integral_constant<int, 0>{});
-  first_ref(std::integral_constant<int, 1>{});
-  if (n_tiles > 1) read_k(1);
-  unsigned kr_stage = 2;                 // stage of K(t+2), whose fragments iteration t requests
-  unsigned vr_stage = 0;                 // stage of V(t)
+  if constexpr (PIPE) {
+    // ---- prologue: K(0..3), V(0), V(1) on their way; S(0) referenced to its own row max; fragments of K(1) requested
+    issue_v(); issue_v();
+    issue_k(); issue_k(); issue_k(); issue_k();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    read_k(0);
+    for_seq([&](auto I) { qk_mfma(I, sA); }, std::make_integer_sequence<int, 12>{});
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sA[0][0]), "+v"(sA[0][1]), "+v"(sA[1][0]), "+v"(sA[1][1]));
+    auto first_ref = [&](auto QB) {
+      constexpr int qb = decltype(QB)::value;
+      const float m = (float)(half_t)tile_max(sA[qb]);
+  #pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) sA[qb][kb][r] -= m;
+      set_ref(QB, m);
+    };
+    first_ref(std::integral_constant<int, 0>{});
+    first_ref(std::integral_constant<int, 1>{});
+    if (n_tiles > 1) read_k(1);
+    unsigned kr_stage = 2;                 // stage of K(t+2), whose fragments iteration t requests
+    unsigned vr_stage = 0;                 // stage of V(t)
 
-  // One key tile = 28 MFMA slots (12 of S(t+1) = K(t+1) Q^T, 16 of O += V(t)^T P(t)), every slot = {one MFMA, its share
-  // of the softmax VALU work, at most two LDS fragment requests}, pinned in this order (sched_barrier): the VALU and
-  // LDS instructions sit in the issue gaps of the wave's own MFMAs.  What a gap hides was measured
-  // (tools/probe_mfma_valu_overlap.hip, one wave per SIMD): 15.3 ns per MFMA with up to 3 v_exp_f32 or 5 plain VALU
-  // instructions beside it, +3.4 ns for every further exponential — so the 64 exponentials of a tile are dealt out
-  // three per slot in the order the PV MFMAs need them (k-step 0 by slot 12, 1 by 16, 2 by 20, 3 by 24), the row max of
-  // S(t+1) two steps per slot from slot 12 on, the V fragments six slots ahead of their MFMAs and the K fragments of
-  // the next iteration in the last six slots.
-  // `sc` holds S(t) (referenced), `sn` receives S(t+1); the caller alternates the two register blocks.
-  auto tile = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], bool rd_k) {
-    // V(t+2) -> stage of V(t-1) (read in iteration t-1), K(t+4) -> stage of K(t+1) (fragments read at the end of
-    // iteration t-1): the barrier at the end of iteration t-1 lies in between
-    if constexpr (!(ABL & 1)) {
-      issue_v();
-      issue_k();
-    }
-    const unsigned char* vbase = v_lane + vr_stage * TILE_B;
-    const unsigned char* kbase = k_lane + kr_stage * TILE_B;
-    half8_t vf[2][4], pf[2][4];
-    float pe[64];
-    float mx[2] = {0.f, 0.f};
-    if constexpr (ABL & 8)
-      for (int i = 0; i < 8; ++i) vf[i & 1][i >> 1] = kf[i % 6];
-    // V^T fragment (dvb, ku), A operand of O^T = V^T P^T: two transposing reads (key rows 16 ku + 4 hh + 0..3 and + 8
-    // of the natural [key][dv] tile), in the key order the P registers have
-    auto read_v = [&](auto DVB, auto KU) {
-      constexpr int dvb = decltype(DVB)::value, ku = decltype(KU)::value;
-      const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(uintptr_t)(unsigned)(uintptr_t)(vbase + ku * 16 * ROWB + dvb * 64));
-      const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(uintptr_t)(unsigned)(uintptr_t)(vbase + ku * 16 * ROWB + 8 * ROWB + dvb * 64));
-      const short8_t both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      vf[dvb][ku] = __builtin_bit_cast(half8_t, both);
-    };
-    // exponential E (0..63), in the order the PV MFMAs need them: k-step ku = E / 16, query block (E % 16) / 8
-    auto exp_one = [&](auto E_) {
-      constexpr int E = decltype(E_)::value, ku = E / 16, qb = (E % 16) / 8, j = E % 8;
-      if constexpr (ABL & 4) pe[E] = sc[qb][ku / 2][8 * (ku % 2) + j];
-      else pe[E] = __builtin_amdgcn_exp2f(sc[qb][ku / 2][8 * (ku % 2) + j]);
-      if constexpr (j % 2 == 1) {
-        pf[qb][ku][j - 1] = (half_t)pe[E - 1];
-        pf[qb][ku][j] = (half_t)pe[E];
-        // the packs happen HERE, not in front of the MFMA that reads the fragment (hipcc sinks them there otherwise,
-        // and an asm MFMA gets no wait states behind a VALU write of its operand)
-        if constexpr (j == 7) asm volatile("" : "+v"(pf[qb][ku]));
-      }
-    };
-    auto slot = [&](auto S_) {
-      constexpr int S = decltype(S_)::value;
-      using I0 = std::integral_constant<int, 0>;
-      using I1 = std::integral_constant<int, 1>;
-      if constexpr (ABL & 16) {
-        if constexpr (S < 12) asm volatile("" : "+v"(sn[S % 2][(S / 2) % 2]) : "v"(kf[S / 2]));
-        else asm volatile("" ::"v"(vf[((S - 12) / 2) % 2][(S - 12) / 4]), "v"(pf[(S - 12) % 2][(S - 12) / 4]));
-      } else if constexpr (S < 12) {
-        qk_mfma(S_, sn);
-      } else {
-        constexpr int M = S - 12, ku = M / 4, dvb = (M / 2) % 2, qb = M % 2;
-        mfma_pv<2 * qb + dvb>(vf[dvb][ku], pf[qb][ku]);
-      }
-      // three exponentials per slot (slots 0..21: 64 of them, 66 places)
-      if constexpr (3 * S < 64) exp_one(std::integral_constant<int, 3 * S>{});
-      if constexpr (3 * S + 1 < 64) exp_one(std::integral_constant<int, 3 * S + 1>{});
-      if constexpr (3 * S + 2 < 64) exp_one(std::integral_constant<int, 3 * S + 2>{});
-      // V fragments: k-step ku's two fragments in slots 4 ku + 4, 4 ku + 5 (their MFMAs start at slot 12 + 4 ku)
-      if constexpr (S >= 4 && S < 20 && (S % 4) < 2 && !(ABL & 8))
-        read_v(std::integral_constant<int, S % 4>{}, std::integral_constant<int, (S - 4) / 4>{});
-      // row max of S(t+1), complete since slot 11 (the asm MFMAs' results need no explicit wait states by now: the last
-      // one is >= 1 MFMA = 64+ cycles back at slot 12... the first step reads the chain that finished at slot 8)
-      if constexpr (S >= 12 && !(ABL & 32)) {
-        constexpr int q = (S - 12) / 8, st0 = 2 * ((S - 12) % 8);
-        max_step(std::integral_constant<int, st0>{}, mx[q], sn[q]);
-        max_step(std::integral_constant<int, st0 + 1>{}, mx[q], sn[q]);
-        asm volatile("" : "+v"(mx[q]));          // keeps the steps in this slot (they would sink to the vote)
-      }
-      // fragments of K(t+2) for the next iteration (landed before the previous barrier)
-      if constexpr (S >= 22)
-        if (rd_k) kf[S - 22] = *reinterpret_cast<const half8_t*>(kbase + ((S - 22) & 1) * 32 * ROWB + ((S - 22) >> 1) * 32);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    for_seq(slot, std::make_integer_sequence<int, 28>{});
-    kr_stage = kr_stage == K_STAGES - 1 ? 0 : kr_stage + 1;
-    vr_stage = vr_stage == V_STAGES - 1 ? 0 : vr_stage + 1;
-    mx[0] = pair_max(mx[0]);
-    mx[1] = pair_max(mx[1]);
-    // reference of tile t+1: raised on a wave-uniform vote only (row max more than 2^8 above it); PV(t) is complete in
-    // issue order, so the rescale covers everything accumulated at the old reference exactly once (S(t+1) is shifted)
-    if (__builtin_amdgcn_ballot_w64(fmaxf(mx[0], mx[1]) > 8.f) != 0) {
-      asm volatile("s_nop 15\n\ts_nop 3");          // the last PV MFMAs have written their accumulators
-      auto raise = [&](auto QB) {
-        constexpr int qb = decltype(QB)::value;
-        const float m_new = (float)(half_t)fmaxf(m_ref[qb], mx[qb] + m_ref[qb]);
-        const float shift = m_new - m_ref[qb];
-        agpr_scale<32 * qb, 32>(__builtin_amdgcn_exp2f(-shift));
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sn[qb][kb][r] -= shift;
-        set_ref(QB, m_new);
-      };
-      raise(std::integral_constant<int, 0>{});
-      raise(std::integral_constant<int, 1>{});
-    }
-    // Everything but this iteration's four DMA instructions has landed: V(t+1) and K(t+3) of the previous iteration's
-    // issue.  Behind the barrier every wave is done with V(t)'s fragments and holds K(t+2)'s in registers.
-    if constexpr (!(ABL & 2)) {
-      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-  };
-  // the last key tile: nothing to multiply ahead
-  auto last_tile = [&](f32x16 (&sc)[2][2]) {
-    const unsigned char* vbase = v_lane + vr_stage * TILE_B;
-#pragma unroll
-    for (int ku = 0; ku < 4; ++ku) {
-      half8_t pfq[2];
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pfq[qb][j] = (half_t)__builtin_amdgcn_exp2f(sc[qb][ku >> 1][8 * (ku & 1) + j]);
-      half8_t vfd[2];
-#pragma unroll
-      for (int dvb = 0; dvb < 2; ++dvb) {
+    // One key tile = 28 MFMA slots (12 of S(t+1) = K(t+1) Q^T, 16 of O += V(t)^T P(t)), every slot = {one MFMA, its share
+    // of the softmax VALU work, at most two LDS fragment requests}, pinned in this order (sched_barrier): the VALU and
+    // LDS instructions sit in the issue gaps of the wave's own MFMAs.  What a gap hides was measured
+    // (tools/probe_mfma_valu_overlap.hip, one wave per SIMD): 15.3 ns per MFMA with up to 3 v_exp_f32 or 5 plain VALU
+    // instructions beside it, +3.4 ns for every further exponential — so the 64 exponentials of a tile are dealt out
+    // three per slot in the order the PV MFMAs need them (k-step 0 by slot 12, 1 by 16, 2 by 20, 3 by 24), the row max of
+    // S(t+1) two steps per slot from slot 12 on, the V fragments six slots ahead of their MFMAs and the K fragments of
+    // the next iteration in the last six slots.
+    // `sc` holds S(t) (referenced), `sn` receives S(t+1); the caller alternates the two register blocks.
+    auto tile = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], bool rd_k, auto STEADY) {
+      // V(t+2) -> stage of V(t-1) (read in iteration t-1), K(t+4) -> stage of K(t+1) (fragments read at the end of
+      // iteration t-1): the barrier at the end of iteration t-1 lies in between.  The four DMA instructions sit behind
+      // the MFMAs of slots 1, 8, 15, 22 (an LDS-DMA instruction occupies the wave's issue for 60+ cycles).
+      const unsigned char* vbase = v_lane + vr_stage * TILE_B;
+      const unsigned char* kbase = k_lane + kr_stage * TILE_B;
+      half8_t vf[2][4], pf[2][4];
+      float pe[64];
+      float mx[2] = {0.f, 0.f};
+      if constexpr (ABL & 8)
+        for (int i = 0; i < 8; ++i) vf[i & 1][i >> 1] = kf[i % 6];
+      // V^T fragment (dvb, ku), A operand of O^T = V^T P^T: two transposing reads (key rows 16 ku + 4 hh + 0..3 and + 8
+      // of the natural [key][dv] tile), in the key order the P registers have
+      auto read_v = [&](auto DVB, auto KU) {
+        constexpr int dvb = decltype(DVB)::value, ku = decltype(KU)::value;
         const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(uintptr_t)(unsigned)(uintptr_t)(vbase + ku * 16 * ROWB + dvb * 64));
         const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(uintptr_t)(unsigned)(uintptr_t)(vbase + ku * 16 * ROWB + 8 * ROWB + dvb * 64));
         const short8_t both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        vfd[dvb] = __builtin_bit_cast(half8_t, both);
+        vf[dvb][ku] = __builtin_bit_cast(half8_t, both);
+      };
+      // exponential E (0..63), in the order the PV MFMAs need them: k-step ku = E / 16, query block (E % 16) / 8
+      auto exp_one = [&](auto E_) {
+        constexpr int E = decltype(E_)::value, ku = E / 16, qb = (E % 16) / 8, j = E % 8;
+        if constexpr (ABL & 4) pe[E] = sc[qb][ku / 2][8 * (ku % 2) + j];
+        else pe[E] = __builtin_amdgcn_exp2f(sc[qb][ku / 2][8 * (ku % 2) + j]);
+        if constexpr (j % 2 == 1) {
+          pf[qb][ku][j - 1] = (half_t)pe[E - 1];
+          pf[qb][ku][j] = (half_t)pe[E];
+          // the packs happen HERE, not in front of the MFMA that reads the fragment (hipcc sinks them there otherwise,
+          // and an asm MFMA gets no wait states behind a VALU write of its operand)
+          if constexpr (j == 7) asm volatile("" : "+v"(pf[qb][ku]));
+        }
+      };
+      auto slot = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        if constexpr (ABL & 16) {
+          if constexpr (S < 12) asm volatile("" : "+v"(sn[S % 2][(S / 2) % 2]) : "v"(kf[S / 2]));
+          else asm volatile("" ::"v"(vf[((S - 12) / 2) % 2][(S - 12) / 4]), "v"(pf[(S - 12) % 2][(S - 12) / 4]));
+        } else if constexpr (S < 12) {
+          qk_mfma(S_, sn);
+        } else {
+          constexpr int M = S - 12, ku = M / 4, dvb = (M / 2) % 2, qb = M % 2;
+          mfma_pv<2 * qb + dvb>(vf[dvb][ku], pf[qb][ku]);
+        }
+        // three exponentials per slot (slots 0..21: 64 of them, 66 places)
+        if constexpr (3 * S < 64) exp_one(std::integral_constant<int, 3 * S>{});
+        if constexpr (3 * S + 1 < 64) exp_one(std::integral_constant<int, 3 * S + 1>{});
+        if constexpr (3 * S + 2 < 64) exp_one(std::integral_constant<int, 3 * S + 2>{});
+        // V fragments: k-step ku's two fragments in slots 4 ku + 4, 4 ku + 5 (their MFMAs start at slot 12 + 4 ku)
+        if constexpr (S >= 4 && S < 20 && (S % 4) < 2 && !(ABL & 8))
+          read_v(std::integral_constant<int, S % 4>{}, std::integral_constant<int, (S - 4) / 4>{});
+        // row max of S(t+1), complete since slot 11 (the asm MFMAs' results need no explicit wait states by now: the last
+        // one is >= 1 MFMA = 64+ cycles back at slot 12... the first step reads the chain that finished at slot 8)
+        if constexpr (S >= 12 && !(ABL & 32)) {
+          constexpr int q = (S - 12) / 8, st0 = 2 * ((S - 12) % 8);
+          max_step(std::integral_constant<int, st0>{}, mx[q], sn[q]);
+          max_step(std::integral_constant<int, st0 + 1>{}, mx[q], sn[q]);
+          asm volatile("" : "+v"(mx[q]));          // keeps the steps in this slot (they would sink to the vote)
+        }
+        // fragments of K(t+2) for the next iteration (landed before the previous barrier)
+        if constexpr (S >= 22) {
+          if (decltype(STEADY)::value || rd_k)
+            kf[S - 22] = *reinterpret_cast<const half8_t*>(kbase + ((S - 22) & 1) * 32 * ROWB + ((S - 22) >> 1) * 32);
+        }
+        if constexpr (!(ABL & 1)) {
+          if constexpr (S == 1) issue_one(I0_{}, STEADY);
+          if constexpr (S == 8) { issue_one(I1_{}, STEADY); advance_v(); }
+          if constexpr (S == 15) issue_one(I2_{}, STEADY);
+          if constexpr (S == 22) { issue_one(I3_{}, STEADY); advance_k(); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      for_seq(slot, std::make_integer_sequence<int, 28>{});
+      kr_stage = kr_stage == K_STAGES - 1 ? 0 : kr_stage + 1;
+      vr_stage = vr_stage == V_STAGES - 1 ? 0 : vr_stage + 1;
+      mx[0] = pair_max(mx[0]);
+      mx[1] = pair_max(mx[1]);
+      // reference of tile t+1: raised on a wave-uniform vote only (row max more than 2^8 above it); PV(t) is complete in
+      // issue order, so the rescale covers everything accumulated at the old reference exactly once (S(t+1) is shifted)
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(fmaxf(mx[0], mx[1]) > 8.f) != 0, 0)) {
+        asm volatile("s_nop 15\n\ts_nop 3");          // the last PV MFMAs have written their accumulators
+        auto raise = [&](auto QB) {
+          constexpr int qb = decltype(QB)::value;
+          const float m_new = (float)(half_t)fmaxf(m_ref[qb], mx[qb] + m_ref[qb]);
+          const float shift = m_new - m_ref[qb];
+          agpr_scale<32 * qb, 32>(__builtin_amdgcn_exp2f(-shift));
+  #pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) sn[qb][kb][r] -= shift;
+          set_ref(QB, m_new);
+        };
+        raise(std::integral_constant<int, 0>{});
+        raise(std::integral_constant<int, 1>{});
       }
-      mfma_pv_fresh<0>(vfd[0], pfq[0]); mfma_pv_fresh<2>(vfd[0], pfq[1]);
-      mfma_pv<1>(vfd[1], pfq[0]); mfma_pv<3>(vfd[1], pfq[1]);
+      // Everything but this iteration's four DMA instructions has landed: V(t+1) and K(t+3) of the previous iteration's
+      // issue.  Behind the barrier every wave is done with V(t)'s fragments and holds K(t+2)'s in registers.
+      if constexpr (!(ABL & 2)) {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    };
+    // the last key tile: nothing to multiply ahead
+    auto last_tile = [&](f32x16 (&sc)[2][2]) {
+      const unsigned char* vbase = v_lane + vr_stage * TILE_B;
+  #pragma unroll
+      for (int ku = 0; ku < 4; ++ku) {
+        half8_t pfq[2];
+  #pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+  #pragma unroll
+          for (int j = 0; j < 8; ++j) pfq[qb][j] = (half_t)__builtin_amdgcn_exp2f(sc[qb][ku >> 1][8 * (ku & 1) + j]);
+        half8_t vfd[2];
+  #pragma unroll
+        for (int dvb = 0; dvb < 2; ++dvb) {
+          const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(uintptr_t)(unsigned)(uintptr_t)(vbase + ku * 16 * ROWB + dvb * 64));
+          const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(uintptr_t)(unsigned)(uintptr_t)(vbase + ku * 16 * ROWB + 8 * ROWB + dvb * 64));
+          const short8_t both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          vfd[dvb] = __builtin_bit_cast(half8_t, both);
+        }
+        mfma_pv_fresh<0>(vfd[0], pfq[0]); mfma_pv_fresh<2>(vfd[0], pfq[1]);
+        mfma_pv<1>(vfd[1], pfq[0]); mfma_pv<3>(vfd[1], pfq[1]);
+      }
+    };
+    int t = 0;
+    // steady state: both iterations issue interior tiles only (K(t+4), K(t+5) exist and have no padded keys)
+    for (; t + 5 < t_ragged; t += 2) {
+      tile(sA, sB, true, std::true_type{});
+      tile(sB, sA, true, std::true_type{});
     }
-  };
-  int t = 0;
-  for (; t + 2 < n_tiles; t += 2) {
-    tile(sA, sB, t + 2 < n_tiles);
-    tile(sB, sA, t + 3 < n_tiles);
-  }
-  if (t + 1 < n_tiles) {          // two tiles left
-    tile(sA, sB, false);
-    last_tile(sB);
+    for (; t + 2 < n_tiles; t += 2) {
+      tile(sA, sB, t + 2 < n_tiles, std::false_type{});
+      tile(sB, sA, t + 3 < n_tiles, std::false_type{});
+    }
+    if (t + 1 < n_tiles) {          // two tiles left
+      tile(sA, sB, false, std::false_type{});
+      last_tile(sB);
+    } else {
+      last_tile(sA);
+    }
   } else {
-    last_tile(sA);
+    // ---- two waves per SIMD: plain per-tile sequence.  K(0..2), V(0), V(1) on their way; iteration t issues V(t+2)
+    // (stage of V(t-1)) and K(t+3) (stage of K(t-1)) and waits, at its end, for the previous iteration's DMAs.
+    issue_v(); issue_v();
+    issue_k(); issue_k(); issue_k();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned kst = 0, vst = 0;
+    for (int t = 0; t < n_tiles; ++t) {
+      issue_v();
+      issue_k();
+      read_k(kst);
+      for_seq([&](auto I) { qk_mfma(I, sA); }, std::make_integer_sequence<int, 12>{});
+      asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sA[0][0]), "+v"(sA[0][1]), "+v"(sA[1][0]), "+v"(sA[1][1]));
+      float mx[2] = {tile_max(sA[0]), tile_max(sA[1])};
+      // reference: the first tile's own row max, afterwards raised on a wave-uniform vote only (row max more than 2^8
+      // above it); PV(t-1) is complete, so the rescale covers everything accumulated at the old reference exactly once
+      if (__builtin_expect(t == 0 || __builtin_amdgcn_ballot_w64(fmaxf(mx[0], mx[1]) > 8.f) != 0, 0)) {
+        asm volatile("s_nop 15\n\ts_nop 3");
+        auto raise = [&](auto QB) {
+          constexpr int qb = decltype(QB)::value;
+          const float m_new = (float)(half_t)(t == 0 ? mx[qb] : fmaxf(m_ref[qb], mx[qb] + m_ref[qb]));
+          const float shift = m_new - m_ref[qb];
+          agpr_scale<32 * qb, 32>(__builtin_amdgcn_exp2f(-shift));
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sA[qb][kb][r] -= shift;
+          set_ref(QB, m_new);
+        };
+        raise(std::integral_constant<int, 0>{});
+        raise(std::integral_constant<int, 1>{});
+      }
+      const unsigned char* vbase = v_lane + vst * TILE_B;
+#pragma unroll
+      for (int ku = 0; ku < 4; ++ku) {
+        half8_t pfq[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pfq[qb][j] = (half_t)__builtin_amdgcn_exp2f(sA[qb][ku >> 1][8 * (ku & 1) + j]);
+        half8_t vfd[2];
+#pragma unroll
+        for (int dvb = 0; dvb < 2; ++dvb) {
+          const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(uintptr_t)(unsigned)(uintptr_t)(vbase + ku * 16 * ROWB + dvb * 64));
+          const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(uintptr_t)(unsigned)(uintptr_t)(vbase + ku * 16 * ROWB + 8 * ROWB + dvb * 64));
+          const short8_t both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          vfd[dvb] = __builtin_bit_cast(half8_t, both);
+        }
+        mfma_pv_fresh<0>(vfd[0], pfq[0]); mfma_pv_fresh<2>(vfd[0], pfq[1]);
+        mfma_pv<1>(vfd[1], pfq[0]); mfma_pv<3>(vfd[1], pfq[1]);
+      }
+      kst = kst == K_STAGES - 1 ? 0 : kst + 1;
+      vst = vst == V_STAGES - 1 ? 0 : vst + 1;
+      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the padding instructions behind the last tile
   asm volatile("s_nop 15\n\ts_nop 3");              // the last PV MFMAs have written their accumulators
@@ -492,6 +562,9 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const AttnW4Args a) {
 
 }  // namespace
 
+static int g_w4_pipe = -1;
+void lgd_attn_w4_set_pipe(int v) { g_w4_pipe = v ? 1 : 0; }
+
 int lgd_attn_w4_supported(const AttnW4Args& a) {
   return a.d == D && a.Sq >= 1 && a.Sk >= 1 && (a.ldq % 8) == 0 && (a.ldk % 8) == 0 && (a.ldv % 8) == 0 && (a.ldo % 4) == 0;
 }
@@ -501,19 +574,24 @@ int lgd_attn_w4_launch(const AttnW4Args& a, hipStream_t st) {
 #ifdef LGD_W4_ABLATION
   static const int abl = [] { const char* e = getenv("LGD_W4_ABL"); return e ? atoi(e) : 0; }();
   switch (abl) {
-    case 1: hipLaunchKernelGGL(attn_w4_kernel<1>, grid, dim3(256), 0, st, a); return lgd_check_launch();
-    case 2: hipLaunchKernelGGL(attn_w4_kernel<2>, grid, dim3(256), 0, st, a); return lgd_check_launch();
-    case 3: hipLaunchKernelGGL(attn_w4_kernel<3>, grid, dim3(256), 0, st, a); return lgd_check_launch();
-    case 4: hipLaunchKernelGGL(attn_w4_kernel<4>, grid, dim3(256), 0, st, a); return lgd_check_launch();
-    case 8: hipLaunchKernelGGL(attn_w4_kernel<8>, grid, dim3(256), 0, st, a); return lgd_check_launch();
-    case 16: hipLaunchKernelGGL(attn_w4_kernel<16>, grid, dim3(256), 0, st, a); return lgd_check_launch();
-    case 32: hipLaunchKernelGGL(attn_w4_kernel<32>, grid, dim3(256), 0, st, a); return lgd_check_launch();
-    case 36: hipLaunchKernelGGL(attn_w4_kernel<36>, grid, dim3(256), 0, st, a); return lgd_check_launch();
-    case 47: hipLaunchKernelGGL(attn_w4_kernel<47>, grid, dim3(256), 0, st, a); return lgd_check_launch();
-    case 31: hipLaunchKernelGGL(attn_w4_kernel<31>, grid, dim3(256), 0, st, a); return lgd_check_launch();
+    case 1: hipLaunchKernelGGL((attn_w4_kernel<1, true>), grid, dim3(256), 0, st, a); return lgd_check_launch();
+    case 2: hipLaunchKernelGGL((attn_w4_kernel<2, true>), grid, dim3(256), 0, st, a); return lgd_check_launch();
+    case 3: hipLaunchKernelGGL((attn_w4_kernel<3, true>), grid, dim3(256), 0, st, a); return lgd_check_launch();
+    case 4: hipLaunchKernelGGL((attn_w4_kernel<4, true>), grid, dim3(256), 0, st, a); return lgd_check_launch();
+    case 8: hipLaunchKernelGGL((attn_w4_kernel<8, true>), grid, dim3(256), 0, st, a); return lgd_check_launch();
+    case 16: hipLaunchKernelGGL((attn_w4_kernel<16, true>), grid, dim3(256), 0, st, a); return lgd_check_launch();
+    case 32: hipLaunchKernelGGL((attn_w4_kernel<32, true>), grid, dim3(256), 0, st, a); return lgd_check_launch();
+    case 36: hipLaunchKernelGGL((attn_w4_kernel<36, true>), grid, dim3(256), 0, st, a); return lgd_check_launch();
+    case 47: hipLaunchKernelGGL((attn_w4_kernel<47, true>), grid, dim3(256), 0, st, a); return lgd_check_launch();
+    case 31: hipLaunchKernelGGL((attn_w4_kernel<31, true>), grid, dim3(256), 0, st, a); return lgd_check_launch();
     default: break;
   }
 #endif
-  hipLaunchKernelGGL(attn_w4_kernel<0>, grid, dim3(256), 0, st, a);
+  // variant (lgd_set_option("attn_w4_pipe", v); initial value from LGD_W4_PIPE): 1 = one wave per SIMD with the in-wave
+  // software pipeline (default), 0 = two waves per SIMD.  Measured equal within 2 % on MI355X (B = 16: 497 vs 500 us,
+  // B = 8: 264 vs 259 us) — both sit at the SUM of their MFMA and softmax-VALU time, see DESIGN.md.
+  if (g_w4_pipe < 0) { const char* e = getenv("LGD_W4_PIPE"); g_w4_pipe = e ? atoi(e) : 1; }
+  if (g_w4_pipe) hipLaunchKernelGGL((attn_w4_kernel<0, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((attn_w4_kernel<0, false>), grid, dim3(256), 0, st, a);
   return lgd_check_launch();
 }

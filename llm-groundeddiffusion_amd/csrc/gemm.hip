@@ -853,7 +853,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
   const int lrow = lane >> 3;
   const int kseg = (lane & 7) ^ ((((wid & 1) << 2) + (lrow >> 1)) & 7);
   const int cin = ga.cin;
-  const bool conv = d.taps == 9;
+  // persistent workgroups serve plain (taps == 1) contractions only (the launcher sees to it): a compile-time `false`
+  // removes the convolution's gather state from the tile-crossing kernels, which spilled 62-170 registers with it
+  const bool conv = PERSIST ? false : d.taps == 9;
   // K position of the next tile to issue.  Tap-major: (tap0, ch0) follow the weight layout.  Chunk-major:
   // tile t of the split's range is (chunk = t / 9, tap = t % 9).
   int tap0 = 0, ch0 = 0;
@@ -868,7 +870,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
   const bool b_half_on = (lane >> 5) == (wid & 1);
   const half_t* w_row[B_IT];
   // issue side of one output tile: K walk back to the start of the split's range, row pointers of the tile
+  int m0_iss = 0;                 // first row of the tile the issue side works on (persistent: rows are recomputed from it)
   auto setup_issue = [&](int m0, int n0) {
+  m0_iss = m0;
   if (CM) { const int t = k_beg / BK; ch0 = (t / 9) * BK; tap0 = t - (t / 9) * 9; }
   else { tap0 = conv ? k_beg / cin : 0; ch0 = k_beg - tap0 * cin; }
   kt_issue = 0;
@@ -925,6 +929,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
     for (int i = 0; i < A_IT; ++i) {
       bool ok = true;
       long row = a_row[i];
+      if constexpr (PERSIST) {      // plain contraction: the row index is cheaper to recompute than to keep (2 registers each)
+        int m = m0_iss + (i * NW + wid) * 8 + lrow;
+        row = m >= d.M ? d.M - 1 : m;
+      }
       if (conv) {
         int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
         if (d.ups) {
@@ -1093,8 +1101,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
         wait_frags<(D - 2) * T_DMA + T1>(af1, bf1);
         if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
         if constexpr (!(ABL & 2)) {
-          lds_read_frags<0, FSTR>(af0, a_b0 + so_nxt, seqA{});     // frags(kt+1, half 0) — of the next output tile
-          lds_read_frags<0, FSTR>(bf0, b_b0 + so_nxt, seqB{});     // after the last K tile
+          // frags(kt+1, half 0).  A persistent workgroup requests the NEXT output tile's first fragments only behind
+          // the epilogue (below): held across it they cost 36 registers on top of the accumulators, the epilogue's own
+          // and the issue side's state — the 256-row tiles spilled 54-131 registers for them
+          if (!PERSIST || kt + 1 < nk) {
+            lds_read_frags<0, FSTR>(af0, a_b0 + so_nxt, seqA{});
+            lds_read_frags<0, FSTR>(bf0, b_b0 + so_nxt, seqB{});
+          }
         }
         dma_and_mma(T1, T2, so_iss, live, af1, bf1);               // rest of K tile kt+D beside k-half 1
         advance();
@@ -1127,6 +1140,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // first fragments of the next output tile (its first K tile landed before the last barrier of the K loop)
+        if constexpr (!(ABL & 2)) {
+          lds_read_frags<0, FSTR>(af0, a_b0 + so_cur, seqA{});
+          lds_read_frags<0, FSTR>(bf0, b_b0 + so_cur, seqB{});
+        }
       }
       // the reads of the (non-existent) K tile behind the last one and the zero-line DMAs behind the last real tiles
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1215,19 +1233,25 @@ int launch_gemm_pipe_cm(const GemmArgs& ga, hipStream_t st) {
   // tiles b, b + grid, ... with its DMA ring running across tile boundaries.  LGD_GEMM_PERSIST=0 = one tile per
   // workgroup (A/B timing).  Split-K / batched launches already spread over blockIdx.z and keep one tile each.
   static const long resident = [] {
-    const char* e = getenv("LGD_GEMM_PERSIST");
-    int per_cu = 0, cus = 0, dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &per_cu, reinterpret_cast<const void*>(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, true>), 64 * WM * WN, SMEM);
-    return (e && e[0] == '0') ? 0L : (long)(cus / 8) * 8 * (per_cu > 0 ? per_cu : 1);
+    // no persistent form of the chunk-major (3x3 convolution) kernels, nor of the 256 x 160 tile: with 80 accumulator
+    // registers the tile-crossing state does not fit 256 VGPRs (58 spilled even after the trims above); measured gain
+    // of persistence on that tile's K <= 640 shapes was +4..9 % of ~2.5 % of the step
+    if constexpr (CM || (MI == 4 && NI == 5)) return 0L;
+    else {
+      const char* e = getenv("LGD_GEMM_PERSIST");
+      int per_cu = 0, cus = 0, dev = 0;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<MI, NI, WM, WN, NS, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(
+          &per_cu, reinterpret_cast<const void*>(&gemm_pipe_kernel<MI, NI, WM, WN, NS, false, true>), 64 * WM * WN, SMEM);
+      return (e && e[0] == '0') ? 0L : (long)(cus / 8) * 8 * (per_cu > 0 ? per_cu : 1);
+    }
   }();
   // measured (tools/gemm_ab.py, LGD_GEMM_PERSIST=0 vs 1): +4..9 % where K <= 640 (5-10 K tiles per output tile: the
   // pipeline fill is a visible share of a tile), neutral to -8 % from K = 1280 up — enabled for short K walks only
-  const bool persist = resident > 0 && d.nb_o * d.nb_i * d.splits == 1 && tiles > resident && d.K <= 10 * BK;
+  const bool persist = resident > 0 && d.nb_o * d.nb_i * d.splits == 1 && tiles > resident && d.K <= 10 * BK && d.taps == 1;
   dim3 grid((unsigned)(persist ? resident : tiles), 1, (unsigned)(d.nb_o * d.nb_i * d.splits));
 #ifdef LGD_GEMM_ABLATION
   static const int abl = [] { const char* e = getenv("LGD_GEMM_ABL"); return e ? atoi(e) : 0; }();
@@ -1249,8 +1273,13 @@ int launch_gemm_pipe_cm(const GemmArgs& ga, hipStream_t st) {
     return lgd_check_launch();
   }
 #endif
-  if (persist) hipLaunchKernelGGL((gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, true>), grid, dim3(64 * WM * WN), SMEM, st, ga);
-  else hipLaunchKernelGGL((gemm_pipe_kernel<MI, NI, WM, WN, NS, CM>), grid, dim3(64 * WM * WN), SMEM, st, ga);
+  if constexpr (!CM && !(MI == 4 && NI == 5)) {     // see `resident`: no such instantiations
+    if (persist) {
+      hipLaunchKernelGGL((gemm_pipe_kernel<MI, NI, WM, WN, NS, false, true>), grid, dim3(64 * WM * WN), SMEM, st, ga);
+      return lgd_check_launch();
+    }
+  }
+  hipLaunchKernelGGL((gemm_pipe_kernel<MI, NI, WM, WN, NS, CM>), grid, dim3(64 * WM * WN), SMEM, st, ga);
   return lgd_check_launch();
 }
 

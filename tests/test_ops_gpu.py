@@ -9,6 +9,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 import lgd_amd  # noqa: E402
+from conftest import gate  # noqa: E402
 from lgd_amd import ops  # noqa: E402
 
 H16, F32 = torch.float16, torch.float32
@@ -457,3 +458,49 @@ def test_cfg_ddim_step(dev):
     out = torch.empty(4, device=dev)
     ops.select_row(table, torch.tensor([3], device=dev, dtype=torch.int32), out)
     assert torch.equal(out, table[3])
+
+
+@pytest.mark.parametrize("pipe", [1, 0])
+@pytest.mark.parametrize("B,H,Sq,Sk,kw", [
+    (2, 8, 4096, 4096, {}), (2, 8, 4096, 4126, {}), (1, 2, 300, 77, {}), (1, 3, 257, 64, {}), (2, 2, 64, 1, {}),
+    (1, 2, 1000, 129, {}), (2, 8, 4096, 4096, dict(spike=True)), (2, 4, 2048, 2111, dict(spike=True)),
+    (2, 8, 4096, 4096, dict(scale_q=6.0)), (1, 1, 31, 200, {}), (1, 2, 256, 192, {}), (1, 2, 512, 320, {}),
+])
+def test_attn_w4_kernel_every_size(dev, pipe, B, H, Sq, Sk, kw):
+    """The round-4 d = 40 self-attention forward (csrc/attn_w4.hip: attention_processor.py:338-363 semantics), forced for
+    every problem size (lgd_set_option("attn_w4", 2)), in both variants (one wave per SIMD with the in-wave software
+    pipeline / two waves per SIMD): ragged query and key counts (padded keys dropped through the DMA'd constant lines),
+    1 .. 65 key tiles (prologue-only, one pipelined tile, steady-state loop, generic tail), spiked keys and large
+    logits (the lazily raised reference must rescale), output and log-sum-exp vs fp32 torch on EVERY (image, head), no
+    NaN anywhere, bit-for-bit determinism."""
+    d = 40
+    C = H * d
+    g = torch.Generator().manual_seed(7)
+    q = (torch.randn(B, Sq, C, generator=g) * kw.get("scale_q", 1.0)).to(dev).half()
+    k = torch.randn(B, Sk, C, generator=g).to(dev).half()
+    v = torch.randn(B, Sk, C, generator=g).to(dev).half()
+    if kw.get("spike"):
+        for j in (Sk // 2 + 3, Sk - 5):
+            k[:, j] = q[:, (j * 7) % Sq] * 6.0
+    ops.set_option("attn_w4", 2)
+    ops.set_option("attn_w4_pipe", pipe)
+    try:
+        outs = []
+        for _ in range(2):
+            o = torch.full((B, Sq, C), float("nan"), device=dev, dtype=H16)
+            lse = torch.full((B, H, Sq), float("nan"), device=dev)
+            ops.attn_fwd(q, k, v, o, B, H, Sq, Sk, d, d ** -0.5, lse=lse)
+            torch.cuda.synchronize()
+            outs.append((o, lse))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        o, lse = outs[0]
+        assert bool(torch.isfinite(o.float()).all()) and bool(torch.isfinite(lse).all())
+        sp = lambda t, S: t.float().reshape(B, S, H, d).permute(0, 2, 1, 3)
+        logits = torch.einsum("bhqd,bhkd->bhqk", sp(q, Sq), sp(k, Sk)) * d ** -0.5
+        ref = torch.einsum("bhqk,bhkd->bhqd", logits.softmax(-1), sp(v, Sk)).permute(0, 2, 1, 3).reshape(B, Sq, C)
+        gate(f"[attn_w4 pipe={pipe} B{B} H{H} {Sq}x{Sk} {kw}] output", relerr(o, ref), 4e-3)
+        gate(f"[attn_w4 pipe={pipe} B{B} H{H} {Sq}x{Sk} {kw}] log-sum-exp (log2 domain, abs)",
+             float((lse - torch.logsumexp(logits, -1) * 1.4426950408889634).abs().max()), 2e-2)
+    finally:
+        ops.set_option("attn_w4", 1)
+        ops.set_option("attn_w4_pipe", 1)
