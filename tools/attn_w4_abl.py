@@ -10,7 +10,7 @@ B, H, S, Sk = 16, 8, 4096, 4096
 g = torch.Generator().manual_seed(0)
 q = torch.randn(B, S, H * d, generator=g).to(dev).half(); k = torch.randn(B, Sk, H * d, generator=g).to(dev).half()
 v = torch.randn(B, Sk, H * d, generator=g).to(dev).half(); o = torch.empty_like(q)
-ops.set_option("attn_w4", 2)
+ops.set_option("attn_w4", int(os.environ.get("W4MODE", "2")))
 ts = []
 for _ in range(5):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

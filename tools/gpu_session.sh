@@ -17,5 +17,19 @@ case $STAGE in
   bench)      # args = bench.py flags; writes bench.json
     timeout 900 python bench.py "$@" > $OUT/bench.log 2>&1; echo "bench rc=$?"
     grep '^{' $OUT/bench.log | tail -1 > $OUT/bench.json; cut -c1-400 $OUT/bench.json ;;
+  tune)       # args: TOP [streams]; re-tunes the TOP most expensive GEMM shapes (latency table, or the lanes table with streams > 1)
+    TOP=${1:-100}; STREAMS=${2:-1}
+    if [ "$STREAMS" -gt 1 ]; then
+      python - <<'PY'
+import json
+a = json.load(open("llm-groundeddiffusion_amd/tuning_gfx950.json")); a.update(json.load(open("llm-groundeddiffusion_amd/tuning_gfx950_lanes.json")))
+json.dump(a, open("gpurun_out/tune/lanes_full.json", "w"), indent=0, sort_keys=True)
+PY
+      LGD_TUNE_STREAMS=$STREAMS LGD_TUNE_TOP=$TOP timeout ${TUNE_TIMEOUT:-480} python tools/tune_gemm.py sd14_gligen $OUT/lanes_full.json > $OUT/tune.log 2>&1
+    else
+      cp llm-groundeddiffusion_amd/tuning_gfx950.json $OUT/latency.json
+      LGD_TUNE_TOP=$TOP timeout ${TUNE_TIMEOUT:-480} python tools/tune_gemm.py sd14_gligen $OUT/latency.json > $OUT/tune.log 2>&1
+    fi
+    echo "tune rc=$?"; tail -n 4 $OUT/tune.log ;;
   *) echo "unknown stage $STAGE"; exit 2 ;;
 esac

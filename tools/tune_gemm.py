@@ -56,8 +56,10 @@ ops.gemm_launch = orig
 print(f"{len(shapes)} distinct GEMM shapes")
 
 TILE_DIMS = {17: (128, 128), 18: (128, 64), 19: (64, 128), 20: (64, 64), 21: (32, 128), 22: (128, 160), 23: (64, 160),
-             33: (256, 160), 34: (256, 128), 35: (256, 64), 37: (128, 160), 38: (128, 128)}
-NO_GEGLU = {22, 23, 33, 37}                      # odd fragment counts cannot pair value | gate column blocks
+             33: (256, 160), 34: (256, 128), 35: (256, 64), 37: (128, 160), 38: (128, 128),
+             # round 4: the deeper-ringed small 8-wave tiles (5-6 LDS stages) were in the library but never candidates
+             39: (128, 64), 40: (64, 160), 41: (64, 128), 42: (64, 64)}
+NO_GEGLU = {22, 23, 33, 37, 40}                  # odd fragment counts cannot pair value | gate column blocks
 VERIFY_TOL = 2e-3                                # fp16 outputs, different summation orders
 rejected = []
 
@@ -201,6 +203,11 @@ for key, sh in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"
                     best = (t_old, o["tile"], o["splits"])
                     table[key].update(tile=o["tile"], splits=o["splits"], us=round(t_old, 2), tflops=round(fl / t_old / 1e6, 1))
     tot_old += ref_us * sh["count"]; tot_new += best[0] * sh["count"]
+    n_done = globals().get("n_done", 0) + 1
+    globals()["n_done"] = n_done
+    if n_done % 8 == 0:                                        # a killed run keeps what it measured
+        merged = dict(old_entries, **table) if os.environ.get("LGD_TUNE_TOP") else table
+        json.dump(merged, open(out_path, "w"), indent=0, sort_keys=True)
     print(f"{key:60s} n={sh['count']:3d} base {ref_us:7.1f}us -> tile {best[1]} split {best[2]:2d} {best[0]:7.1f}us "
           f"{fl / best[0] / 1e6:6.1f} TF/s", flush=True)
 print(f"sum over passes: {tot_old/1e3:.2f} ms -> {tot_new/1e3:.2f} ms")
