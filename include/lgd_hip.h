@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LGD_ABI_VERSION 7
+#define LGD_ABI_VERSION 8
 int lgd_abi_version(void);
 /* Kernel-variant switches of the library (A/B timing and tests; the defaults are what the benchmark runs).  No
  * counterpart in the reference.  "attn32": self-attention forward without map capture — 0 = the 16x16x32 kernel,
@@ -57,6 +57,12 @@ int lgd_set_option(const char* name, int value);
 #define LGD_EPI_GEGLU 1   /* weights/bias rows packed [16 value | 16 gate] blocks               */
 #define LGD_EPI_OUT_F32 2 /* C is fp32                                                           */
 #define LGD_EPI_RES_F32 4 /* res is fp32                                                         */
+#define LGD_EPI_ROWNORM 8 /* LayerNorm of the A rows folded into the GEMM (ABI v8): the contraction runs on the RAW rows
+                             x with W' = W * gamma (per input channel), and the epilogue computes, per row m and column n,
+                             rstd[m] * (acc - mean[m] * colsum[n]) before bias / GEGLU / alpha / residual, where
+                             colsum[n] = sum_k W'[n][k] and the bias holds b[n] + sum_k beta[k] W[n][k]:
+                             LN(x) W^T + b  =  rstd (x W'^T - mean colsum) + b'   (attention.py:185,206,223 followed by
+                             attention_processor.py to_q/k/v, attention.py:286-289 GEGLU).  Needs rowstat + colsum. */
 
 typedef struct LgdGemmDesc {
   const void* a0;
@@ -89,6 +95,8 @@ typedef struct LgdGemmDesc {
                          output tile sums the `splits` partials in split order 0,1,2.. (bit-identical to the separate
                          reduce kernel), applies the epilogue and leaves the counter at zero again.  NULL = second
                          launch (splitk_reduce_kernel).  One counter buffer may serve every GEMM of a stream. */
+  const float* rowstat; /* LGD_EPI_ROWNORM: fp32 [M][2] = (mean, rstd) of every A row (lgd_layernorm_f16 with y = NULL) */
+  const float* colsum;  /* LGD_EPI_ROWNORM: fp32 [N] = row sums of the (gamma-scaled) weight matrix as stored          */
 } LgdGemmDesc;
 
 int lgd_gemm_f16(const LgdGemmDesc* desc /* host */, void* stream);

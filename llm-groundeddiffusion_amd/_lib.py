@@ -14,7 +14,7 @@ import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgd_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -39,10 +39,11 @@ class LgdGemmDesc(C.Structure):
         ("splits", C.c_int32), ("ws", c_void_p),
         ("tile", C.c_int32),
         ("cnt", c_void_p),
+        ("rowstat", c_void_p), ("colsum", c_void_p),
     ]
 
 
-EPI_GEGLU, EPI_OUT_F32, EPI_RES_F32 = 1, 2, 4
+EPI_GEGLU, EPI_OUT_F32, EPI_RES_F32, EPI_ROWNORM = 1, 2, 4, 8
 
 # name -> argtypes (every function returns int; last argument is the hipStream_t)
 _P, _I, _L, _F = c_void_p, c_int, c_i64, c_float

@@ -42,6 +42,18 @@ __device__ __forceinline__ float4 ld_bias4(const float* p, int n) {
   return *reinterpret_cast<const float4*>(p + n);
 }
 
+// LGD_EPI_ROWNORM: the LayerNorm of the A rows, folded behind the contraction (see include/lgd_hip.h): accumulator
+// columns n_in..n_in+3 of row m become rstd (acc - mean colsum).
+__device__ __forceinline__ f32x4 rownorm4(const LgdGemmDesc& d, int m, int n_in, f32x4 v) {
+  if (d.epi & LGD_EPI_ROWNORM) {
+    const float2 st = *reinterpret_cast<const float2*>(d.rowstat + (long)m * 2);
+    const float4 cs = *reinterpret_cast<const float4*>(d.colsum + n_in);
+    v[0] = st.y * (v[0] - st.x * cs.x); v[1] = st.y * (v[1] - st.x * cs.y);
+    v[2] = st.y * (v[2] - st.x * cs.z); v[3] = st.y * (v[3] - st.x * cs.w);
+  }
+  return v;
+}
+
 // The epilogue arithmetic on 4 consecutive output channels (n..n+3) of row m: bias, GEGLU, alpha, residual.
 // For GEGLU `v` holds the value accumulators and `g` the gate accumulators of the same columns.
 template <bool GEGLU>
@@ -183,7 +195,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& ga, f32x4 (&acc)[N
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           const int m = m0 + wm * 16 * MI + mi * 16 + m_l;
-          if (m < d.M) epilogue_store4<true>(d, c_off, r_off, m, n_out, acc[ni][mi], acc[ni + 1][mi], bv, bg);
+          if (m < d.M)
+            epilogue_store4<true>(d, c_off, r_off, m, n_out, rownorm4(d, m, n_in, acc[ni][mi]),
+                                  rownorm4(d, m, n_in + 16, acc[ni + 1][mi]), bv, bg);
         }
       }
     }
@@ -222,7 +236,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& ga, f32x4 (&acc)[N
       for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + wm * 16 * MI + mi * 16 + m_l;
         if (m < d.M)
-          epilogue_store4<false>(d, c_off, r_off, m, n, acc[ni][mi], acc[ni][mi], bv, bv, res16,
+          epilogue_store4<false>(d, c_off, r_off, m, n, rownorm4(d, m, n, acc[ni][mi]), acc[ni][mi], bv, bv, res16,
                                  res16 ? rpre[nj][mi] : (half4_t){0, 0, 0, 0});
       }
     }
@@ -266,17 +280,41 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& ga, f32x4 (&ac
   half_t* cbase = reinterpret_cast<half_t*>(d.c) + c_off;
   // biases of this wave's columns: all loads in flight at once
   float4 bv[NI_OUT], bg[NI_OUT];
+  // folded LayerNorm (LGD_EPI_ROWNORM): column sums with the biases, row statistics of all MI row tiles — one batch
+  // of loads, one memory round trip, before the first accumulator is touched
+  const bool rn = d.epi & LGD_EPI_ROWNORM;
+  float4 cv[NI_OUT], cg[NI_OUT];
+  float2 st[MI];
 #pragma unroll
   for (int no = 0; no < NI_OUT; ++no) {
     const int n_out = n0_out + wn * 16 * NI_OUT + no * 16 + n_l;
     const int n_in = GEGLU ? n0 + wn * 16 * NI + no * 32 + n_l : n_out;
     bv[no] = make_float4(0.f, 0.f, 0.f, 0.f);
     bg[no] = bv[no];
+    cv[no] = bv[no];
+    cg[no] = bv[no];
     if (n_out < n_total_out) {
       bv[no] = ld_bias_sum4(d, n_in);
       if (GEGLU && d.bias) bg[no] = ld_bias4(d.bias, n_in + 16);
+      if (rn) {
+        cv[no] = *reinterpret_cast<const float4*>(d.colsum + n_in);
+        if (GEGLU) cg[no] = *reinterpret_cast<const float4*>(d.colsum + n_in + 16);
+      }
     }
   }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    int m = m0 + wm * 16 * MI + mi * 16 + m_l;
+    if (m >= d.M) m = d.M - 1;
+    st[mi] = rn ? *reinterpret_cast<const float2*>(d.rowstat + (long)m * 2) : make_float2(0.f, 1.f);
+  }
+  auto rownorm = [&](f32x4 v, const float2 s2, const float4 c) {
+    if (rn) {
+      v[0] = s2.y * (v[0] - s2.x * c.x); v[1] = s2.y * (v[1] - s2.x * c.y);
+      v[2] = s2.y * (v[2] - s2.x * c.z); v[3] = s2.y * (v[3] - s2.x * c.w);
+    }
+    return v;
+  };
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     // residual fetches of the round first (one memory round trip for MI_R x NI_OUT pieces)
@@ -305,8 +343,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& ga, f32x4 (&ac
         int m = m0 + wm * 16 * MI + mi * 16 + m_l;
         if (m >= d.M) m = d.M - 1;
         f32x4 v;
-        if constexpr (GEGLU) v = epilogue_value4<true>(d, r_off, m, nn, acc[2 * no][mi], acc[2 * no + 1][mi], bv[no], bg[no], false, (half4_t){0, 0, 0, 0});
-        else v = epilogue_value4<false>(d, r_off, m, nn, acc[no][mi], acc[no][mi], bv[no], bv[no], res16, res16 ? rpre[no][mj] : (half4_t){0, 0, 0, 0});
+        if constexpr (GEGLU) {
+          v = epilogue_value4<true>(d, r_off, m, nn, rownorm(acc[2 * no][mi], st[mi], cv[no]), rownorm(acc[2 * no + 1][mi], st[mi], cg[no]),
+                                    bv[no], bg[no], false, (half4_t){0, 0, 0, 0});
+        } else {
+          v = epilogue_value4<false>(d, r_off, m, nn, rownorm(acc[no][mi], st[mi], cv[no]), acc[no][mi], bv[no], bv[no], res16,
+                                     res16 ? rpre[no][mj] : (half4_t){0, 0, 0, 0});
+        }
         half4_t o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
@@ -1189,10 +1232,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs ga) {
       }
     }
     const float4 bv = ld_bias_sum4(d, n_in);
+    v = rownorm4(d, m, n_in, v);
     if (geglu) {
       float4 bg = make_float4(0.f, 0.f, 0.f, 0.f);
       if (d.bias) bg = ld_bias4(d.bias, n_in + 16);
-      epilogue_store4<true>(d, c_off, r_off, m, gcol, v, g, bv, bg);
+      epilogue_store4<true>(d, c_off, r_off, m, gcol, v, rownorm4(d, m, n_in + 16, g), bv, bg);
     } else {
       epilogue_store4<false>(d, c_off, r_off, m, gcol, v, g, bv, bv);
     }
@@ -1319,6 +1363,9 @@ extern "C" int lgd_gemm_f16(const LgdGemmDesc* desc, void* stream) {
   const bool geglu = d.epi & LGD_EPI_GEGLU;
   if (geglu && (d.N % 32)) return LGD_ERR_ARG;
   if (d.splits > 1 && !d.ws) return LGD_ERR_ARG;
+  // folded LayerNorm: statistics are indexed by the row of ONE matrix, the columns by the stored weight row
+  if ((d.epi & LGD_EPI_ROWNORM) && (!d.rowstat || !d.colsum || d.taps != 1 || d.nb_o * d.nb_i != 1 || d.c1 > 0))
+    return LGD_ERR_ARG;
   // K range of each split, multiple of BK
   int ktiles = (d.K + BK - 1) / BK;
   int tps = (ktiles + d.splits - 1) / d.splits;

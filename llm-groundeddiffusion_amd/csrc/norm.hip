@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
 #pragma unroll
   for (int j = 0; j < MAXV; ++j) {
     const int v = lane + j * 64;
-    if (v < nvec) {
+    if (v < nvec && y) {                       // y == nullptr: statistics only
       const float4 g0 = *reinterpret_cast<const float4*>(gamma + v * 8);
       const float4 g1 = *reinterpret_cast<const float4*>(gamma + v * 8 + 4);
       const float4 b0 = *reinterpret_cast<const float4*>(beta + v * 8);
@@ -542,6 +542,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
       stats[(long)row * 2] = mean;
       stats[(long)row * 2 + 1] = rstd;
     }
+    if (!y) continue;                          // statistics only (uniform)
     const int bb = row / rpb, rr = row - bb * rpb;
     half_t* yr = y + bb * y_bs + (long)rr * ldy;
 #pragma unroll
@@ -663,6 +664,7 @@ extern "C" int lgd_layernorm_f16(const void* x, int64_t ldx, void* y, int64_t ld
                                  int rows_per_batch, int64_t x_bs, int64_t y_bs, void* stream) {
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if ((C % 8) || C > 64 * 8 * LN_MAXV || rows < 1) return LGD_ERR_ARG;
+  if (!y && (!stats || C > 192 * 8)) return LGD_ERR_ARG;      // statistics-only form: the row kernels, stats required
   if (rows_per_batch < 1) rows_per_batch = rows;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const half_t* xp = (const half_t*)x;

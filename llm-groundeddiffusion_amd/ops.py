@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import EPI_GEGLU, EPI_OUT_F32, EPI_RES_F32, LgdGemmDesc
+from ._lib import EPI_GEGLU, EPI_OUT_F32, EPI_RES_F32, EPI_ROWNORM, LgdGemmDesc
 
 F16, F32 = torch.float16, torch.float32
 
@@ -86,7 +86,7 @@ def choose_splits(M, N, K, batches=1):
 def gemm_desc(a0, w, c, M, N, K, *, a1=None, lda0=None, lda1=0, c0=None, c1=0, taps=1,
               hin=0, win=0, hout=0, wout=0, stride=1, ups=0, ldw=None, bias=None, bias2=None,
               res=None, ldr=0, alpha=1.0, epi=0, ldc=None, splits=None, ws=None, tile=0,
-              nb_o=1, nb_i=1, a_bs=(0, 0), w_bs=(0, 0), c_bs=(0, 0), r_bs=(0, 0)):
+              nb_o=1, nb_i=1, a_bs=(0, 0), w_bs=(0, 0), c_bs=(0, 0), r_bs=(0, 0), rowstat=None, colsum=None):
     """Builds an LgdGemmDesc from raw pointers (ints) or tensors.  splits=None / tile=0: taken from
     the measured tuning table (tuning_gfx950.json) when the shape is listed, else from heuristics."""
     d = LgdGemmDesc()
@@ -108,6 +108,9 @@ def gemm_desc(a0, w, c, M, N, K, *, a1=None, lda0=None, lda1=0, c0=None, c1=0, t
     d.r_bs_o, d.r_bs_i = r_bs
     d.bias, d.bias2 = ptr(bias), ptr(bias2)
     d.res, d.ldr = ptr(res), ldr
+    if rowstat is not None:                              # rows arrive raw, w / bias / colsum are the folded set (weightstore)
+        epi |= EPI_ROWNORM
+    d.rowstat, d.colsum = ptr(rowstat), ptr(colsum)
     d.alpha, d.epi = alpha, epi
     d.c = ptr(c)
     n_out = N // 2 if (epi & EPI_GEGLU) else N
@@ -301,7 +304,7 @@ def gemm_launch(desc, tag=None, flops=None):
 
 
 def linear(x, w, bias=None, res=None, out=None, *, alpha=1.0, geglu=False, out_f32=False,
-           splits=None, ws=None, tile=0, bias2=None):
+           splits=None, ws=None, tile=0, bias2=None, rowstat=None, colsum=None):
     """y = x @ w.T (+bias) ... ; x [M,K] fp16 contiguous, w [N,K] fp16."""
     M, K = x.shape
     N = w.shape[0]
@@ -314,7 +317,7 @@ def linear(x, w, bias=None, res=None, out=None, *, alpha=1.0, geglu=False, out_f
     d = gemm_desc(x, w, out, M, N, K, bias=bias, bias2=bias2, res=res,
                   ldr=(res.stride(0) if res is not None else 0), alpha=alpha, epi=epi,
                   splits=splits, ws=ws, tile=tile, lda0=x.stride(0), ldw=w.stride(0),
-                  ldc=out.stride(0))
+                  ldc=out.stride(0), rowstat=rowstat, colsum=colsum)
     gemm_launch(d)
     return out
 
@@ -423,6 +426,18 @@ def layernorm(x, gamma, beta, eps=1e-5, *, out=None, ldy=None, stats=None, rows_
     _call("lgd_layernorm_f16", _p(x), ldx or C_, _p(out), ldy or C_, rows, C_, float(eps), _p(gamma),
           _p(beta), _p(stats), rows_per_batch, x_bs, y_bs, _stream())
     return out
+
+
+def layernorm_stats(x, C_, eps=1e-5, *, stats=None, rows=None, ldx=None):
+    """(mean, rstd) of every row, fp32 [rows][2]: the statistics half of LayerNorm, whose other half rides in the
+    consuming GEMM's epilogue (EPI_ROWNORM)."""
+    if rows is None:
+        rows = x.numel() // C_
+    if stats is None:
+        stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+    _call("lgd_layernorm_f16", _p(x), ldx or C_, _p(None), C_, rows, C_, float(eps), _p(None), _p(None), _p(stats),
+          0, 0, 0, _stream())
+    return stats
 
 
 def layernorm_bwd(gy, x, gamma, stats, *, gx=None, rows=None, ldgy=None, ldx=None, ldgx=None,

@@ -20,6 +20,7 @@ attention_processor.py of the reference (and torch.autograd for pipelines.py:56)
     key (pipelines.py:46 TODO).
 """
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -287,6 +288,30 @@ class Plan:
         self._add(fwd, make_bwd, [x])
         return y
 
+    def ln_linear(self, x: Act, norm: str, name: str, *, geglu=False) -> Act:
+        """linear(LayerNorm(x)) (attention.py:185,206,223 + the projection behind each).  No-grad plans of an engine with
+        `fold_ln` read the rows RAW: one statistics pass (mean, rstd per row; no normalised copy is written or re-read)
+        and the normalisation rides in the GEMM's epilogue on the gamma-folded weights (weightstore._lnlin,
+        LGD_EPI_ROWNORM).  Grad plans keep the two ops: the backward needs the LayerNorm's own node."""
+        eng = self.eng
+        has_b = f"{name}.b" in eng.w.f
+        if self.grad or not eng.fold_ln:
+            y = self.layernorm(x, norm)
+            if geglu:
+                return self.linear(y, name, geglu=True)
+            return self.linear(y, name, bias=has_b)
+        W, cs, b = eng.w.h[f"{name}.wln"], eng.w.f[f"{name}.cs"], eng.w.f[f"{name}.bln"]
+        N, K = W.shape
+        M = x.rows
+        stats = self._alloc((M, 2))
+        y = self._act(M, N // 2 if geglu else N)
+        d = ops.gemm_desc(x.t, W, y.t, M, N, K, lda0=x.C, bias=b, epi=EPI_GEGLU if geglu else 0, ldc=y.C,
+                          rowstat=stats, colsum=cs)
+        tag = "attn_path" if any(t in name for t in (".attn1.", ".attn2.", ".fuser.attn.")) else None
+        xt = x.t
+        self._add(lambda: (ops.layernorm_stats(xt, K, stats=stats, rows=M), ops.gemm_launch(d, tag)))
+        return y
+
     # ---- attention -------------------------------------------------------------------------
     def self_attn(self, qkv: Act, heads: int, S: int, Sk: Optional[int] = None) -> Act:
         """Flash attention over a fused [B*(Sk), 3C] projection; queries are the first S rows of each
@@ -361,11 +386,14 @@ class Plan:
         self._add(fwd, make_bwd, [q])
         return o
 
-    def ff(self, x: Act, res: Act, name: str, alpha=1.0) -> Act:
-        """FeedForward(GEGLU) + residual (attention.py:228-233): fused epilogue in no-grad plans."""
+    def ff(self, x: Act, res: Act, name: str, alpha=1.0, norm: Optional[str] = None) -> Act:
+        """FeedForward(GEGLU) + residual (attention.py:228-233): fused epilogue in no-grad plans.  norm: the LayerNorm
+        in front of it (x is then its INPUT)."""
         if not self.grad:
-            h = self.linear(x, f"{name}.net.0.proj", geglu=True)
+            h = self.ln_linear(x, norm, f"{name}.net.0.proj", geglu=True) if norm else self.linear(x, f"{name}.net.0.proj", geglu=True)
             return self.linear(h, f"{name}.net.2", res=res, alpha=alpha)
+        if norm:
+            x = self.layernorm(x, norm)
         pre = self.linear(x, f"{name}.net.0.proj")                 # packed [M, 8C] pre-activation
         act = self._act(x.rows, pre.C // 2)
         self._add(lambda: ops.geglu_fwd(pre.t, out=act.t),
@@ -399,7 +427,7 @@ class Plan:
             t = f"{a.prefix}.transformer_blocks.{dpt}"
             key = tuple(a.key[:3]) + (dpt,)
             # 1. self-attention (attention.py:185-195)
-            qkv = self.linear(self.layernorm(h, f"{t}.norm1"), f"{t}.attn1.qkv", bias=False)
+            qkv = self.ln_linear(h, f"{t}.norm1", f"{t}.attn1.qkv")
             h = self.linear(self.self_attn(qkv, heads, S), f"{t}.attn1.to_out.0", res=h)
             if dpt == 0:
                 self.dbg[f"{a.prefix}.after_attn1"] = h
@@ -415,10 +443,10 @@ class Plan:
                 o = self.self_attn(qkv_f, heads, S, Sk)
                 h = self.linear(o, f"{f}.attn.to_out.0", res=h, alpha=eng.w.scalars[f"{f}.alpha_attn"])
                 self.dbg[f"{a.prefix}.after_fuser_attn"] = h
-                h = self.ff(self.layernorm(h, f"{f}.norm2"), h, f"{f}.ff", alpha=eng.w.scalars[f"{f}.alpha_dense"])
+                h = self.ff(h, h, f"{f}.ff", alpha=eng.w.scalars[f"{f}.alpha_dense"], norm=f"{f}.norm2")
                 self.dbg[f"{a.prefix}.after_fuser"] = h
             # 2. cross-attention (attention.py:204-220) — the hook of attention_processor.py:377-483
-            q = self.linear(self.layernorm(h, f"{t}.norm2"), f"{t}.attn2.to_q", bias=False)
+            q = self.ln_linear(h, f"{t}.norm2", f"{t}.attn2.to_q")
             last = self.stop_key is not None and key == self.stop_key
             o = self.cross_attn(q, key, eng.kv_name(a.prefix, dpt), heads, S, last)
             if last:
@@ -427,7 +455,7 @@ class Plan:
             if dpt == 0:
                 self.dbg[f"{a.prefix}.after_attn2"] = h
             # 3. feed-forward (attention.py:223-233)
-            h = self.ff(self.layernorm(h, f"{t}.norm3"), h, f"{t}.ff")
+            h = self.ff(h, h, f"{t}.ff", norm=f"{t}.norm3")
         out = self.linear(h, f"{a.prefix}.proj_out", res=x)                      # transformer_2d.py:319-327
         self.dbg[f"{a.prefix}.out"] = out
         return out
@@ -549,6 +577,8 @@ class UNetEngine:
         # GEMM tuning table of this engine's plans ("latency" | "throughput" | None = ops.current_tuning_mode() at
         # plan-build time); lanes.make_lanes sets "throughput" on the engines it hands to lanes.  Part of the plan key.
         self.tuning_mode: Optional[str] = None
+        # LayerNorm folded into the consuming GEMM in no-grad plans (Plan.ln_linear); LGD_FOLD_LN=0 keeps the two ops
+        self.fold_ln = os.environ.get("LGD_FOLD_LN", "1") != "0"
         self.blocks = unet_blocks(cfg)
         if weights is not None:
             if weights.cfg != cfg or torch.device(weights.device) != self.device or state_dict is not None:
@@ -735,7 +765,7 @@ class UNetEngine:
              text_batch_offset=0, obj_batch_offset=0) -> Plan:
         mode = self.tuning_mode or ops.current_tuning_mode()
         key = (B, L, grad, fuser, tuple(stop_key) if stop_key else None, tuple(map(tuple, save_keys)),
-               text_batch_offset, obj_batch_offset, mode)
+               text_batch_offset, obj_batch_offset, mode, self.fold_ln)
         if B + text_batch_offset > self.max_text_batch:
             raise RuntimeError(f"plan batch {B} (+{text_batch_offset}) exceeds max_text_batch={self.max_text_batch}")
         if key not in self._plans:

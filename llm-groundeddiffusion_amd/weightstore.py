@@ -101,6 +101,13 @@ class WeightStore:
         if bias:
             self._e32(f"{name}.b", (n,))
 
+    def _lnlin(self, name, n, k):
+        """The LayerNorm-folded twin of a linear layer whose input is a LayerNorm (no-grad plans; LGD_EPI_ROWNORM in
+        include/lgd_hip.h): wln = W * gamma per input channel, cs = row sums of wln AS STORED (fp16), bln = b + W beta."""
+        self._e16(f"{name}.wln", (n, k))
+        self._e32(f"{name}.cs", (n,))
+        self._e32(f"{name}.bln", (n,))
+
     def _conv(self, name, cout, cin, bwd=False):
         self._e16(f"{name}.w", (cout, 9 * cin))
         if bwd:
@@ -144,13 +151,16 @@ class WeightStore:
                     t = f"{a.prefix}.transformer_blocks.{d}"
                     self._normp(f"{t}.norm1", C)
                     self._lin(f"{t}.attn1.qkv", 3 * C, C, bias=False, bwd=bw)
+                    self._lnlin(f"{t}.attn1.qkv", 3 * C, C)
                     self._lin(f"{t}.attn1.to_out.0", C, C, bwd=bw)
                     self._normp(f"{t}.norm2", C)
                     self._lin(f"{t}.attn2.to_q", C, C, bias=False, bwd=bw)
+                    self._lnlin(f"{t}.attn2.to_q", C, C)
                     self._lin(f"{t}.attn2.kv", 2 * C, cx, bias=False)
                     self._lin(f"{t}.attn2.to_out.0", C, C, bwd=bw)
                     self._normp(f"{t}.norm3", C)
                     self._lin(f"{t}.ff.net.0.proj", 8 * C, C, bwd=bw)
+                    self._lnlin(f"{t}.ff.net.0.proj", 8 * C, C)
                     self._lin(f"{t}.ff.net.2", C, 4 * C, bwd=bw)
                     if cfg.use_gated_attention:
                         f = f"{t}.fuser"
@@ -160,6 +170,7 @@ class WeightStore:
                         self._lin(f"{f}.attn.to_out.0", C, C, bwd=bw)
                         self._normp(f"{f}.norm2", C)
                         self._lin(f"{f}.ff.net.0.proj", 8 * C, C, bwd=bw)
+                        self._lnlin(f"{f}.ff.net.0.proj", 8 * C, C)
                         self._lin(f"{f}.ff.net.2", C, 4 * C, bwd=bw)
                 self._lin(f"{a.prefix}.proj_out", C, C, bwd=bw)
             if b.sampler:
@@ -210,6 +221,16 @@ class WeightStore:
             perm = geglu_perm(w.shape[0] // 2)
             lin(dst, None, bwd=bwd, w=w[perm].contiguous(), b=b[perm].contiguous())
 
+        def fold(dst, norm):
+            # after lin()/geglu(): the rows are already in kernel order, the fold runs along K
+            w = h16[f"{dst}.w"].to(F16).float()                      # the values the unfolded GEMM multiplies by
+            g, bt = sd[f"{norm}.weight"].float(), sd[f"{norm}.bias"].float()
+            wln = (w * g[None, :]).to(F16)
+            h16[f"{dst}.wln"] = wln
+            f32[f"{dst}.cs"] = wln.float().sum(dim=1)
+            b0 = f32.get(f"{dst}.b")
+            f32[f"{dst}.bln"] = w @ bt + (b0.float() if b0 is not None else 0.0)
+
         h16["conv_in.w"] = pack_conv(sd["conv_in.weight"])
         h16["conv_in.wd"] = pack_conv_dgrad(sd["conv_in.weight"])
         wi = sd["conv_in.weight"]
@@ -246,14 +267,17 @@ class WeightStore:
                     qkv = torch.cat([sd[f"{t}.attn1.to_q.weight"], sd[f"{t}.attn1.to_k.weight"],
                                      sd[f"{t}.attn1.to_v.weight"]], dim=0)
                     lin(f"{t}.attn1.qkv", None, bias=False, bwd=bw, w=qkv)
+                    fold(f"{t}.attn1.qkv", f"{t}.norm1")
                     lin(f"{t}.attn1.to_out.0", f"{t}.attn1.to_out.0", bwd=bw)
                     normp(f"{t}.norm2")
                     lin(f"{t}.attn2.to_q", f"{t}.attn2.to_q", bias=False, bwd=bw)
+                    fold(f"{t}.attn2.to_q", f"{t}.norm2")
                     kv = torch.cat([sd[f"{t}.attn2.to_k.weight"], sd[f"{t}.attn2.to_v.weight"]], dim=0)
                     lin(f"{t}.attn2.kv", None, bias=False, w=kv)
                     lin(f"{t}.attn2.to_out.0", f"{t}.attn2.to_out.0", bwd=bw)
                     normp(f"{t}.norm3")
                     geglu(f"{t}.ff.net.0.proj", f"{t}.ff.net.0.proj", bw)
+                    fold(f"{t}.ff.net.0.proj", f"{t}.norm3")
                     lin(f"{t}.ff.net.2", f"{t}.ff.net.2", bwd=bw)
                     if cfg.use_gated_attention:
                         f = f"{t}.fuser"
@@ -265,6 +289,7 @@ class WeightStore:
                         lin(f"{f}.attn.to_out.0", f"{f}.attn.to_out.0", bwd=bw)
                         normp(f"{f}.norm2")
                         geglu(f"{f}.ff.net.0.proj", f"{f}.ff.net.0.proj", bw)
+                        fold(f"{f}.ff.net.0.proj", f"{f}.norm2")
                         lin(f"{f}.ff.net.2", f"{f}.ff.net.2", bwd=bw)
                         gates += [float(sd[f"{f}.alpha_attn"].tanh()), float(sd[f"{f}.alpha_dense"].tanh())]
                 lin(f"{a.prefix}.proj_out", f"{a.prefix}.proj_out", bwd=bw)

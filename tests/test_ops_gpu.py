@@ -85,6 +85,45 @@ def test_gemm_geglu(dev, M, dim, splits, tile):
     assert y.shape == (M, inner) and relerr(y, ref) < 3e-3
 
 
+@pytest.mark.parametrize("M,C,N,geglu,tile,splits", [
+    (8192, 320, 960, False, 0, 1), (8192, 320, 2560, True, 0, 1), (2048, 640, 640, False, 0, 1),
+    (300, 640, 5120, True, 0, 1), (128, 1280, 3840, False, 0, 2), (128, 1280, 10240, True, 0, 2),
+    (4100, 320, 960, False, 33, 1), (4100, 640, 1920, False, 34, 1), (4100, 320, 2560, True, 34, 1),   # LDS epilogue, ragged M
+    (515, 1280, 1280, False, 37, 1), (515, 320, 320, False, 2, 1), (515, 640, 640, False, 18, 1),
+    (128, 1280, 1280, False, 20, 4),                                                                    # split-K, both reducers
+])
+def test_gemm_rownorm_is_layernorm_then_linear(dev, M, C, N, geglu, tile, splits):
+    """LGD_EPI_ROWNORM (ABI v8): statistics pass + GEMM on the raw rows with gamma-folded weights == LayerNorm
+    followed by the linear layer (attention.py:185,206,223), on rows with a mean far from zero."""
+    x = (rnd(M, C, dev=dev, seed=1) * 1.5 + rnd(M, 1, dev=dev, seed=7) * 2.0).half()
+    w = rnd(N, C, dev=dev, seed=2, scale=C ** -0.5)
+    b = rnd(N, dev=dev, seed=3)
+    gm, bt = 1.0 + 0.3 * rnd(C, dev=dev, seed=4), 0.2 * rnd(C, dev=dev, seed=5)
+    h = F.layer_norm(x.float(), (C,), gm, bt, 1e-5) @ w.half().float().t() + b
+    if geglu:
+        v, g = h.chunk(2, dim=-1)
+        ref = v * F.gelu(g)
+        wk, bk = pack_geglu(w, b)
+    else:
+        ref, wk, bk = h, w, b
+    wln = (wk.half().float() * gm[None, :]).half()
+    cs = wln.float().sum(1)
+    bln = bk + wk.half().float() @ bt
+    for in_launch in (True, False):
+        stats = ops.layernorm_stats(x, C)
+        mu, var = x.float().mean(1), x.float().var(1, unbiased=False)
+        assert relerr(stats[:, 0], mu) < 1e-4 and relerr(stats[:, 1], (var + 1e-5).rsqrt()) < 1e-4
+        old = ops.SPLITK_IN_LAUNCH
+        ops.SPLITK_IN_LAUNCH = in_launch
+        try:
+            y = ops.linear(x, wln, bln, geglu=geglu, tile=tile, splits=splits, rowstat=stats, colsum=cs)
+        finally:
+            ops.SPLITK_IN_LAUNCH = old
+        assert relerr(y, ref) < 4e-3, (in_launch, relerr(y, ref))
+        if splits == 1:
+            break
+
+
 @pytest.mark.parametrize("dma", [0, 16])
 @pytest.mark.parametrize("B,H,C0,C1,Cout,stride,ups,splits", [
     (2, 16, 64, 0, 64, 1, False, 1), (2, 32, 320, 0, 320, 1, False, 1),
