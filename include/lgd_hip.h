@@ -33,7 +33,9 @@ int lgd_abi_version(void);
  * 2 = that kernel for every problem size.  "attn_w4": the d = 40 kernel of round 4 (csrc/attn_w4.hip: 4-wave
  * workgroups, LDS-DMA K / V, transposing V reads) — 0 = never, 1 = (default) once a launch has >= 256 workgroups of
  * 256 queries and >= 256 keys, 2 = for every problem size; "attn_w4_pipe": 1 = (default) one wave per SIMD with the
- * in-wave software pipeline, 0 = two waves per SIMD.  Returns 0, or LGD_ERR_ARG for an unknown name. */
+ * in-wave software pipeline, 0 = two waves per SIMD.  "gn_fused": the largest map (pixels per image) lgd_groupnorm_f16
+ * normalises in ONE launch (a workgroup holds its image x groups slab in registers); default 256 (16x16), 0 = always
+ * the two-launch form.  Returns 0, or LGD_ERR_ARG for an unknown name. */
 int lgd_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------------------------------------

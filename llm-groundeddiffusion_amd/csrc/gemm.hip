@@ -36,6 +36,9 @@ struct GemmArgs {
   LgdGemmDesc d;
   int cin;       // c0 + c1
   int k_per_split;  // multiple of BK
+#ifdef LGD_GEMM_ABLATION
+  int stagger;      // tools: workgroups of the second residency slot start late by stagger x 64 x 127 cycles
+#endif
 };
 
 __device__ __forceinline__ float4 ld_bias4(const float* p, int n) {
@@ -64,6 +67,12 @@ __device__ __forceinline__ f32x4 epilogue_value4(const LgdGemmDesc& d, long r_of
   v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
   if (GEGLU) {
     g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
+#ifdef LGD_GEMM_ABLATION                 // tools: epi bit 16 = GEGLU without the GELU arithmetic
+    if (d.epi & (1 << 16)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = v[r] * g[r];
+    } else
+#endif
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = v[r] * gelu_f(g[r]);
   }
@@ -207,7 +216,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& ga, f32x4 (&acc)[N
   // all MI x NI fetches are issued before the first one is consumed, so the epilogue pays one
   // memory round trip, not MI x NI of them.  Out-of-range lanes fetch a clamped, valid address.
   const bool res16 = d.res && !(d.epi & LGD_EPI_RES_F32);
-  constexpr int NCH = NI > 5 ? 5 : NI;  // ni columns per prefetch round (bounds the live registers)
+  constexpr int NCH = NI <= 5 ? NI : (NI % 5 == 0 ? 5 : 4);  // ni columns per prefetch round (bounds the live registers)
   static_assert(NI % NCH == 0, "NI must split into equal prefetch rounds");
 #pragma unroll
   for (int nc = 0; nc < NI; nc += NCH) {
@@ -293,6 +302,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& ga, f32x4 (&ac
     bg[no] = bv[no];
     cv[no] = bv[no];
     cg[no] = bv[no];
+#ifdef LGD_GEMM_ABLATION                 // tools: epi bit 18 = no parameter loads in the epilogue
+    if (d.epi & (1 << 18)) continue;
+#endif
     if (n_out < n_total_out) {
       bv[no] = ld_bias_sum4(d, n_in);
       if (GEGLU && d.bias) bg[no] = ld_bias4(d.bias, n_in + 16);
@@ -365,6 +377,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& ga, f32x4 (&ac
       const int row = idx / CPR, ch = idx - row * CPR;
       const int wr = row / WROWS;
       const int m = m0 + wr * 16 * MI + r * WROWS + (row - wr * WROWS), n = n0_out + ch * 8;
+#ifdef LGD_GEMM_ABLATION                 // tools: epi bit 17 = no global stores (one dummy lane keeps the data path alive)
+      if ((d.epi & (1 << 17)) && idx != 0) continue;
+#endif
       if (idx < RROWS * CPR && m < d.M && n < n_total_out) {
         const uint4 val = *reinterpret_cast<const uint4*>(lds + row * CROW + ch * 16);
         *reinterpret_cast<uint4*>(cbase + (long)m * d.ldc + n) = val;
@@ -778,6 +793,13 @@ __device__ __forceinline__ void wait_frags(half8_t (&a)[NA], half8_t (&b)[NB]) {
   if constexpr (NA == 4 && NB == 5)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]),
                  "+v"(b[2]), "+v"(b[3]), "+v"(b[4]));
+  else if constexpr (NA == 8 && NB == 8)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]),
+                 "+v"(a[6]), "+v"(a[7]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]),
+                 "+v"(b[6]), "+v"(b[7]));
+  else if constexpr (NA == 4 && NB == 8)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]),
+                 "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
   else if constexpr (NA == 4 && NB == 4)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]),
                  "+v"(b[2]), "+v"(b[3]));
@@ -822,29 +844,44 @@ __device__ __forceinline__ void wait_frags(half8_t (&a)[NA], half8_t (&b)[NB]) {
 //   Requires cin % 64 == 0 and c0 % 64 == 0 (a K tile never straddles a tap or a source; true for every
 //   UNet contraction), checked by the launcher.
 // ABL (tools only; results are wrong by design): 1 = no DMA in the loop, 2 = no fragment reads in the loop,
-// 4 = no MFMA, 8 = no barrier — the cost of each ingredient by removal.
+// 4 = no MFMA, 8 = no barrier, 16 = no epilogue — the cost of each ingredient by removal.
 // CM ("chunk-major"): 3x3 stride-1 single-source convolutions walk K as (channel chunk, tap) instead of the
 // weight layout's (tap, channel): the nine taps of one 64-channel chunk touch the same 6 x 66 pixel halo of
 // the input, 1/5..1/20 of the map's bytes, so the re-reads hit the XCD's L2 instead of falling out of it
 // between taps (the weight rows are simply visited in a different order; partial sums are order-free).
+// Two-stage rings of the 128-row tiles are 64-72 KB: TWO workgroups share a CU (launch bound 2 => at most 128 VGPRs), so
+// that one's epilogue (GEGLU arithmetic + stores: 60 % of the K = 320 feed-forward GEMM, tools/gemm_abl.sh ABL=16) runs
+// beside the other's MFMAs — waves of ONE workgroup move through the phases in lock-step and cannot overlap them.
+template <int MI, int NI, int NS>
+constexpr int pipe_occupancy() { return (NS == 2 && MI * NI <= 10) ? 2 : 1; }
+
 template <int MI, int NI, int WM, int WN, int NS, bool CM, bool PERSIST = false, int ABL = 0>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs ga) {
+__global__ __launch_bounds__(64 * WM * WN, (pipe_occupancy<MI, NI, NS>())) void gemm_pipe_kernel(const GemmArgs ga) {
   constexpr int NW = WM * WN;
-  static_assert(NW == 8, "eight waves");
+  static_assert(NW == 8 || NW == 4, "eight waves, or four (one per SIMD, the whole register file each)");
   constexpr int BM = WM * 16 * MI;
   constexpr int BN = WN * 16 * NI;
   constexpr int GA = BM / 8, GB = BN / 8;            // 8-row groups (one DMA wave-instruction each)
   static_assert(GA % NW == 0, "A rows");
   static_assert(GB % NW == 0 || GB % NW == NW / 2, "B rows: whole groups per wave plus at most a half group");
+  static_assert(NS != 2 || GB % NW == 0, "the two-stage issue path has no half-group instruction");
   constexpr int A_IT = GA / NW, B_FULL = GB / NW;
   constexpr bool B_HALF = (GB % NW) != 0;
   constexpr int B_IT = B_FULL + (B_HALF ? 1 : 0);
   constexpr int T_DMA = A_IT + B_IT;                         // DMA instructions per wave per K tile
-  constexpr int T1 = (T_DMA + 1) / 2, T2 = T_DMA - T1;       // issued beside k-half 0 / k-half 1
+  // TWO-STAGE RING (round 4, the 256 x 256 tile: a stage is 64 KB).  Tile kt sits in stage kt % 2; the stage of tile kt
+  // is free for tile kt + 2 once every wave's last fragment reads of it (k-half 1, requested at the top of iteration
+  // kt) have retired — they are waited for in front of the barrier in the middle of iteration kt — so ALL of tile
+  // kt + 2's DMA instructions go beside k-half 1 of iteration kt and have until the middle of iteration kt + 1 to
+  // land: one whole K tile of flight time, which on a tile of this size is as many cycles (128 MFMAs per wave) as
+  // the two K tiles a three-stage ring gives the smaller tiles.  The middle wait is then vmcnt(0).
+  constexpr bool TWO = NS == 2;
+  constexpr int T1 = TWO ? 0 : (T_DMA + 1) / 2, T2 = T_DMA - T1;   // issued beside k-half 0 / k-half 1
   constexpr int STAGE = (BM + BN) * BK;                      // halfs per stage
   constexpr int STAGE_B = STAGE * 2;                         // bytes
-  static_assert(NS >= 3 && NS * STAGE_B <= 160 * 1024, "LDS");
-  constexpr int D = NS - 1;                                  // prefetch distance in K tiles
+  static_assert(NS >= 2 && NS * STAGE_B <= 160 * 1024, "LDS");
+  static_assert(!(TWO && PERSIST), "the two-stage ring has no tile-crossing form");
+  constexpr int D = TWO ? 2 : NS - 1;                        // K tiles in flight behind the prologue
   constexpr int NMMA = MI * NI;                              // MFMAs per k-half
 
   extern __shared__ __attribute__((aligned(1024))) half_t smem[];
@@ -855,6 +892,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid - wm * WN;
 
+#ifdef LGD_GEMM_ABLATION
+  if (ga.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int i = 0; i < ga.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   const int n_tiles_n = (d.N + BN - 1) / BN;
   // PERSISTENT TILE LOOP: the launcher may start fewer workgroups than output tiles; workgroup b then computes
   // tiles b, b + gridDim.x, ... and keeps its DMA ring running across tile boundaries: the first D K tiles of the
@@ -898,7 +939,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
   const int cin = ga.cin;
   // persistent workgroups serve plain (taps == 1) contractions only (the launcher sees to it): a compile-time `false`
   // removes the convolution's gather state from the tile-crossing kernels, which spilled 62-170 registers with it
-  const bool conv = PERSIST ? false : d.taps == 9;
+  // so do the two-stage (256 x 256) workgroups, which also keep NO per-row issue state at all: a wave of theirs issues 16
+  // DMA instructions per K tile, and 16 row pointers + 16 weight-row pointers on top of 256 accumulators and 128
+  // fragment registers do not fit; their source addresses are recomputed per instruction (a 64-bit multiply-add each,
+  // against 8 MFMAs per DMA instruction)
+  const bool conv = (PERSIST || TWO) ? false : d.taps == 9;
+  int n0_iss = 0;
   // K position of the next tile to issue.  Tap-major: (tap0, ch0) follow the weight layout.  Chunk-major:
   // tile t of the split's range is (chunk = t / 9, tap = t % 9).
   int tap0 = 0, ch0 = 0;
@@ -916,6 +962,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
   int m0_iss = 0;                 // first row of the tile the issue side works on (persistent: rows are recomputed from it)
   auto setup_issue = [&](int m0, int n0) {
   m0_iss = m0;
+  n0_iss = n0;
+  if constexpr (TWO) { kt_issue = 0; return; }
   if (CM) { const int t = k_beg / BK; ch0 = (t / 9) * BK; tap0 = t - (t / 9) * 9; }
   else { tap0 = conv ? k_beg / cin : 0; ch0 = k_beg - tap0 * cin; }
   kt_issue = 0;
@@ -962,6 +1010,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
   bool a_ok[A_IT];
   // tap-major: (re)derive the A source pointers of the tile about to be issued — at tap / source changes only
   auto derive = [&]() {
+    if constexpr (TWO) return;
     int ky = 0, kx = 0;
     if (conv) { ky = tap0 / 3; kx = tap0 - ky * 3; }
     const bool src1 = ch0 >= d.c0;
@@ -1001,6 +1050,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
   auto issue_one = [&](int j, int so, bool live) {
     half_t* As = smem + so;
     half_t* Bs = As + BM * BK;
+    if constexpr (TWO) {
+      const int kcur = k_beg + kt_issue * BK + kseg * 8;
+      if (j < A_IT) {
+        int m = m0_iss + (j * NW + wid) * 8 + lrow;
+        if (m >= d.M) m = d.M - 1;
+        const half_t* p = live ? A0 + (long)m * d.lda0 + kcur : zero;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)(As + (j * NW + wid) * 8 * BK), 16, 0, 0);
+      } else {
+        const int i = j - A_IT;
+        int n = n0_iss + (i * NW + wid) * 8 + lrow;
+        if (n >= d.N) n = d.N - 1;
+        const half_t* p = live ? W + (long)n * d.ldw + kcur : zero;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)p, (lds_ptr_t)(Bs + (i * NW + wid) * 8 * BK), 16, 0, 0);
+      }
+      return;
+    }
     if (j < A_IT) {
       const half_t* p;
       if (CM) p = (((a_mask[j] >> tap0) & 1) && live) ? a_cen[j] + cm_off : zero;
@@ -1020,6 +1085,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
   // after a tile has been issued: advance the K walk and the source pointers (uniform control flow)
   auto advance = [&]() {
     ++kt_issue;
+    if constexpr (TWO) return;
     if (CM) {
       int wstep = cin;
       if (++tap0 == 9) { tap0 = 0; ch0 += BK; wstep = BK - 8 * cin; }
@@ -1127,7 +1193,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
     lds_read_frags<0, FSTR>(bf0, b_b0, seqB{});
     // byte offsets of the stages of K tile kt, kt+1 and of the one being issued (kt+D); the ring keeps turning
     // across output tiles
-    unsigned so_cur = 0, so_nxt = STAGE_B, so_iss = D * STAGE_B;
+    unsigned so_cur = 0, so_nxt = STAGE_B, so_iss = (D % NS) * STAGE_B;   // two stages: the issue stage IS the current one
     auto next_stage = [](unsigned x) { x += STAGE_B; return x == NS * STAGE_B ? 0u : x; };
     auto k_loop = [&]() {
       for (int kt = 0; kt < nk; ++kt) {
@@ -1161,6 +1227,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
     const bool lds_epi = d.splits == 1 && !(d.epi & LGD_EPI_OUT_F32) && !(d.N & 7) && !(d.ldc & 7) && !(c_off & 7) &&
                          !(reinterpret_cast<uintptr_t>(d.c) & 15) && !((d.epi & LGD_EPI_GEGLU) && (NI & 1));
     auto epilogue = [&](int m0_, int n0_) {
+      if constexpr (ABL & 16) {       // tools: no epilogue at all (every accumulator stays live: no MFMA is dead code)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(acc[ni][mi]));
+        return;
+      }
       if (lds_epi) {
         unsigned char* free_stage = reinterpret_cast<unsigned char*>(smem) + so_iss;
         if (d.epi & LGD_EPI_GEGLU) {
@@ -1170,7 +1243,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
           gemm_epilogue_lds<MI, NI, WM, WN, STAGE_B, false, !PERSIST>(ga, acc, m0_, n0_, wm, wn, lane, tid, c_off, r_off, free_stage);
         }
       } else {
-        gemm_epilogue<MI, NI>(ga, acc, m0_, n0_, wm, wn, lane, batch, split, c_off, r_off, reinterpret_cast<int*>(smem));
+        // the 256 x 256 tile has no register-layout epilogue (128 accumulators + its residual prefetch spilled 239
+        // registers): the launcher admits it only where the LDS epilogue applies
+        if constexpr (!(TWO && MI * NI >= 32))
+          gemm_epilogue<MI, NI>(ga, acc, m0_, n0_, wm, wn, lane, batch, split, c_off, r_off, reinterpret_cast<int*>(smem));
       }
     };
     if constexpr (PERSIST) {
@@ -1200,7 +1276,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_pipe_kernel(const GemmArgs 
     for (int v = blockIdx.x; v < total_tiles; v += gridDim.x) {
       int m0, n0;
       tile_origin(v, m0, n0);
-      gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off, reinterpret_cast<int*>(smem));
+      if constexpr (!(TWO && MI * NI >= 32))
+        gemm_epilogue<MI, NI>(ga, acc, m0, n0, wm, wn, lane, batch, split, c_off, r_off, reinterpret_cast<int*>(smem));
     }
   }
 }
@@ -1280,7 +1357,7 @@ int launch_gemm_pipe_cm(const GemmArgs& ga, hipStream_t st) {
     // no persistent form of the chunk-major (3x3 convolution) kernels, nor of the 256 x 160 tile: with 80 accumulator
     // registers the tile-crossing state does not fit 256 VGPRs (58 spilled even after the trims above); measured gain
     // of persistence on that tile's K <= 640 shapes was +4..9 % of ~2.5 % of the step
-    if constexpr (CM || (MI == 4 && NI == 5)) return 0L;
+    if constexpr (CM || (MI == 4 && NI == 5) || NS == 2) return 0L;
     else {
       const char* e = getenv("LGD_GEMM_PERSIST");
       int per_cu = 0, cus = 0, dev = 0;
@@ -1312,12 +1389,15 @@ int launch_gemm_pipe_cm(const GemmArgs& ga, hipStream_t st) {
       case 6: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, false, 6>); break;
       case 8: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, false, 8>); break;
       case 11: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, false, 11>); break;
+      case 16: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, false, 16>); break;
+      case 17: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, false, 17>); break;
+      case 20: go(&gemm_pipe_kernel<MI, NI, WM, WN, NS, CM, false, 20>); break;
       default: break;
     }
     return lgd_check_launch();
   }
 #endif
-  if constexpr (!CM && !(MI == 4 && NI == 5)) {     // see `resident`: no such instantiations
+  if constexpr (!CM && !(MI == 4 && NI == 5) && NS != 2) {     // see `resident`: no such instantiations
     if (persist) {
       hipLaunchKernelGGL((gemm_pipe_kernel<MI, NI, WM, WN, NS, false, true>), grid, dim3(64 * WM * WN), SMEM, st, ga);
       return lgd_check_launch();
@@ -1333,8 +1413,19 @@ template <int MI, int NI, int WM, int WN, int NS>
 int launch_gemm_pipe(const GemmArgs& ga, hipStream_t st) {
   const LgdGemmDesc& d = ga.d;
   static const int no_cm = [] { const char* e = getenv("LGD_GEMM_NO_CM"); return (e && e[0] == '1') ? 1 : 0; }();
+  if constexpr (NS == 2) {          // the two-stage 256 x 256 tile: plain single-source contractions only
+    if (d.taps != 1 || d.c1 > 0) return LGD_ERR_ARG;
+    if constexpr (MI * NI >= 32) {  // 256 x 256: the LDS epilogue only (one split, fp16 rows of whole 16-byte pieces)
+      const long c_off_max = (long)(d.nb_o - 1) * d.c_bs_o + (long)(d.nb_i - 1) * d.c_bs_i;
+      if (d.splits != 1 || (d.epi & LGD_EPI_OUT_F32) || (d.N & 7) || (d.ldc & 7) || (c_off_max & 7) || (d.c_bs_o & 7) ||
+          (d.c_bs_i & 7) || (reinterpret_cast<uintptr_t>(d.c) & 15) || d.K < BK)
+        return LGD_ERR_ARG;
+    }
+    return launch_gemm_pipe_cm<MI, NI, WM, WN, NS, false>(ga, st);
+  } else {
   const bool cm = d.taps == 9 && d.stride == 1 && d.ups == 0 && d.c1 == 0 && !no_cm;
   return cm ? launch_gemm_pipe_cm<MI, NI, WM, WN, NS, true>(ga, st) : launch_gemm_pipe_cm<MI, NI, WM, WN, NS, false>(ga, st);
+  }
 }
 
 }  // namespace
@@ -1367,6 +1458,9 @@ extern "C" int lgd_gemm_f16(const LgdGemmDesc* desc, void* stream) {
   if ((d.epi & LGD_EPI_ROWNORM) && (!d.rowstat || !d.colsum || d.taps != 1 || d.nb_o * d.nb_i != 1 || d.c1 > 0))
     return LGD_ERR_ARG;
   // K range of each split, multiple of BK
+#ifdef LGD_GEMM_ABLATION
+  { const char* e = getenv("LGD_GEMM_STAGGER"); ga.stagger = e ? atoi(e) : 0; }
+#endif
   int ktiles = (d.K + BK - 1) / BK;
   int tps = (ktiles + d.splits - 1) / d.splits;
   ga.k_per_split = tps * BK;
@@ -1401,6 +1495,8 @@ extern "C" int lgd_gemm_f16(const LgdGemmDesc* desc, void* stream) {
       case 40: rc = geglu ? LGD_ERR_ARG : launch_gemm_pipe<1, 5, 4, 2, 5>(ga, st); break;  // 64x160,  5
       case 41: rc = launch_gemm_pipe<1, 4, 4, 2, 5>(ga, st); break;                         // 64x128,  5
       case 42: rc = launch_gemm_pipe<1, 2, 4, 2, 6>(ga, st); break;                         // 64x64,   6
+      case 44: rc = launch_gemm_pipe<4, 8, 4, 2, 2>(ga, st); break;                         // 256x256, 2 stages, eight waves of 64x128
+      case 45: rc = launch_gemm_pipe<2, 4, 4, 2, 2>(ga, st); break;                         // 128x128, 2 stages, two workgroups per CU
       default: return LGD_ERR_ARG;
     }
     if (rc) return rc;

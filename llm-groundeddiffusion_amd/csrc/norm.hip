@@ -224,6 +224,110 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// GroupNorm(+SiLU) in ONE launch for maps whose (image, group set) slab fits the register file of a workgroup
+// (round 4): grid = (G / kg, B); a workgroup owns kg whole groups of one image (kg = smallest count whose channels
+// are a multiple of 8, so every 16-byte vector belongs to one workgroup), reads its slab ONCE into registers
+// (MAXP pixels x 8 channels per thread), reduces mean, then the CENTRED squares (two-pass variance — no
+// E[x^2] - mean^2 cancellation), and writes the normalised (+SiLU) slab.  The two-launch form reads the map
+// twice and, at 16x16 and 8x8, both of its launches sit on the launch floor.  Fixed summation order, no atomics.
+// ------------------------------------------------------------------------------------------
+template <int MAXP>
+__global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict__ x0, const half_t* __restrict__ x1,
+                                                        int c0, int c1, int HW, int G, float eps,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int silu, half_t* __restrict__ y, float* stats, int kg) {
+  __shared__ float s_part[256 * 8];
+  __shared__ float s_ch[256];
+  __shared__ float s_g[8][2];
+  const int tid = threadIdx.x;
+  const int C = c0 + c1, cpg = C / G;
+  const int b = blockIdx.y, g_lo = blockIdx.x * kg;
+  const int W = kg * cpg, nv = W / 8, pl = 256 / nv;
+  const int vcol = tid % nv, plane = tid / nv;
+  const bool active = plane < pl;
+  const int c = g_lo * cpg + vcol * 8;                 // first of this thread's 8 channels
+  const bool second = c >= c0;
+  const half_t* src = second ? x1 : x0;
+  const int cc = second ? c - c0 : c;
+  const int ld = second ? c1 : c0;
+  half8_t h[MAXP];
+#pragma unroll
+  for (int u = 0; u < MAXP; ++u) {
+    const int pp = plane + u * pl;
+    h[u] = (active && pp < HW) ? *reinterpret_cast<const half8_t*>(src + ((long)b * HW + pp) * ld + cc)
+                               : (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  // per-channel totals over the pixel lanes, then per-group totals: thread j < W owns channel j of the slab
+  auto group_sum = [&](const float (&v)[8], int slot) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_part[tid * 8 + e] = active ? v[e] : 0.f;
+    __syncthreads();
+    if (tid < W) {
+      float t = 0.f;
+      for (int p = 0; p < pl; ++p) t += s_part[p * W + tid];
+      s_ch[tid] = t;
+    }
+    __syncthreads();
+    if (tid < kg) {
+      float t = 0.f;
+      for (int j = 0; j < cpg; ++j) t += s_ch[tid * cpg + j];
+      s_g[tid][slot] = t / ((float)HW * cpg);
+    }
+    __syncthreads();
+  };
+  float a[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = 0.f;
+#pragma unroll
+  for (int u = 0; u < MAXP; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += (float)h[u][e];
+  group_sum(a, 0);
+  float mean[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { mean[e] = s_g[(vcol * 8 + e) / cpg][0]; a[e] = 0.f; }
+#pragma unroll
+  for (int u = 0; u < MAXP; ++u) {
+    const bool ok = plane + u * pl < HW;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float dlt = (float)h[u][e] - mean[e];
+      a[e] += ok ? dlt * dlt : 0.f;
+    }
+  }
+  group_sum(a, 1);                                      // s_g[g][1] = variance
+  if (tid < kg && stats) {
+    stats[((long)b * G + g_lo + tid) * 2 + 0] = s_g[tid][0];
+    stats[((long)b * G + g_lo + tid) * 2 + 1] = rsqrtf(s_g[tid][1] + eps);
+  }
+  if (!active) return;
+  float sa[8], sb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float rstd = rsqrtf(s_g[(vcol * 8 + e) / cpg][1] + eps);
+    sa[e] = rstd * gamma[c + e];
+    sb[e] = beta[c + e] - mean[e] * sa[e];
+  }
+#pragma unroll
+  for (int u = 0; u < MAXP; ++u) {
+    const int pp = plane + u * pl;
+    if (pp < HW) {
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)h[u][e] * sa[e] + sb[e];
+        if (silu) f = silu_f(f);
+        o[e] = (half_t)f;
+      }
+      *reinterpret_cast<half8_t*>(y + ((long)b * HW + pp) * C + c) = o;
+    }
+  }
+}
+
+// option "gn_fused": largest map (pixels) the one-launch GroupNorm takes; 0 = always two launches
+int g_gn_fused_hw = 256;
+
+// ------------------------------------------------------------------------------------------
 // GroupNorm backward (w.r.t. x).  With xhat = (x-mean)*rstd, z = gamma*xhat+beta, y = act(z):
 //   dz = gy * act'(z);  dxhat = dz*gamma
 //   dx = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat*xhat))
@@ -624,6 +728,8 @@ int gn_apply_blocks(int B, int HW, int C) {
 
 }  // namespace
 
+void lgd_gn_set_fused_hw(int hw) { g_gn_fused_hw = hw; }    // lgd_set_option("gn_fused", hw) (attn.hip)
+
 extern "C" int lgd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, int B, int HW,
                                  int G, float eps, const float* gamma, const float* beta, int silu,
                                  void* y, float* part, int nchunk, float* stats, void* stream) {
@@ -632,6 +738,27 @@ extern "C" int lgd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1,
   if (G > 64 || C > GN_MAXC || (C % G) || (c0 % 8) || (c1 % 8) || nchunk < 1) return LGD_ERR_ARG;
   if (c1 > 0 && !x1) return LGD_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  {
+    // one launch when a workgroup can hold its (image, kg groups) slab in registers
+    const int cpg = C / G;
+    int kg = 1;
+    while ((kg * cpg) % 8) kg *= 2;
+    const int W = kg * cpg, nv = W / 8;
+    if (HW <= g_gn_fused_hw && kg <= 8 && (G % kg) == 0 && W <= 256) {
+      const int pl = 256 / nv, npx = (HW + pl - 1) / pl;
+      if (npx <= 32) {
+#define GN_FUSED(P)                                                                                                 \
+  hipLaunchKernelGGL(gn_fused_kernel<P>, dim3(G / kg, B), dim3(256), 0, st, (const half_t*)x0, (const half_t*)x1,    \
+                     c0, c1, HW, G, eps, gamma, beta, silu, (half_t*)y, stats, kg)
+        if (npx <= 4) GN_FUSED(4);
+        else if (npx <= 8) GN_FUSED(8);
+        else if (npx <= 16) GN_FUSED(16);
+        else GN_FUSED(32);
+#undef GN_FUSED
+        return lgd_check_launch();
+      }
+    }
+  }
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, st, (const half_t*)x0,
                      (const half_t*)x1, c0, c1, HW, G, part, nchunk);
   const int napply = gn_apply_blocks(B, HW, C);

@@ -147,6 +147,8 @@ TILE_NAMES.update({25: "gemm_dma_kernel<4,10,4> 256x320", 26: "gemm_dma_kernel<4
 _PIPE_DIMS = {33: (4, 5, 3), 34: (4, 4, 3), 35: (4, 2, 4), 37: (2, 5, 4), 38: (2, 4, 4), 39: (2, 2, 5), 40: (1, 5, 5),
               41: (1, 4, 5), 42: (1, 2, 6)}
 TILE_NAMES.update({t: f"gemm_pipe_kernel<{mi},{ni},4,2,{ns}> {64 * mi}x{32 * ni}" for t, (mi, ni, ns) in _PIPE_DIMS.items()})
+# round 4: 256 x 256, two-stage ring (plain single-source contractions only), eight waves of 64 x 128
+TILE_NAMES.update({44: "gemm_pipe_kernel<4,8,4,2,2> 256x256", 45: "gemm_pipe_kernel<2,4,4,2,2> 128x128 x2/CU"})
 
 
 def choose_tile(M, N, batches=1, geglu=False, K=64, pipe_ok=False):

@@ -49,6 +49,9 @@ def pack_geglu(w, b):  # [2n,K] -> 16-row value/gate interleave
     # 8-wave 256-row tiles (25: 256x320, 26: 256x128)
     (8192, 320, 320, 25, 1), (4100, 640, 640, 25, 1), (2048, 640, 2560, 26, 2), (300, 1280, 1280, 26, 1),
     (515, 960, 192, 25, 1),
+    # round 4, two-stage rings: 44 = 256x256 (eight waves of 64x128), 45 = 128x128 with two workgroups per CU
+    (8192, 512, 320, 44, 1), (4100, 2560, 640, 44, 1), (300, 1280, 1280, 44, 1), (515, 1280, 1280, 45, 1), (4100, 640, 640, 45, 1),
+    (8192, 320, 64, 44, 1), (8192, 320, 64, 45, 1),                      # one K tile: the ring's prologue alone
 ])
 def test_gemm_plain(dev, M, N, K, tile, splits):
     x = rnd(M, K, dev=dev, seed=1).half()
@@ -71,7 +74,8 @@ def test_gemm_out_f32_bias2(dev):
 
 
 @pytest.mark.parametrize("M,dim,splits,tile", [(4096, 320, 1, 0), (300, 640, 1, 0), (128, 1280, 2, 0),
-                                               (4096, 320, 1, 17), (300, 640, 1, 19), (128, 1280, 2, 20)])
+                                               (4096, 320, 1, 17), (300, 640, 1, 19), (128, 1280, 2, 20),
+                                               (4100, 320, 1, 44), (300, 640, 1, 44), (4100, 320, 1, 45), (300, 640, 2, 45)])
 def test_gemm_geglu(dev, M, dim, splits, tile):
     inner = 4 * dim
     x = rnd(M, dim, dev=dev, seed=1).half()
@@ -91,6 +95,7 @@ def test_gemm_geglu(dev, M, dim, splits, tile):
     (4100, 320, 960, False, 33, 1), (4100, 640, 1920, False, 34, 1), (4100, 320, 2560, True, 34, 1),   # LDS epilogue, ragged M
     (515, 1280, 1280, False, 37, 1), (515, 320, 320, False, 2, 1), (515, 640, 640, False, 18, 1),
     (128, 1280, 1280, False, 20, 4),                                                                    # split-K, both reducers
+    (4100, 320, 2560, True, 44, 1), (4100, 640, 1920, False, 44, 1), (515, 640, 1920, False, 45, 1), (515, 320, 2560, True, 45, 1),
 ])
 def test_gemm_rownorm_is_layernorm_then_linear(dev, M, C, N, geglu, tile, splits):
     """LGD_EPI_ROWNORM (ABI v8): statistics pass + GEMM on the raw rows with gamma-folded weights == LayerNorm
@@ -269,6 +274,40 @@ def test_groupnorm_fwd_bwd(dev, B, HW, C0, C1, silu, eps):
     assert relerr(gx0, gref[..., :C0].reshape(B * HW, C0)) < 5e-3
     if C1:
         assert relerr(gx1, gref[..., C0:].reshape(B * HW, C1)) < 5e-3
+
+
+@pytest.mark.parametrize("B,HW,C0,C1,silu", [
+    (2, 256, 1280, 0, True), (2, 256, 1280, 1280, True), (3, 256, 1280, 640, True),    # cpg 40, 80, 60 (two groups per workgroup)
+    (2, 256, 640, 0, True), (2, 64, 1280, 1280, True), (5, 64, 1280, 0, False),          # cpg 20; the 8x8 level
+    (2, 256, 320, 0, False), (1, 100, 960, 0, True), (2, 256, 128, 64, False),           # cpg 10 (4 groups), 30, 6 (concat inside a group)
+    (2, 1024, 640, 320, True), (1, 1024, 1280, 640, True),                               # 32x32 with "gn_fused" raised to 1024
+])
+def test_groupnorm_one_launch_vs_torch_and_two_launch(dev, B, HW, C0, C1, silu):
+    """The register-resident one-launch GroupNorm of the small maps (csrc/norm.hip gn_fused_kernel) against
+    torch.group_norm and against the two-launch kernels, statistics included (the backward reads them)."""
+    C, G, eps = C0 + C1, 32, 1e-5
+    x = (rnd(B, HW, C, dev=dev, seed=1) * 2 + 3.0 * rnd(B, 1, C, dev=dev, seed=9)).half()      # per-channel offsets: mean >> std in places
+    gamma, beta = 1 + 0.2 * rnd(C, dev=dev, seed=2), 0.2 * rnd(C, dev=dev, seed=3)
+    x0 = x[..., :C0].reshape(B * HW, C0).contiguous()
+    x1 = x[..., C0:].reshape(B * HW, C1).contiguous() if C1 else None
+    st1, st2 = torch.zeros(B, G, 2, device=dev), torch.zeros(B, G, 2, device=dev)
+    try:
+        ops.set_option("gn_fused", max(HW, 256))
+        y1 = ops.groupnorm(x0, B, HW, G, eps, gamma, beta, silu, x1=x1, stats=st1)
+        ops.set_option("gn_fused", 0)
+        y2 = ops.groupnorm(x0, B, HW, G, eps, gamma, beta, silu, x1=x1, stats=st2)
+    finally:
+        ops.set_option("gn_fused", 256)
+    ref = F.group_norm(x.float().permute(0, 2, 1), G, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    refl = ref.permute(0, 2, 1).reshape(B * HW, C)
+    xg = x.float().reshape(B, HW, G, C // G)
+    mean, var = xg.mean(dim=(1, 3)), xg.var(dim=(1, 3), unbiased=False)
+    assert relerr(st1[..., 0], mean) < 1e-5 and relerr(st1[..., 1], (var + eps).rsqrt()) < 1e-5
+    assert relerr(st2[..., 0], mean) < 1e-4 and relerr(st2[..., 1], (var + eps).rsqrt()) < 1e-3
+    assert relerr(y1, refl) < 2e-3 and relerr(y2, refl) < 3e-3
+    assert relerr(y1, y2) < 3e-3
 
 
 @pytest.mark.parametrize("rows,C", [(8192, 320), (2048, 640), (513, 1280), (30, 64)])

@@ -84,7 +84,7 @@ for (M, N, K, taps, cin, h, geglu) in SHAPES:
             continue
         if sp > 1 and K // 64 < 2 * sp:
             continue
-        d = ops.gemm_desc(a0, w, c, M, N, K, c0=cin, lda0=cin, bias=bias, res=res, ldr=n_out, epi=geglu, ldc=n_out,
+        d = ops.gemm_desc(a0, w, c, M, N, K, c0=cin, lda0=cin, bias=bias, res=res, ldr=n_out, epi=geglu | (int(os.environ.get("EPI_ABL", "0")) << 16), ldc=n_out,
                           tile=tile, splits=None if tile == 0 else sp, **kw)
         c.zero_()
         try:

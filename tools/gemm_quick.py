@@ -40,6 +40,8 @@ for (M, N, K, taps, c0, c1, h, geglu) in SHAPES:
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 100
         if best is None or us < best[0]: best = (us, d.tile, d.splits)
+    if best is None:
+        continue
     tot += best[0]
     print(f"M{M:6d} N{N:5d} K{K:6d} t{taps} g{geglu}: tile {best[1]} split {best[2]} {best[0]:8.1f} us {2.0*M*N*K/best[0]/1e6:7.1f} TF/s")
 print(f"total {tot:.1f} us")
