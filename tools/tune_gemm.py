@@ -58,7 +58,10 @@ print(f"{len(shapes)} distinct GEMM shapes")
 TILE_DIMS = {17: (128, 128), 18: (128, 64), 19: (64, 128), 20: (64, 64), 21: (32, 128), 22: (128, 160), 23: (64, 160),
              33: (256, 160), 34: (256, 128), 35: (256, 64), 37: (128, 160), 38: (128, 128),
              # round 4: the deeper-ringed small 8-wave tiles (5-6 LDS stages) were in the library but never candidates
-             39: (128, 64), 40: (64, 160), 41: (64, 128), 42: (64, 64)}
+             39: (128, 64), 40: (64, 160), 41: (64, 128), 42: (64, 64),
+             # round 4: two-stage rings (plain single-source contractions only): 256x256, and 128x128 at two workgroups per CU
+             44: (256, 256), 45: (128, 128)}
+PLAIN_ONLY = {44, 45}
 NO_GEGLU = {22, 23, 33, 37, 40}                  # odd fragment counts cannot pair value | gate column blocks
 VERIFY_TOL = 2e-3                                # fp16 outputs, different summation orders
 rejected = []
@@ -171,13 +174,27 @@ for key, sh in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"
             continue
         if tile > 32 and (not pipe_ok or M < bm):
             continue
+        if tile in PLAIN_ONLY and (sh["taps"] != 1 or sh["c1"] > 0):
+            continue
         wgs = -(-M // bm) * -(-N // bn)
         for sp in (1, 2, 3, 4, 6, 8, 12, 16):
             if sp > 1 and (K // 64 < 4 * sp or wgs * sp > 2048 or sp * M * N > (1 << 26)):
                 continue
+            if tile == 44 and sp > 1:
+                continue   # the 256 x 256 tile leaves through the LDS epilogue only (one split)
             if wgs * sp < (8 if N_STREAMS > 1 else 48) and sp < 16 and K // 64 >= 8 * sp:
                 continue   # hopelessly under-filled, a larger split exists (shared GPU: other sequences fill it)
             cands.append((tile, sp))
+    only = os.environ.get("LGD_TUNE_ONLY_TILES")      # "44,45": try just these tiles against the entry the table holds
+    if only:
+        keep = {int(t) for t in only.split(",")}
+        cands = [(t, sp) for t, sp in cands if t in keep and (sp == 1 or t != 44)]
+        if not cands:
+            if key in old_entries:
+                table[key] = old_entries[key]
+            continue
+        if key in old_entries:
+            cands.append((old_entries[key]["tile"], old_entries[key]["splits"]))
     pb = make_problem(sh)
     ref = reference(sh, pb)
     best = None
