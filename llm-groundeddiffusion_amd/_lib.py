@@ -106,6 +106,10 @@ def load():
         fn.restype = c_int
     if lib.lgd_abi_version() != ABI_VERSION:
         raise RuntimeError("liblgd_hip.so ABI version mismatch; rebuild")
+    # LGD_OPTIONS="gn_fused=0,attn_w4=2": kernel-variant switches (lgd_set_option) for A/B runs of unmodified commands
+    for item in filter(None, os.environ.get("LGD_OPTIONS", "").split(",")):
+        name, _, value = item.partition("=")
+        check(lib.lgd_set_option(name.strip().encode(), int(value)), f"lgd_set_option({name})")
     _lib = lib
     return lib
 

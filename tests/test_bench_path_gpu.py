@@ -349,7 +349,10 @@ def test_fullsize_guidance_iteration_vs_oracle(dev):
     print(f"[full] guidance loss hip {l_hip:.4f} oracle {l_ref:.4f}; latent-gradient cosine {cos:.5f} "
           f"rel-L2 {rel_l2(a, b):.3e}")
     gate("[full] guidance loss rel. error", abs(l_hip - l_ref) / abs(l_ref), 1e-4)
-    gate("[full] latent-gradient cosine", cos, 0.99988, at_least=True)
+    # the energy RANKS map elements (top 20 %): elements at the threshold change sides with the last bit of the map, so
+    # launch plans that differ only in the summation order of one GEMM move this cosine between 0.99981 and 0.99996
+    # (profiles/r04_guidance_gradient_vs_gemm_tiling.txt, ten variants); the limit is 3x the worst of them
+    gate("[full] latent-gradient cosine", cos, 0.9994, at_least=True)
     gate("[full] latent-gradient rel-L2", rel_l2(a, b), 2.7e-2)
 
 
