@@ -546,7 +546,7 @@ def main():
             # HBM bytes per launch come from a committed PMC summary of THIS command's short form (PMC passes serialise
             # every dispatch: they cannot run inside the timed region) — the source file is named in the record
             traffic, traffic_note, traffic_source = None, "no PMC summary for this kernel under profiles/", None
-            for fname in ("r03_bench_traffic_pmc.json", "r02_bench_traffic_pmc.json"):
+            for fname in ("r04_bench_traffic_pmc.json", "r03_bench_traffic_pmc.json", "r02_bench_traffic_pmc.json"):
                 tpath = os.path.join(ROOT, "profiles", fname)
                 if not os.path.exists(tpath):
                     continue
@@ -563,9 +563,9 @@ def main():
                             avg_launch_us=round(a["raw_ms"] * 1e3 / a["raw_n"], 2),
                             launches_per_image=round(a["n"]), est_ms_per_image=round(a["ms"], 1),
                             traffic_note=traffic_note, traffic_source=traffic_source,
-                            rocprof_summary="profiles/r03a_bench_4layouts_kernel_stats.csv (one launch sequence alone: its "
+                            rocprof_summary="profiles/r04b_bench_lanes1_kernel_stats.csv (one launch sequence alone: its "
                                             "per-launch averages are the ones comparable with avg_launch_us); "
-                                            "profiles/r03b_bench_4lanes_kernel_stats.csv (this command with 4 lanes: "
+                                            "profiles/r04b_bench_4lanes_kernel_stats.csv (this command with 4 lanes: "
                                             "durations of kernels that overlap each other)",
                             method="HIP events around each launch, eager replay of the benchmark's plans right after "
                                    "the timed region, ONE launch sequence alone on the GPU (the timed region itself "

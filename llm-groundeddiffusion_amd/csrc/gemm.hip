@@ -36,6 +36,7 @@ struct GemmArgs {
   LgdGemmDesc d;
   int cin;       // c0 + c1
   int k_per_split;  // multiple of BK
+  int group_m;      // gemm_pipe_kernel: output tiles are walked in groups of group_m row panels (1 = rows of tiles)
 #ifdef LGD_GEMM_ABLATION
   int stagger;      // tools: workgroups of the second residency slot start late by stagger x 64 x 127 cycles
 #endif
@@ -904,13 +905,29 @@ __global__ __launch_bounds__(64 * WM * WN, (pipe_occupancy<MI, NI, NS>())) void 
   // is the one-tile-per-workgroup kernel.)  Consecutive workgroup ids land on consecutive XCDs, and b + i*gridDim.x
   // keeps b's XCD when gridDim.x % 8 == 0, so the XCD-contiguous tile remap below holds for every tile of a workgroup.
   const int total_tiles = ((d.M + BM - 1) / BM) * n_tiles_n;
+  // GROUPED WALK (round 4): with the plain order (n fastest) every row panel streams the WHOLE weight matrix; once that
+  // no longer fits the XCD's 4 MB L2 (feed-forward layers: 5120 x 640, 10240 x 1280, 1280 x 5120 weights = 6.5-26 MB)
+  // each panel re-fetches it from the Infinity Cache (PMC: 265 MB read per launch for 27 MB of operands).  Walking
+  // group_m row panels per weight column block keeps that block AND the group's A panels L2-resident.
   auto tile_origin = [&](int v, int& m0_, int& n0_) {
     const int q = total_tiles >> 3, r = total_tiles & 7;
     const int xcd = v & 7, idx = v >> 3;
     const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tile_m = bid / n_tiles_n;
+    int tile_m, tile_n;
+    if (ga.group_m > 1) {
+      const int per_group = ga.group_m * n_tiles_n;
+      const int g = bid / per_group, in = bid - g * per_group;
+      const int n_tiles_m = total_tiles / n_tiles_n;
+      int rows = n_tiles_m - g * ga.group_m;
+      if (rows > ga.group_m) rows = ga.group_m;
+      tile_n = in / rows;
+      tile_m = g * ga.group_m + (in - tile_n * rows);
+    } else {
+      tile_m = bid / n_tiles_n;
+      tile_n = bid - tile_m * n_tiles_n;
+    }
     m0_ = tile_m * BM;
-    n0_ = (bid - tile_m * n_tiles_n) * BN;
+    n0_ = tile_n * BN;
   };
   const int zz = blockIdx.z;
   const int batch = zz / d.splits;
@@ -1461,6 +1478,17 @@ extern "C" int lgd_gemm_f16(const LgdGemmDesc* desc, void* stream) {
 #ifdef LGD_GEMM_ABLATION
   { const char* e = getenv("LGD_GEMM_STAGGER"); ga.stagger = e ? atoi(e) : 0; }
 #endif
+  {
+    // grouped tile walk of the pipelined kernels: plain contractions whose weights exceed what an XCD's L2 keeps beside
+    // the A panels; the group is as many 256-row A panels as fit ~3 MB (LGD_GEMM_GROUP_M forces a size, 1 = off)
+    static const int forced = [] { const char* e = getenv("LGD_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
+    ga.group_m = 1;
+    const long w_bytes = (long)d.N * d.K * 2;
+    if (d.taps == 1 && d.nb_o * d.nb_i == 1 && w_bytes > (5L << 19)) {
+      long g = (3L << 20) / (256L * d.K * 2);
+      ga.group_m = forced > 0 ? forced : (int)(g < 1 ? 1 : g > 8 ? 8 : g);
+    }
+  }
   int ktiles = (d.K + BK - 1) / BK;
   int tps = (ktiles + d.splits - 1) / d.splits;
   ga.k_per_split = tps * BK;

@@ -38,6 +38,6 @@ res = dict(method="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passe
                             hbm_read_bytes_per_launch=round(e["read"] / e["launches"]),
                             hbm_write_bytes_per_launch=round(e["write"] / e["launches"]), launches=e["launches"])
                     for n, e in sorted(out.items())})
-json.dump(res, open("$OUT/r02_bench_traffic_pmc.json", "w"), indent=1)
+json.dump(res, open("$OUT/bench_traffic_pmc.json", "w"), indent=1)
 print("kernels:", len(res["kernels"]))
 PY
