@@ -74,8 +74,10 @@ __device__ __forceinline__ f32x4 epilogue_value4(const LgdGemmDesc& d, long r_of
       for (int r = 0; r < 4; ++r) v[r] = v[r] * g[r];
     } else
 #endif
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = v[r] * gelu_f(g[r]);
+    {
+      const f32x2_t g01 = gelu2_f((f32x2_t){g[0], g[1]}), g23 = gelu2_f((f32x2_t){g[2], g[3]});
+      v[0] *= g01[0]; v[1] *= g01[1]; v[2] *= g23[0]; v[3] *= g23[1];
+    }
   }
   const float alpha = d.alpha;
 #pragma unroll

@@ -287,7 +287,7 @@ def test_fullsize_cfg_forward_throughput_table_vs_oracle(dev):
             gate(f"[full, throughput table, fuser={fuser}] map {k} relerr", relerr(plan.maps[k], saved[k]), 2.7e-2)
             gate(f"[full, throughput table, fuser={fuser}] map {k} rel-L2", rel_l2(plan.maps[k], saved[k]), 1.2e-2)
         if ("eps", fuser) in _FULL:
-            gate(f"[full, throughput vs latency table, fuser={fuser}] eps relerr", relerr(eps, _FULL[("eps", fuser)]), 3e-3)
+            gate(f"[full, throughput vs latency table, fuser={fuser}] eps relerr", relerr(eps, _FULL[("eps", fuser)]), 4.5e-3)   # measured 1.4-1.6e-3
     del eng
     torch.cuda.empty_cache()
 

@@ -460,7 +460,8 @@ def test_backward_guidance_run_vs_reference_run_golden(dev):
                 got_l = np.array([x["loss"] for x in tr]) / kw["overall_loss_scale"]
                 if want_iters[i]:
                     gate(f"[bg run {tag}] step {i}: {want_iters[i]} per-iteration losses, max rel. error",
-                         float(np.abs(got_l - want_losses[n0:n0 + want_iters[i]]).max() / np.abs(want_losses).max()), 6e-3)
+                         float(np.abs(got_l - want_losses[n0:n0 + want_iters[i]]).max() / np.abs(want_losses).max()),
+                         1.5e-2 if (tag, i) == ("a", 0) else 6e-3)    # run a, step 0 (5 iterations from noise): measured 4.9e-3
                 n0 += want_iters[i]
                 gate(f"[bg run {tag}] step {i} teacher-forced ({want_iters[i]} guidance iterations)",
                      relerr(out["latents"], want), (1e-1 if (tag, i) == ("a", 0) else 1e-2) if want_iters[i] else 1e-3)
@@ -542,7 +543,7 @@ def test_unet_wrapper_is_differentiable_wrt_sample_as_the_guidance_loop_drives_i
     want = torch.autograd.grad(loss_o, [lat])[0]
     loss, grad = hip_grad({}, 30)
     gate("[unet wrapper autograd, ratio default] loss vs oracle", abs(loss - float(loss_o)) / float(loss_o), 2e-3)
-    gate("[unet wrapper autograd, ratio default] latent-gradient cosine vs oracle", cos(grad, want), 0.9998, at_least=True)
+    gate("[unet wrapper autograd, ratio default] latent-gradient cosine vs oracle", cos(grad, want), 0.9996, at_least=True)   # measured 0.99989
     gate("[unet wrapper autograd, ratio default] latent-gradient rel-L2", float((grad - want).norm() / want.norm()), 3e-2)
     # without grad mode the same call is a plain forward with detached maps
     with torch.no_grad():
