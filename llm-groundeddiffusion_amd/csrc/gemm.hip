@@ -267,8 +267,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& ga, f32x4 (&acc)[N
 //   reads of it retired before the K loop's last barrier) on ENTRY, for one-tile and persistent workgroups alike; on
 //   EXIT a persistent workgroup closes the last round with a barrier (see the end of the round loop).
 //   Bare s_barrier + lgkmcnt(0): a __syncthreads() would drain the DMA queue of a persistent workgroup.
+// The round-3 form with runtime flags: kept for the 256 x 256 tile, whose 128 accumulators leave no room for six
+// specialisations' worth of live parameters (the specialised form spilled 6-10 registers there).
 template <int MI, int NI, int WM, int WN, int STAGE_B, bool GEGLU, bool RES_PREFETCH>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& ga, f32x4 (&acc)[NI][MI], int m0, int n0, int wm,
+__device__ __forceinline__ void gemm_epilogue_lds_generic(const GemmArgs& ga, f32x4 (&acc)[NI][MI], int m0, int n0, int wm,
                                                   int wn, int lane, int tid, long c_off, long r_off,
                                                   unsigned char* lds) {
   const LgdGemmDesc& d = ga.d;
@@ -369,6 +371,170 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& ga, f32x4 (&ac
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
         *reinterpret_cast<half4_t*>(lds + (wm * WROWS + mj * 16 + m_l) * CROW + (wn * 16 * NI_OUT + no * 16 + n_l) * 2) = o;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // whole rows, 16 bytes per lane
+#pragma unroll
+    for (int i = 0; i < (RROWS * CPR + NT - 1) / NT; ++i) {
+      const int idx = tid + i * NT;
+      const int row = idx / CPR, ch = idx - row * CPR;
+      const int wr = row / WROWS;
+      const int m = m0 + wr * 16 * MI + r * WROWS + (row - wr * WROWS), n = n0_out + ch * 8;
+#ifdef LGD_GEMM_ABLATION                 // tools: epi bit 17 = no global stores (one dummy lane keeps the data path alive)
+      if ((d.epi & (1 << 17)) && idx != 0) continue;
+#endif
+      if (idx < RROWS * CPR && m < d.M && n < n_total_out) {
+        const uint4 val = *reinterpret_cast<const uint4*>(lds + row * CROW + ch * 16);
+        *reinterpret_cast<uint4*>(cbase + (long)m * d.ldc + n) = val;
+      }
+    }
+    // Between rounds the staging rows are rewritten; behind the LAST round of a persistent workgroup (RES_PREFETCH ==
+    // !PERSIST) the next output tile's K loop issues LDS-DMA into this very stage before its first barrier — every
+    // wave's staged-row reads must have retired before any wave gets there.
+    if (r + 1 < R || !RES_PREFETCH) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+}
+
+// RES16 (an fp16 residual is added; never with GEGLU) and RN (LGD_EPI_ROWNORM) are COMPILE-TIME here (round 4): with
+// runtime flags every 4-output piece carried the dispatch of all residual forms and the row-norm select — ~94
+// instructions and six uniform branches per piece, 1500 per wave against the 2560 MFMA cycles of a K = 320 main loop
+// (the epilogue was 45-60 % of the short-K GEMMs, tools/gemm_abl.sh).  The call site picks one of six specialisations
+// once per tile; an fp32 residual or GEGLU + residual take the register-layout epilogue instead.
+template <int MI, int NI, int WM, int WN, int STAGE_B, bool GEGLU, bool RES_PREFETCH, bool RES16, bool RN>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& ga, f32x4 (&acc)[NI][MI], int m0, int n0, int wm,
+                                                  int wn, int lane, int tid, long c_off, long r_off,
+                                                  unsigned char* lds) {
+  static_assert(!(GEGLU && RES16), "GEGLU outputs take no residual here");
+  const LgdGemmDesc& d = ga.d;
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = WM * 16 * MI, BN = WN * 16 * NI;
+  constexpr int BN_OUT = GEGLU ? BN / 2 : BN;
+  constexpr int NI_OUT = GEGLU ? NI / 2 : NI;           // output column tiles of a wave
+  constexpr int CROW = BN_OUT * 2 + 16;                 // bytes per staged row
+  // rounds over the 16-row tiles (mi) of EVERY wave: all waves work in both phases of a round, and a round still
+  // covers whole output rows (16 MI_R rows of each of the WM wave rows)
+  constexpr int R = (BM * CROW <= STAGE_B) ? 1 : ((BM / 2) * CROW <= STAGE_B) ? 2 : 4;
+  static_assert(MI % R == 0 && (BM / R) * CROW <= STAGE_B, "staged rows must fit one ring stage");
+  constexpr int MI_R = MI / R;
+  constexpr int WROWS = 16 * MI_R;                      // rows of one wave row per round
+  constexpr int RROWS = WM * WROWS;
+  constexpr int CPR = BN_OUT / 8;                       // 16-byte chunks per row
+  const int m_l = lane & 15, n_l = (lane >> 4) * 4;
+  const int n0_out = GEGLU ? n0 / 2 : n0;
+  const int n_total_out = GEGLU ? d.N / 2 : d.N;
+  half_t* cbase = reinterpret_cast<half_t*>(d.c) + c_off;
+  const f32x2_t alpha2 = {d.alpha, d.alpha};
+  // parameters of this wave's columns (biases, column sums of the folded LayerNorm) and rows (clamped index, row
+  // statistics): one batch of loads, one memory round trip, before the first accumulator is touched
+  // LEAN (the 256 x 256 tile: 128 accumulators): column sums are fetched per column block inside the round loop and the
+  // residual's column select is recomputed — hoisted they spill
+  constexpr bool LEAN = MI * NI >= 32;
+  float4 bv[NI_OUT], bg[NI_OUT], cv[NI_OUT], cg[NI_OUT];
+  int ncol[NI_OUT];                                     // clamped output column of the residual fetch
+#pragma unroll
+  for (int no = 0; no < NI_OUT; ++no) {
+    const int n_out = n0_out + wn * 16 * NI_OUT + no * 16 + n_l;
+    const int n_in = GEGLU ? n0 + wn * 16 * NI + no * 32 + n_l : n_out;
+    const bool ok = n_out < n_total_out;
+    ncol[no] = ok ? n_out : 0;
+    bv[no] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bg[no] = bv[no];
+    cv[no] = bv[no];
+    cg[no] = bv[no];
+#ifdef LGD_GEMM_ABLATION                 // tools: epi bit 18 = no parameter loads in the epilogue
+    if (d.epi & (1 << 18)) continue;
+#endif
+    if (ok) {
+      bv[no] = ld_bias_sum4(d, n_in);
+      if (GEGLU && d.bias) bg[no] = ld_bias4(d.bias, n_in + 16);
+      if constexpr (RN && !LEAN) {
+        cv[no] = *reinterpret_cast<const float4*>(d.colsum + n_in);
+        if (GEGLU) cg[no] = *reinterpret_cast<const float4*>(d.colsum + n_in + 16);
+      }
+    }
+  }
+  int mrow[MI];
+  float2 st[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    int m = m0 + wm * 16 * MI + mi * 16 + m_l;
+    if (m >= d.M) m = d.M - 1;
+    mrow[mi] = m;
+    st[mi] = make_float2(0.f, 1.f);
+    if constexpr (RN) st[mi] = *reinterpret_cast<const float2*>(d.rowstat + (long)m * 2);
+  }
+  // rstd (v - mean colsum) + bias on the two halves of a piece
+  auto normed = [&](const f32x4& v, const float2 s2, const float4 c, const float4 b, f32x2_t& lo, f32x2_t& hi) {
+    lo = (f32x2_t){v[0], v[1]};
+    hi = (f32x2_t){v[2], v[3]};
+    if constexpr (RN) {
+      const f32x2_t mean = {s2.x, s2.x}, rstd = {s2.y, s2.y};
+      lo = rstd * (lo - mean * (f32x2_t){c.x, c.y});
+      hi = rstd * (hi - mean * (f32x2_t){c.z, c.w});
+    }
+    lo += (f32x2_t){b.x, b.y};
+    hi += (f32x2_t){b.z, b.w};
+  };
+  unsigned char* lw = lds + (wm * WROWS + m_l) * CROW + (wn * 16 * NI_OUT + n_l) * 2;   // this lane's staging origin
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    // residual fetches of the round first (one memory round trip for MI_R x NI_OUT pieces)
+    half4_t rpre[NI_OUT][MI_R];
+    if constexpr (RES16) {
+      const half_t* rb = reinterpret_cast<const half_t*>(d.res) + r_off;
+#pragma unroll
+      for (int mj = 0; mj < MI_R; ++mj) {
+        const half_t* rrow = rb + (long)mrow[r * MI_R + mj] * d.ldr;
+#pragma unroll
+        for (int no = 0; no < NI_OUT; ++no) {
+          int nc = ncol[no];
+          if constexpr (LEAN) {
+            const int n_out = n0_out + wn * 16 * NI_OUT + no * 16 + n_l;
+            nc = n_out < n_total_out ? n_out : 0;
+          }
+          rpre[no][mj] = *reinterpret_cast<const half4_t*>(rrow + nc);
+        }
+      }
+    }
+#pragma unroll
+    for (int no = 0; no < NI_OUT; ++no) {
+      if constexpr (RN && LEAN) {
+        const int n_out = n0_out + wn * 16 * NI_OUT + no * 16 + n_l;
+        const int n_in = GEGLU ? n0 + wn * 16 * NI + no * 32 + n_l : n_out;
+        if (n_out < n_total_out) {
+          cv[no] = *reinterpret_cast<const float4*>(d.colsum + n_in);
+          if (GEGLU) cg[no] = *reinterpret_cast<const float4*>(d.colsum + n_in + 16);
+        }
+      }
+#pragma unroll
+      for (int mj = 0; mj < MI_R; ++mj) {
+        const int mi = r * MI_R + mj;
+        f32x2_t lo, hi;
+        if constexpr (GEGLU) {
+          f32x2_t glo, ghi;
+          normed(acc[2 * no][mi], st[mi], cv[no], bv[no], lo, hi);
+          normed(acc[2 * no + 1][mi], st[mi], cg[no], bg[no], glo, ghi);
+#ifdef LGD_GEMM_ABLATION                 // tools: epi bit 16 = GEGLU without the GELU arithmetic
+          if (d.epi & (1 << 16)) { lo *= glo; hi *= ghi; } else
+#endif
+          { lo *= gelu2_f(glo); hi *= gelu2_f(ghi); }
+        } else {
+          normed(acc[no][mi], st[mi], cv[no], bv[no], lo, hi);
+        }
+        lo *= alpha2;
+        hi *= alpha2;
+        if constexpr (RES16) {
+          const half4_t rr = rpre[no][mj];
+          lo += (f32x2_t){(float)rr[0], (float)rr[1]};
+          hi += (f32x2_t){(float)rr[2], (float)rr[3]};
+        }
+        const half4_t o = {(half_t)lo[0], (half_t)lo[1], (half_t)hi[0], (half_t)hi[1]};
+        *reinterpret_cast<half4_t*>(lw + mj * 16 * CROW + no * 32) = o;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1244,7 +1410,8 @@ __global__ __launch_bounds__(64 * WM * WN, (pipe_occupancy<MI, NI, NS>())) void 
     };
     // fp16 outputs without split-K leave through LDS as whole rows (gemm_epilogue_lds); the stage consumed last is free
     const bool lds_epi = d.splits == 1 && !(d.epi & LGD_EPI_OUT_F32) && !(d.N & 7) && !(d.ldc & 7) && !(c_off & 7) &&
-                         !(reinterpret_cast<uintptr_t>(d.c) & 15) && !((d.epi & LGD_EPI_GEGLU) && (NI & 1));
+                         !(reinterpret_cast<uintptr_t>(d.c) & 15) && !((d.epi & LGD_EPI_GEGLU) && (NI & 1)) &&
+                         !(d.res && (d.epi & (LGD_EPI_RES_F32 | LGD_EPI_GEGLU)));   // fp32 / GEGLU residuals: register-layout epilogue
     auto epilogue = [&](int m0_, int n0_) {
       if constexpr (ABL & 16) {       // tools: no epilogue at all (every accumulator stays live: no MFMA is dead code)
 #pragma unroll
@@ -1255,12 +1422,25 @@ __global__ __launch_bounds__(64 * WM * WN, (pipe_occupancy<MI, NI, NS>())) void 
       }
       if (lds_epi) {
         unsigned char* free_stage = reinterpret_cast<unsigned char*>(smem) + so_iss;
-        if (d.epi & LGD_EPI_GEGLU) {
-          if constexpr (NI % 2 == 0)
-            gemm_epilogue_lds<MI, NI, WM, WN, STAGE_B, true, !PERSIST>(ga, acc, m0_, n0_, wm, wn, lane, tid, c_off, r_off, free_stage);
+        // one specialisation per (GEGLU, fp16 residual, folded LayerNorm): no per-piece dispatch inside
+#define LGD_EPI_LDS(G, RS, RNORM) \
+  gemm_epilogue_lds<MI, NI, WM, WN, STAGE_B, G, !PERSIST, RS, RNORM>(ga, acc, m0_, n0_, wm, wn, lane, tid, c_off, r_off, free_stage)
+        const bool rn_ = d.epi & LGD_EPI_ROWNORM;
+        if constexpr (MI * NI >= 32) {
+          if (d.epi & LGD_EPI_GEGLU)
+            gemm_epilogue_lds_generic<MI, NI, WM, WN, STAGE_B, true, !PERSIST>(ga, acc, m0_, n0_, wm, wn, lane, tid, c_off, r_off, free_stage);
+          else
+            gemm_epilogue_lds_generic<MI, NI, WM, WN, STAGE_B, false, !PERSIST>(ga, acc, m0_, n0_, wm, wn, lane, tid, c_off, r_off, free_stage);
+        } else if (d.epi & LGD_EPI_GEGLU) {
+          if constexpr (NI % 2 == 0) {
+            if (rn_) LGD_EPI_LDS(true, false, true); else LGD_EPI_LDS(true, false, false);
+          }
+        } else if (d.res) {
+          if (rn_) LGD_EPI_LDS(false, true, true); else LGD_EPI_LDS(false, true, false);
         } else {
-          gemm_epilogue_lds<MI, NI, WM, WN, STAGE_B, false, !PERSIST>(ga, acc, m0_, n0_, wm, wn, lane, tid, c_off, r_off, free_stage);
+          if (rn_) LGD_EPI_LDS(false, false, true); else LGD_EPI_LDS(false, false, false);
         }
+#undef LGD_EPI_LDS
       } else {
         // the 256 x 256 tile has no register-layout epilogue (128 accumulators + its residual prefetch spilled 239
         // registers): the launcher admits it only where the LDS epilogue applies
@@ -1437,7 +1617,8 @@ int launch_gemm_pipe(const GemmArgs& ga, hipStream_t st) {
     if constexpr (MI * NI >= 32) {  // 256 x 256: the LDS epilogue only (one split, fp16 rows of whole 16-byte pieces)
       const long c_off_max = (long)(d.nb_o - 1) * d.c_bs_o + (long)(d.nb_i - 1) * d.c_bs_i;
       if (d.splits != 1 || (d.epi & LGD_EPI_OUT_F32) || (d.N & 7) || (d.ldc & 7) || (c_off_max & 7) || (d.c_bs_o & 7) ||
-          (d.c_bs_i & 7) || (reinterpret_cast<uintptr_t>(d.c) & 15) || d.K < BK)
+          (d.c_bs_i & 7) || (reinterpret_cast<uintptr_t>(d.c) & 15) || d.K < BK ||
+          (d.res && (d.epi & (LGD_EPI_RES_F32 | LGD_EPI_GEGLU))))
         return LGD_ERR_ARG;
     }
     return launch_gemm_pipe_cm<MI, NI, WM, WN, NS, false>(ga, st);
