@@ -90,7 +90,13 @@ typedef struct LgdGemmDesc {
   float* ws;          /* fp32 [batch][splits][M][N]                                         */
   int32_t tile;       /* 0 auto; 1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64, 5: 32x128, 6: 128x160, 7: 64x160
                          (register-staged main loop); +16 = same tile, LDS-DMA main loop (K % 64 == 0);
-                         25: 256x320, 26: 256x128 (8 waves, LDS-DMA only) */
+                         25: 256x320, 26: 256x128 (8 waves, LDS-DMA only);
+                         33..42: 8-wave pipelined main loop, 3-6 LDS stages (K, c0, c1 % 64 == 0): 33: 256x160,
+                         34: 256x128, 35: 256x64, 37: 128x160, 38: 128x128, 39: 128x64, 40: 64x160, 41: 64x128,
+                         42: 64x64 (160-wide tiles: no GEGLU);
+                         44 / 45 (ABI v8): two-stage rings, plain single-source contractions only (taps == 1,
+                         c1 == 0): 44: 256x256 (one split, fp16 rows of whole 16-byte pieces, no fp32 / GEGLU
+                         residual), 45: 128x128 with two workgroups per CU.  LGD_ERR_ARG where a code does not apply */
   int32_t* cnt;       /* split-K arrival counters (ABI v5), device int32[batches * tiles], ALL ZERO on entry, or NULL.
                          With counters the split-K combine happens inside the GEMM launch: every workgroup stores its
                          fp32 partial, publishes it (agent-scope release) and takes a ticket; the last arriver of an
