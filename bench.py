@@ -302,7 +302,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="batch4", choices=["batch4", "lmd_v0.1", "backward_guidance", "sdxl_refiner"])
+    ap.add_argument("--workload", default="batch4", choices=["batch4", "lmd", "lmd_v0.1", "backward_guidance", "sdxl_refiner"])
     ap.add_argument("--sdxl-step-ratio", type=float, default=0.3, help="sdxl_refiner: img2img strength (generate.py:52)")
     ap.add_argument("--layouts", type=int, default=4, help="batch4: cached layouts per rank per step")
     ap.add_argument("--prompts", type=int, default=100, help="lmd_v0.1: prompts of the cache (whole job)")
@@ -311,6 +311,11 @@ def main():
     ap.add_argument("--lanes", type=int, default=4,
                     help="concurrent denoising pipelines per GPU, each on its own HIP stream with its own engine state "
                          "(lgd_amd/lanes.py): steps (batch4) or halves of the prompt set (lmd_v0.1) run side by side")
+    ap.add_argument("--group", type=int, default=1,
+                    help="batch4 / lmd: steps a lane takes AT ONCE (their layouts share UNet calls: --group 2 with --layouts 4 "
+                         "= 16 per-box generations and 8 overall generations per denoising call, chunked by --max-batch*)")
+    ap.add_argument("--max-batch", type=int, default=8, help="images per UNet call, unguided generations (LMDSampler.max_batch)")
+    ap.add_argument("--max-batch-guided", type=int, default=4, help="images per UNet call, guided generations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -326,7 +331,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn(args.gpus))
     if args.config is None:
-        args.config = {"backward_guidance": "sd21", "sdxl_refiner": "sdxl_refiner"}.get(args.workload, "sd14_gligen")
+        args.config = {"backward_guidance": "sd21", "sdxl_refiner": "sdxl_refiner", "lmd": "sd15"}.get(args.workload, "sd14_gligen")
     if args.workload == "sdxl_refiner":
         return main_sdxl(args)
 
@@ -346,7 +351,7 @@ def main():
     beta = 0.4                                                      # lmd_plus.py:208-209
 
     # ---- this rank's share of the work (global prompt index preserved: seeds derive from it) -----------------
-    if args.workload in ("batch4", "backward_guidance"):
+    if args.workload in ("batch4", "lmd", "backward_guidance"):
         pool = [i for i, r in enumerate(cache) if len(r["gen_boxes"]) == 2]
         mine = [pool[(rank * args.layouts + i) % len(pool)] for i in range(args.layouts)]
         seeds = [rank * args.layouts + i for i in range(args.layouts)]
@@ -403,7 +408,7 @@ def main():
 
     pinned = ldist.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), lanes=max(1, args.lanes))
     from lgd_amd import ops
-    from lgd_amd.pipeline import backward_guidance_generate_batch, lmd_plus_generate_batch
+    from lgd_amd.pipeline import backward_guidance_generate_batch, lmd_generate_batch, lmd_plus_generate_batch
     from lgd_amd.sampler import LMDSampler
     from lgd_amd.scheduler import DDIMScheduler
     from lgd_amd.unet import UNetEngine
@@ -413,7 +418,9 @@ def main():
     if world > 1:
         ldist.init(backend="nccl")
     # rank 0 materialises the weights; everyone else receives the two arenas over RCCL/xGMI
-    eng = UNetEngine(cfg, dev, weights.synth_state_dict(cfg, 0) if rank == 0 else None)
+    mb = max(1, args.max_batch)
+    mbg = max(1, min(args.max_batch_guided, mb))
+    eng = UNetEngine(cfg, dev, weights.synth_state_dict(cfg, 0) if rank == 0 else None, max_text_batch=max(32, 2 * mb))
     bcast_s = ldist.broadcast_weights(eng.w, src=0) if world > 1 else 0.0
     from lgd_amd.lanes import LanePool, make_lanes
     side = 8 * cfg.sample_size
@@ -433,7 +440,7 @@ def main():
 
     def make_sampler(e):
         return LMDSampler(e, DDIMScheduler(prediction_type=cfg.prediction_type),
-                          vae=None if args.no_decode else make_hip_vae(dev))
+                          vae=None if args.no_decode else make_hip_vae(dev), max_batch=mb, max_batch_guided=mbg)
 
     # lanes: independent pipelines on their own HIP streams sharing one copy of the weights; with one lane this is
     # the plain sequential loop on a side stream
@@ -449,6 +456,14 @@ def main():
         if args.workload == "backward_guidance":       # generation/backward_guidance.py:46-49 defaults
             return backward_guidance_generate_batch(lane.sampler, sub, num_inference_steps=n_steps, height=side,
                                                     width=side, decode=not args.no_decode)
+        if args.workload == "lmd":                     # generation/lmd.py:215-256 defaults (per-box guidance ON)
+            kw = dict(dict(frozen_step_ratio=0.5, so_center_box=True, align_with_overall_bboxes=True), **kw)
+            outs = lmd_generate_batch(lane.sampler, sub, num_inference_steps=n_steps, decode=not args.no_decode,
+                                      mask_refiner=lane.extras["refiner"], **kw)
+            for o in outs:                              # iterations of the per-box stage count as work of the image
+                o["guidance_iters"] += sum(o["so_guidance_iters"])
+                o["guidance_iters_fuser_on"] = 0
+            return outs
         return lmd_plus_generate_batch(lane.sampler, sub, num_inference_steps=n_steps, decode=not args.no_decode,
                                        mask_refiner=lane.extras["refiner"], **kw)
 
@@ -459,26 +474,39 @@ def main():
         step_jobs = [[lays[j] for j in sh] for sh in shares]
     else:
         step_jobs = [lays]
+    group = max(1, args.group) if len(step_jobs) == 1 else 1
+
+    def jobs_of(n_steps):
+        """The lane jobs of n_steps benchmark steps: the layouts of up to `group` consecutive steps per job."""
+        if group == 1:
+            return step_jobs * n_steps
+        out, left = [], n_steps
+        while left > 0:
+            out.append(lays * min(group, left))
+            left -= min(group, left)
+        return out
 
     # launch plans, GEMM kernel attributes and captured hipGraphs of every batch bucket this rank will use are built
     # BEFORE the timed barrier even with --warmup 0, lane by lane: a 2-step pass over the same layouts has the same
     # batch composition, and the sampler's device state (hence its graphs) does not depend on the step count
     t_pre = time.perf_counter()
     pre_kw = {} if args.workload == "backward_guidance" else dict(overall_max_index_step=2, frozen_step_ratio=0.5)
+    if args.workload == "lmd":
+        pre_kw["max_index_step"] = 2
     for k in range(len(lanes)):
-        subs = step_jobs if len(step_jobs) == 1 else [step_jobs[k]]
+        subs = sorted({len(j): j for j in jobs_of(args.steps) + jobs_of(args.warmup)}.values(), key=len) if len(step_jobs) == 1 else [step_jobs[k]]
         lane_pool.map(lambda lane, sub: one_step(lane, sub, 2, **pre_kw), subs, pin=[k] * len(subs))
     torch.cuda.synchronize()
     prebuild_s = time.perf_counter() - t_pre
     if args.warmup:
-        lane_pool.map(one_step, step_jobs * args.warmup)
+        lane_pool.map(one_step, jobs_of(args.warmup))
     for ln in lanes:
         ln.sampler.pass_counts.clear()
     ldist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     it_on = it_all = 0
-    for outs in lane_pool.map(one_step, step_jobs * args.steps):
+    for outs in lane_pool.map(one_step, jobs_of(args.steps)):
         it_all += sum(o["guidance_iters"] for o in outs)
         it_on += sum(o["guidance_iters_fuser_on"] for o in outs)
     torch.cuda.synchronize()
@@ -591,12 +619,19 @@ def main():
         tf = algorithmic_tflop(mean_boxes, T, beta, iters_on, iters_off)
     elif args.config == "sd21" and args.workload == "backward_guidance":
         tf = T * TF_SD21_MAIN + (iters_on + iters_off) * TF_SD21_GUIDE
+    elif args.config == "sd15" and args.workload == "lmd":
+        # LMD = (N+1) x 50 plain CFG calls + every guidance iteration taken (per-box AND overall stage)
+        tf = (mean_boxes + 1) * T * TF_MAIN_OFF + (iters_on + iters_off) * TF_GUIDE_OFF
     what = (f"{args.layouts} cached 2-box layouts/GPU/step" if args.workload != "lmd_v0.1" else
             f"{n_total} layouts of the lmd_v0.1 cache (0-5 boxes, mean {mean_boxes:.2f}) cost-balanced over {world} rank(s)")
-    method = {"backward_guidance": "layout-guidance baseline (generation/backward_guidance.py), "}.get(args.workload, "LMD+ stage 2, ")
-    arch = {"sd14_gligen": "SD1.4+GLIGEN architecture", "sd21": "SD2.1-768 architecture, v-prediction"}.get(args.config, args.config)
-    metric = ("images/sec (50-step SD1.5 512^2, LMD+ guidance)" if args.workload != "backward_guidance" else
-              f"images/sec (50-step SD2.1 {side}^2, backward guidance)")
+    method = {"backward_guidance": "layout-guidance baseline (generation/backward_guidance.py), ",
+              "lmd": "training-free LMD stage 2 (generation/lmd.py defaults: per-box AND overall cross-attention guidance, "
+                     "max_index_step 30, reference-attention transfer, frozen_step_ratio 0.4), "}.get(args.workload, "LMD+ stage 2, ")
+    arch = {"sd14_gligen": "SD1.4+GLIGEN architecture", "sd21": "SD2.1-768 architecture, v-prediction",
+            "sd15": "SD1.5 architecture"}.get(args.config, args.config)
+    metric = {"backward_guidance": f"images/sec (50-step SD2.1 {side}^2, backward guidance)",
+              "lmd": "images/sec (50-step SD1.5 512^2, training-free LMD guidance)"}.get(
+                  args.workload, "images/sec (50-step SD1.5 512^2, LMD+ guidance)")
     res = dict(metric=metric, value=round(n_images / dt, 4),
                unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=round(dt * 1e3 / args.steps, 1), higher_is_better=True,
@@ -608,7 +643,15 @@ def main():
                                     + ("; per-box masks refined by SAM (sam-vit-base architecture, random weights, "
                                        "HIP model + device-side processor)" if args.sam else "; per-box masks = box masks"),
                            mask_refinement="sam" if args.sam else "box",
-                           layouts_per_gpu=(args.layouts if args.workload == "batch4" else round(n_total / world, 2)),
+                           layouts_per_gpu=(args.layouts if args.workload in ("batch4", "lmd") else round(n_total / world, 2)),
+                           # how the step's generations are packed into UNet calls: a lane job = the layouts of
+                           # `steps_per_lane_job` steps; their per-box / overall generations are chunked into calls of at
+                           # most this many images (CFG batch = 2x), padded to a bucket of LMDSampler.BUCKETS
+                           steps_per_lane_job=group,
+                           images_per_unet_call=dict(unguided_max=lanes[0].sampler.max_batch,
+                                                     guided_max=lanes[0].sampler.max_batch_guided,
+                                                     timed_region={f"{k_}{'+fuser' if f_ else ''} x{nb_}": n_
+                                                                   for (k_, f_, nb_), n_ in sorted(pass_counts.items())}),
                            num_inference_steps=T, parallelism=f"dp{world}", rccl_ranks=world,
                            guidance_iters_per_image=round(iters_on + iters_off, 2),
                            guidance_iters_fuser_on=round(iters_on, 2),

@@ -112,6 +112,26 @@ def sam_refiner(model_dict, height, width, **kw):
     return SamRefiner(dict(sam_model=md["sam_model"], sam_processor=md["sam_processor"]), height=height, width=width, **kw)
 
 
+_PRECISION_NOTED = set()
+
+
+def note_precision(where: str, requested: str):
+    """Precision contract of the drop-in: the HIP engine ALWAYS computes in fp16 with fp32
+    accumulation, fp32 statistics / softmax / energy / latents — the arithmetic of the reference's autocast mode
+    (generation/lmd_plus.py:226,336).  The reference runs training-free LMD and the layout-guidance baseline in fp32
+    (`use_autocast=False`, generation/lmd.py:254,375; generation/backward_guidance.py has no autocast at all;
+    `load_sd(use_fp16=False)`, models/models.py:16,33-38).  Such a request is honoured as "fp16 compute within the stated
+    tolerance of the fp32 result" (tests/test_lmd_fullwidth_gpu.py), and said so ONCE per call site instead of silently."""
+    if where in _PRECISION_NOTED:
+        return False
+    _PRECISION_NOTED.add(where)
+    import warnings
+    warnings.warn(f"{where}: {requested} asks for the reference's fp32 execution; the HIP engine computes in fp16 with fp32 "
+                  "accumulation (fp32 latents, statistics, softmax and energy) — results match the fp32 reference within the "
+                  "fp16 tolerances stated in INTEGRATION.md section 2, not bit for bit", RuntimeWarning, stacklevel=3)
+    return True
+
+
 class EasyDict(dict):
     __getattr__ = dict.__getitem__
     __setattr__ = dict.__setitem__

@@ -3,7 +3,7 @@ baseline: one guided generation, no per-box stage), on the HIP engine."""
 import models
 from lgd_amd.pipeline import backward_guidance_generate
 
-from ._common import DEFAULT_OVERALL_NEGATIVE_PROMPT, DEFAULT_SO_NEGATIVE_PROMPT, EasyDict, build_layout
+from ._common import DEFAULT_OVERALL_NEGATIVE_PROMPT, DEFAULT_SO_NEGATIVE_PROMPT, EasyDict, build_layout, note_precision
 
 version = "backward_guidance"
 height = width = 512
@@ -18,6 +18,8 @@ def run(spec, bg_seed=1, overall_loss_scale=30, overall_loss_threshold=0.2, over
     (utils/guidance.py:91,118-130): mean over heads of (1 - sum(A*M)/sum(A))^2 per phrase token; there are no
     reference maps (`ref_ca_saved_attns=None`), so `ref_ca_loss_weight=0.5` has no effect.  Pinned by
     tests/golden/run_backward_guidance_tiny.npz (the reference's own run(), oracle/make_golden_runs.py)."""
+    # the reference runs this baseline without autocast, i.e. in the dtype models.load_sd loaded (fp32 by default)
+    note_precision("generation.backward_guidance.run", "a run() without autocast")
     sm = models.model_dict.sampler
     lay = build_layout(spec, bg_seed, bg_seed, DEFAULT_SO_NEGATIVE_PROMPT, DEFAULT_OVERALL_NEGATIVE_PROMPT, height, width)
     out = backward_guidance_generate(sm, lay, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,

@@ -2,7 +2,8 @@
 import models
 from lgd_amd.pipeline import DEFAULT_MAX_ITER, lmd_generate
 
-from ._common import DEFAULT_OVERALL_NEGATIVE_PROMPT, DEFAULT_SO_NEGATIVE_PROMPT, EasyDict, build_layout, sam_refiner
+from ._common import (DEFAULT_OVERALL_NEGATIVE_PROMPT, DEFAULT_SO_NEGATIVE_PROMPT, EasyDict, build_layout, note_precision,
+                      sam_refiner)
 
 version = "lmd"
 height = width = 512
@@ -23,7 +24,10 @@ def run(spec, bg_seed=1, overall_prompt_override="", fg_seed_start=20, frozen_st
     reference maps are shifted back onto the overall boxes before composition).  When `models.model_dict` carries
     a SAM model (generate.py:126-127 `model_dict.update(sam.load_sam())`) every per-box mask is SAM's refinement of the
     object token's attention map (generation/lmd.py:124-149) with `mask_th_for_point` / `use_box_input`; otherwise the
-    masks are the box masks."""
+    masks are the box masks.  `use_autocast=False` (the reference's default here: fp32) is answered with
+    fp16 compute / fp32 accumulation and ONE RuntimeWarning (`_common.note_precision`)."""
+    if not use_autocast:                       # the reference's default for this method: fp32 (generation/lmd.py:254,375)
+        note_precision("generation.lmd.run", "use_autocast=False")
     if num_inference_steps <= 10:
         # the reference crashes here too (attn_aggregation_step_start=10, generation/lmd.py:36,124-131)
         print("note: the reference's SAM point prompt aggregates maps from step 10 on; with <=10 steps it would fail")

@@ -4,7 +4,7 @@ generate.py imports this module after `models.model_dict` is set (generate.py:11
 import models
 from lgd_amd.pipeline import DEFAULT_MAX_ITER, lmd_plus_generate
 
-from ._common import DEFAULT_OVERALL_NEGATIVE_PROMPT, DEFAULT_SO_NEGATIVE_PROMPT, EasyDict, build_layout, sam_refiner
+from ._common import DEFAULT_OVERALL_NEGATIVE_PROMPT, DEFAULT_SO_NEGATIVE_PROMPT, EasyDict, build_layout, note_precision, sam_refiner
 
 version = "lmd_plus"
 height = width = 512
@@ -20,8 +20,11 @@ def run(spec, bg_seed=1, overall_prompt_override="", fg_seed_start=20, frozen_st
         overall_negative_prompt=DEFAULT_OVERALL_NEGATIVE_PROMPT, so_horizontal_center_only=True,
         align_with_overall_bboxes=False, horizontal_shift_only=True, use_fast_schedule=False, use_ref_ca=True,
         use_autocast=True, verbose=False):
-    """Argument names and defaults of generation/lmd_plus.py:193-228.  `use_autocast` is accepted for
-    compatibility: the HIP path always computes fp16 with fp32 accumulation."""
+    """Argument names and defaults of generation/lmd_plus.py:193-228.  `use_autocast=True` (the default) is the
+    arithmetic the HIP path always runs (fp16 compute, fp32 accumulation); `use_autocast=False` is answered with the same
+    arithmetic and ONE RuntimeWarning (`_common.note_precision`)."""
+    if not use_autocast:
+        note_precision("generation.lmd_plus.run", "use_autocast=False")
     sm = models.model_dict.sampler
     refiner = sam_refiner(models.model_dict, height, width, discourage_mask_below_coarse_iou=0.25, verbose=verbose)
     lay = build_layout(spec, bg_seed, fg_seed_start, so_negative_prompt, overall_negative_prompt, height, width,

@@ -62,6 +62,9 @@ def load_sd(key="runwayml/stable-diffusion-v1-5", use_fp16=False, load_inverse_s
     state dict is repacked into the HIP engine's arenas, the CLIP text tower runs on the HIP kernels
     (lgd_amd.clip), the VAE decoder's state dict is repacked for the HIP kernels (lgd_amd.vae.HipVAEDecoder;
     LGD_HF_VAE=1 in the environment keeps the Hugging Face module, for A/B checks against it)."""
+    if not use_fp16:      # models/models.py:33-38: the reference then loads fp32 weights ("run final results in fp32")
+        from generation._common import note_precision
+        note_precision("models.load_sd", "use_fp16=False")
     try:
         from diffusers import AutoencoderKL, DDIMScheduler as HFDDIM, UNet2DConditionModel as HFUNet
         from transformers import CLIPTextModel, CLIPTokenizer

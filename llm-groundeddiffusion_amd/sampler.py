@@ -116,7 +116,7 @@ class Job:
 
 
 class LMDSampler:
-    BUCKETS = (1, 2, 4, 8, 16)
+    BUCKETS = (1, 2, 4, 8, 16, 32)
 
     def __init__(self, engine: UNetEngine, scheduler: Optional[DDIMScheduler] = None, vae=None,
                  grad_scale: float = 1024.0, use_graphs: bool = True, max_batch: int = 8,

@@ -1,0 +1,172 @@
+"""Training-free LMD (generation/lmd.py) at FULL width: the SD1.5 network (`weights.CONFIGS["sd15"]`, 320/640/1280
+channels, no GLIGEN fuser) at 64x64 latents — BASELINE config[0]'s method on the architecture it is quoted on.
+
+  * stage A (lmd.py:99-149 -> models/pipelines.py:129-247 `generate_semantic_guidance`): a GUIDED per-box generation
+    whose main pass saves `[obj_attn_key, *guidance_attn_keys]` with `return_cond_ca_only` and the word token's column
+    only (lmd.py:340-352) — latents after every step and all five saved maps vs oracle/restate.py, free-running and
+    teacher-forced from the oracle's own latents;
+  * stage B (lmd.py:530-542 -> pipelines.py:541-599 `generate_partial_frozen`): guided overall generation with the
+    reference-attention term (`ref_ca_saved_attns` = the ORACLE's stage-A maps, fed identically to both sides) and the
+    frozen-mask blend — latents after every step vs the oracle;
+  * the per-box stage as `lmd_generate_batch` drives it at the batch size of `bench.py --workload lmd` (every image of
+    the batch is the one-image problem again).
+
+The oracle runs on the GPU box's host cores in fp32 (the reference's precision for this method, lmd.py:254); the HIP path
+computes in fp16 with fp32 accumulation — tolerances as the GLIGEN twin (tests/test_bench_path_gpu.py), printed by `gate`."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import lgd_amd  # noqa: E402,F401
+from lgd_amd import weights  # noqa: E402
+from lgd_amd.sampler import Job, LMDSampler  # noqa: E402
+from lgd_amd.scheduler import DDIMScheduler  # noqa: E402
+from lgd_amd.unet import UNetEngine  # noqa: E402
+from conftest import gate  # noqa: E402
+
+KEYS = [("mid", 0, 0, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 1, 2, 0)]     # pipelines.py:14
+OBJ_KEY = ("down", 2, 1, 0)                                                     # lmd.py:36 / lmd_plus.py:380
+BOXES = [[0.15, 0.35, 0.5, 0.8], [0.6, 0.38, 0.98, 0.8]]
+OBJ_POS = [[1, 2, 3], [5, 6, 7]]
+WORD = 3                                                                        # word token of the per-box prompt
+T = 2
+_S = {}
+
+
+def relerr(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-20))
+
+
+def setup(dev):
+    if not _S:
+        cfg = weights.CONFIGS["sd15"]
+        sd = weights.synth_state_dict(cfg, 0)
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))     # the oracle's fp32 convs thrash when oversubscribed
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn((1, 4, 64, 64), generator=g)
+        unc, cond = weights.synth_embeddings(cfg, 1, seed=1)
+        _S.update(cfg=cfg, sd=sd, eng=UNetEngine(cfg, dev, sd), x=x, ehs=torch.cat([unc, cond]), cond=cond,
+                  cd=dict(block_out_channels=cfg.block_out_channels, layers_per_block=cfg.layers_per_block,
+                          attention_head_dim=cfg.attention_head_dim, norm_num_groups=cfg.norm_num_groups,
+                          norm_eps=cfg.norm_eps, gligen_positive_len=cfg.gligen_positive_len))
+    return _S
+
+
+def so_guidance():
+    """lmd.py:340-352: the per-box generation is guided on its own box with the energy's default weights."""
+    return dict(bboxes=[BOXES[0]], object_positions=[OBJ_POS[0]], loss_scale=5, loss_threshold=0.0, max_iter=[1, 1],
+                max_index_step=T, guidance_attn_keys=KEYS, use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2,
+                fg_weight=1.0, bg_weight=4.0)
+
+
+def oracle_stage_a(s):
+    if "a_ref" not in s:
+        import restate as R
+        g = so_guidance()
+        sk = {k: v for k, v in g.items() if k not in ("bboxes", "object_positions")}
+        with torch.enable_grad():
+            _, saved, hist = R.generate_semantic_guidance(s["sd"], s["cd"], R.DDIM(), s["x"], (s["ehs"], None, s["cond"]), T,
+                                                          g["bboxes"], g["object_positions"], semantic_guidance_kwargs=sk,
+                                                          saved_cross_attn_keys=[OBJ_KEY, *KEYS], return_cond_ca_only=True,
+                                                          return_token_ca_only=WORD)
+        s["a_ref"] = (saved, hist)
+    return s["a_ref"]
+
+
+def test_sd15_stage_a_guided_semantic_guidance_with_map_saving_vs_oracle(dev):
+    """generate_semantic_guidance at full width, guided, saving [obj_key, *guidance_keys] (cond half, word token)."""
+    s = setup(dev)
+    saved_ref, hist_ref = oracle_stage_a(s)
+    sm = LMDSampler(s["eng"], DDIMScheduler())
+    kw = dict(guidance=so_guidance(), saved_cross_attn_keys=[OBJ_KEY, *KEYS], return_cond_ca_only=True, return_token_ca_only=WORD)
+    out = sm.denoise(s["x"], s["ehs"], T, **kw)
+    torch.cuda.synchronize()
+    assert out["guidance_iters"] == 2
+    for i in range(T):
+        gate(f"[sd15 stage A] latents after step {i} (free-running): relerr", relerr(out["latents_all"][i + 1], hist_ref[i + 1]), 1.5e-2)
+        gate(f"[sd15 stage A] latents after step {i} (free-running): rel-L2", rel_l2(out["latents_all"][i + 1], hist_ref[i + 1]), 5e-3)
+    for k in [OBJ_KEY, *KEYS]:
+        assert tuple(out["saved"][k].shape[1:]) == (1, 8, saved_ref[0][k].shape[2], 1)      # (T, 1, heads, HW, 1)
+        # step 0's map sits behind ONE guided iteration from identical latents; step 1's behind the free-running state
+        gate(f"[sd15 stage A] saved map {k} step 0 rel-L2", rel_l2(out["saved"][k][0], saved_ref[0][k]), 1.5e-2)
+        gate(f"[sd15 stage A] saved map {k} step 1 rel-L2", rel_l2(out["saved"][k][1], saved_ref[1][k]), 3e-2)
+    # teacher-forced: step 1 alone, from the ORACLE's latents after step 0
+    out1 = sm.denoise(hist_ref[1], s["ehs"], T, first_step=1, n_steps=1, **kw)
+    torch.cuda.synchronize()
+    assert out1["guidance_iters"] == 1
+    gate("[sd15 stage A] teacher-forced step 1: latents relerr", relerr(out1["latents_all"][2], hist_ref[2]), 1e-2)
+    gate("[sd15 stage A] teacher-forced step 1: latents rel-L2", rel_l2(out1["latents_all"][2], hist_ref[2]), 4e-3)
+    for k in [OBJ_KEY, *KEYS]:
+        gate(f"[sd15 stage A] teacher-forced step 1: saved map {k} rel-L2", rel_l2(out1["saved"][k][1], saved_ref[1][k]), 1.5e-2)
+
+
+def test_sd15_stage_b_partial_frozen_with_reference_attention_vs_oracle(dev):
+    """generate_partial_frozen at full width: guidance with the reference-attention transfer term (object 0's reference
+    maps = the oracle's stage-A maps, object 1's = seeded positive maps), frozen-mask blend in step 0."""
+    import restate as R
+    s = setup(dev)
+    saved_ref, _ = oracle_stage_a(s)
+    g = torch.Generator().manual_seed(5)
+    hist_in = torch.randn((T + 1, 1, 4, 64, 64), generator=g)
+    hist_in[0] = s["x"]
+    fm = torch.zeros(64, 64, dtype=torch.bool)
+    fm[22:52, 10:32] = True
+    hw = {k: saved_ref[0][k].shape[2] for k in KEYS}
+    refs_obj1 = [{k: torch.rand((1, 8, hw[k], 1), generator=g) / hw[k] for k in KEYS} for _ in range(T)]
+    refs_obj0 = [{k: saved_ref[i][k] for k in KEYS} for i in range(T)]
+    overall_bboxes = [[BOXES[0]], [BOXES[1]]]
+    common = dict(loss_scale=5, loss_threshold=0.0, max_iter=[1, 1], max_index_step=T, guidance_attn_keys=KEYS,
+                  use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0, ref_ca_loss_weight=2.0,
+                  ref_ca_word_token_only=True, ref_ca_last_token_only=True, word_token_indices=[3, 7])   # lmd.py:511-528
+    max_hw = max(hw.values())
+    ref_maps = torch.zeros((T, 2, len(KEYS), 8, max_hw))
+    for i in range(T):
+        for b, refs in enumerate((refs_obj0, refs_obj1)):
+            for ki, k in enumerate(KEYS):
+                ref_maps[i, b, ki, :, :hw[k]] = refs[i][k][0, :, :, 0]
+    sm = LMDSampler(s["eng"], DDIMScheduler())
+    out = sm.denoise(hist_in, s["ehs"], T, guidance=dict(bboxes=overall_bboxes, object_positions=OBJ_POS,
+                                                          ref_maps=ref_maps.to(dev), **common),
+                     frozen_steps=1, frozen_mask=fm)
+    torch.cuda.synchronize()
+    per_step, tr = [], []
+    with torch.enable_grad():
+        R.generate_partial_frozen(s["sd"], s["cd"], R.DDIM(), hist_in, fm, (s["ehs"], None, s["cond"]), T, 1,
+                                  bboxes=overall_bboxes, object_positions=OBJ_POS,
+                                  semantic_guidance_kwargs=dict(ref_ca_saved_attns=[[refs_obj0], [refs_obj1]], **common),
+                                  per_step=per_step, trace=tr)
+    assert out["guidance_iters"] == 2 and len(tr) == 2
+    for i in range(T):
+        gate(f"[sd15 stage B] latents after step {i}: relerr", relerr(out["latents_all"][i + 1], per_step[i]), 1.5e-2)
+        gate(f"[sd15 stage B] latents after step {i}: rel-L2", rel_l2(out["latents_all"][i + 1], per_step[i]), 5e-3)
+
+
+def test_sd15_per_box_stage_at_benchmark_batch_matches_single(dev):
+    """`bench.py --workload lmd` runs the guided per-box stage of several layouts as ONE denoising call (B images in the
+    guidance plan, 2B in the CFG plan): every image of such a call must reproduce the one-image result above up to the
+    accumulation order of the differently tiled GEMMs."""
+    s = setup(dev)
+    sm = LMDSampler(s["eng"], DDIMScheduler(), max_batch_guided=4)
+    kw = dict(saved_cross_attn_keys=[OBJ_KEY, *KEYS], return_cond_ca_only=True)
+    one = sm.denoise(s["x"], s["ehs"], T, guidance=so_guidance(), return_token_ca_only=WORD, **kw)
+    jobs = [Job(s["x"], s["ehs"], guidance=so_guidance(), token=WORD) for _ in range(4)]
+    res = sm.denoise_batch(jobs, T, **kw)
+    torch.cuda.synchronize()
+    for b, r in enumerate(res):
+        assert r["guidance_iters"] == 2
+        gate(f"[sd15 stage A, B=4] image {b} final latents vs B=1", relerr(r["latents"], one["latents"]), 1.5e-2)
+        gate(f"[sd15 stage A, B=4] image {b} saved obj-key map (step 1) vs B=1 rel-L2",
+             rel_l2(r["saved"][OBJ_KEY][1], one["saved"][OBJ_KEY][1]), 2e-2)

@@ -85,3 +85,26 @@ def test_convert_spec_matches_the_prompts_the_reference_built(monkeypatch):
         ns["convert_spec"](spec3, 256, 256)
     so2, _, _ = ns["convert_spec"](dict(spec3, gen_boxes=spec3["gen_boxes"][1:]), 256, 256)   # no repeats: fine
     assert len(so2) == 2
+
+
+def test_fp32_requests_are_answered_with_one_warning_per_call_site():
+    """The reference runs LMD / the layout-guidance baseline in fp32 (generation/lmd.py:254,375; models/models.py:33-38);
+    the HIP engine computes in fp16.  The drop-in says so ONCE per call site instead of
+    silently accepting `use_autocast=False` / `use_fp16=False`."""
+    import warnings
+    src = open(os.path.join(ROOT, "llm-groundeddiffusion_amd", "dropin", "generation", "_common.py")).read()
+    ns = {}
+    body = src[src.index("_PRECISION_NOTED = set()"):src.index("class EasyDict(dict):")]
+    exec(compile(body, "_common_note_precision", "exec"), ns)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert ns["note_precision"]("generation.lmd.run", "use_autocast=False") is True
+        assert ns["note_precision"]("generation.lmd.run", "use_autocast=False") is False
+        assert ns["note_precision"]("models.load_sd", "use_fp16=False") is True
+    assert len(w) == 2 and all(issubclass(x.category, RuntimeWarning) for x in w)
+    assert "fp16" in str(w[0].message) and "INTEGRATION.md" in str(w[0].message)
+    # every plugin entry that accepts an fp32 request routes it here
+    for mod, needle in (("lmd.py", 'note_precision("generation.lmd.run"'), ("lmd_plus.py", 'note_precision("generation.lmd_plus.run"'),
+                        ("backward_guidance.py", 'note_precision("generation.backward_guidance.run"')):
+        assert needle in open(os.path.join(ROOT, "llm-groundeddiffusion_amd", "dropin", "generation", mod)).read()
+    assert 'note_precision("models.load_sd"' in open(os.path.join(ROOT, "llm-groundeddiffusion_amd", "dropin", "models", "models.py")).read()

@@ -31,5 +31,13 @@ PY
       LGD_TUNE_TOP=$TOP timeout ${TUNE_TIMEOUT:-480} python tools/tune_gemm.py sd14_gligen $OUT/latency.json > $OUT/tune.log 2>&1
     fi
     echo "tune rc=$?"; tail -n 4 $OUT/tune.log ;;
+  sweep)      # round 5: (lanes x steps per lane job x images per UNet call) on the default workload; args = bench flags
+    for cfg in "4 1 8 4" "2 2 16 8" "4 2 16 8" "1 4 32 16" "2 4 32 16"; do
+      set -- $cfg
+      timeout 600 python bench.py --steps ${SWEEP_STEPS:-8} --warmup 2 --no-cpu-baseline --no-roofline --lanes $1 --group $2 \
+        --max-batch $3 --max-batch-guided $4 > $OUT/l$1_g$2_b$3.log 2>&1
+      echo "lanes=$1 group=$2 max_batch=$3/$4: $(grep '^{' $OUT/l$1_g$2_b$3.log | tail -1 | cut -c1-130)"
+      grep '^{' $OUT/l$1_g$2_b$3.log | tail -1 > $OUT/l$1_g$2_b$3.json
+    done ;;
   *) echo "unknown stage $STAGE"; exit 2 ;;
 esac
