@@ -37,6 +37,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+ROCPROF_SUMMARY = ("profiles/r05_bench_lanes1_kernel_stats.csv (one launch sequence alone: its per-launch averages are the "
+                   "ones comparable with avg_launch_us); profiles/r05_bench_driver_kernel_stats.csv (the default command: "
+                   "durations of kernels of different lanes overlap each other)")
 MFMA_PEAK_F16 = 2.5e15       # dense fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
 
@@ -78,6 +81,33 @@ def partition_by_cost(costs, world):
         load[r] += costs[i]
         mine[r].append(i)
     return [sorted(m) for m in mine]
+
+
+def lanes_for(workload, n_layouts, max_lanes, min_layouts_per_lane=8):
+    """Pipelines per GPU, derived from the work a rank actually has.  The per-step workloads hand every lane whole steps
+    (always enough); the prompt-set workload splits the rank's layouts over the lanes, and a lane with only a few layouts
+    runs small, badly filled UNet calls (100 prompts over 8 ranks = 12-13 layouts per rank: four lanes would get 3 each) —
+    so a lane is only added per `min_layouts_per_lane` layouts."""
+    if workload != "lmd_v0.1":
+        return max(1, max_lanes)
+    return max(1, min(max_lanes, n_layouts // max(1, min_layouts_per_lane)))
+
+
+def padded_work(box_counts, max_batch, max_batch_guided, buckets, n_steps=50):
+    """(real, padded) algorithmic TFLOP of ONE LMD+ denoising job over layouts with these box counts, as
+    LMDSampler.denoise_batch packs it (sampler.plan_chunks): stage A = one unguided generation per box, stage B = one
+    guided generation per layout with boxes + one unguided per layout without.  An inert copy that pads a call costs what
+    a real image of that call costs (it rides through the guidance passes of a guided call as well)."""
+    from lgd_amd.sampler import plan_chunks
+    gen = layout_cost(0, n_steps)                      # one unguided generation
+    gen_g = layout_cost(1, n_steps) - gen              # one guided generation (the overall stage of a layout with boxes)
+    real = pad = 0.0
+    for n, cap, cost in ((sum(box_counts), max_batch, gen), (sum(1 for b in box_counts if b), max_batch_guided, gen_g),
+                         (sum(1 for b in box_counts if not b), max_batch, gen)):
+        for count, bucket in plan_chunks(n, cap, buckets):
+            real += count * cost
+            pad += (bucket - count) * cost
+    return real, pad
 
 
 def select_prompts(rows, n):
@@ -139,6 +169,53 @@ def cpu_baseline(cfg, generations, n_steps, beta, iters_on, iters_off):
                         f"{tg_on:.2f}s, fuser off {tg_off:.2f}s; extrapolated to one image = {generations:.2f} generation(s) x "
                         f"({n_on} on + {n_steps - n_on} off) UNet calls + {iters_on:.1f} + {iters_off:.1f} guidance "
                         f"iterations (fuser on + off; VAE excluded)"))
+
+
+class ClockSampler:
+    """Shader clock of this rank's GPU while the timed region runs: the current level of the driver's
+    `pp_dpm_sclk` table (sysfs; a file read every 0.25 s from a host thread that otherwise sleeps), so that a line's
+    TF/s can be read against the clock the chip actually held (the 2.5 PF peak is quoted at 2.4 GHz).  Reports
+    None where the file is absent or has no current-level mark."""
+
+    def __init__(self, index: int, period: float = 0.25):
+        import glob
+        import threading
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.path = cards[index] if index < len(cards) else None
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self._thread = threading.Thread(target=self._run, name="lgd-clock-sampler", daemon=True)
+
+    def read(self):
+        try:
+            for line in open(self.path):
+                if line.rstrip().endswith("*"):
+                    return float(line.split(":")[1].strip().lower().replace("*", "").replace("mhz", "").strip())
+        except Exception:          # noqa: BLE001 - a missing / unreadable file means "not recorded"
+            pass
+        return None
+
+    def _run(self):
+        while not self._stop.wait(self.period):
+            v = self.read()
+            if v is not None:
+                self.samples.append(v)
+
+    def __enter__(self):
+        if self.path:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self.path:
+            self._thread.join(timeout=2)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        xs = self.samples
+        return dict(mean_mhz=round(sum(xs) / len(xs), 1), min_mhz=min(xs), max_mhz=max(xs), samples=len(xs),
+                    source=f"{self.path}, current level every {self.period}s over the timed region")
 
 
 def free_port():
@@ -313,9 +390,13 @@ def main():
                          "(lgd_amd/lanes.py): steps (batch4) or halves of the prompt set (lmd_v0.1) run side by side")
     ap.add_argument("--group", type=int, default=1,
                     help="batch4 / lmd: steps a lane takes AT ONCE (their layouts share UNet calls: --group 2 with --layouts 4 "
-                         "= 16 per-box generations and 8 overall generations per denoising call, chunked by --max-batch*)")
+                         "= 16 per-box generations and 8 overall generations per denoising call, chunked by --max-batch*); "
+                         "0 = auto: the steps split evenly over the lanes, at most --group-max per job")
+    ap.add_argument("--group-max", type=int, default=5, help="--group 0: most steps a lane job may take")
     ap.add_argument("--max-batch", type=int, default=8, help="images per UNet call, unguided generations (LMDSampler.max_batch)")
     ap.add_argument("--max-batch-guided", type=int, default=4, help="images per UNet call, guided generations")
+    ap.add_argument("--min-layouts-per-lane", type=int, default=8,
+                    help="lmd_v0.1: a lane is added per this many layouts of the rank's share (at most --lanes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -379,13 +460,20 @@ def main():
         # the rank's lanes as host threads: the same hand-out as the GPU path (whole steps, or one cost-balanced share
         # of the rank's layouts per lane), each job "running" for a time proportional to its algorithmic cost
         from lgd_amd.lanes import Lane, LanePool
+        from lgd_amd.sampler import LMDSampler
         costs = [layout_cost(l.n_boxes, args.num_inference_steps) for l in lays]
         my_cost = sum(costs)
-        n_lanes = max(1, args.lanes)
+        n_lanes = lanes_for(args.workload, len(lays), max(1, args.lanes), args.min_layouts_per_lane)
         if args.workload == "lmd_v0.1" and n_lanes > 1:
-            jobs = [[costs[j] for j in sh] for sh in partition_by_cost(costs, n_lanes)]
+            shares = partition_by_cost(costs, n_lanes)
         else:
-            jobs = [costs] * max(1, args.steps)
+            shares = [list(range(len(lays)))]
+        jobs = [[costs[j] for j in sh] for sh in shares] if args.workload == "lmd_v0.1" else [costs] * max(1, args.steps)
+        # inert copies that pad UNet calls up to their bucket: work the rank does for nothing
+        rp = [padded_work([lays[j].n_boxes for j in sh] * (max(1, args.group) if args.workload != "lmd_v0.1" else 1),
+                          max(1, args.max_batch), max(1, min(args.max_batch_guided, args.max_batch)), LMDSampler.BUCKETS,
+                          args.num_inference_steps) for sh in shares]
+        my_pad_frac = sum(p for _, p in rp) / max(sum(r + p for r, p in rp), 1e-9)
         lane_cost = [0.0] * n_lanes
 
         def dry(lane, job):
@@ -395,11 +483,14 @@ def main():
             lp.map(dry, jobs)
         dt = ldist.max_over_ranks(time.perf_counter() - t0)
         loads = ldist.gather_floats(float(my_cost))
+        pads = ldist.gather_floats(float(my_pad_frac))
         csum = ldist.sum_over_ranks(float(ws.arena16.float().abs().sum()))
         ldist.shutdown()
         if rank == 0:
             print(json.dumps(dict(metric="dryrun", n_gpus=world, rccl_ranks=world, images=n_total,
                                   weight_broadcast_s=round(bcast_s, 4), per_rank_cost=loads, lanes_per_gpu=n_lanes,
+                                  per_rank_padded_work_frac=[round(p, 4) for p in pads],
+                                  images_per_unet_call=dict(unguided_max=args.max_batch, guided_max=args.max_batch_guided),
                                   rank0_lane_cost=[round(c, 1) for c in lane_cost],
                                   rank0_cpus=pinned, torch_threads=torch.get_num_threads(),
                                   weights_identical=abs(csum / world - float(ws.arena16.float().abs().sum())) < 1e-3,
@@ -444,7 +535,7 @@ def main():
 
     # lanes: independent pipelines on their own HIP streams sharing one copy of the weights; with one lane this is
     # the plain sequential loop on a side stream
-    lanes = make_lanes(eng, max(1, args.lanes), make_sampler)
+    lanes = make_lanes(eng, lanes_for(args.workload, len(lays), max(1, args.lanes), args.min_layouts_per_lane), make_sampler)
     for ln in lanes:
         ln.extras["refiner"] = make_refiner() if args.sam else None
     sm = lanes[0].sampler
@@ -474,17 +565,26 @@ def main():
         step_jobs = [[lays[j] for j in sh] for sh in shares]
     else:
         step_jobs = [lays]
-    group = max(1, args.group) if len(step_jobs) == 1 else 1
+    group = (args.group if args.group >= 0 else 1) if len(step_jobs) == 1 else 1
+
+    def job_sizes(n_steps):
+        """Steps per lane job.  group = g > 0: g consecutive steps per job (the last one takes the rest).  group = 0
+        (auto): the steps are split EVENLY over the lanes in as few rounds as possible with at most --group-max steps per
+        job (20 steps on 2 lanes, at most 5 per job: 4 jobs of 5; 4 steps: 2 jobs of 2), so that no lane idles at the end."""
+        if n_steps <= 0:
+            return []
+        if group == 0:
+            n_lanes = len(lanes)
+            rounds = -(-n_steps // (n_lanes * max(1, args.group_max)))
+            n_jobs = min(n_steps, rounds * n_lanes)
+            return [n_steps // n_jobs + (1 if i < n_steps % n_jobs else 0) for i in range(n_jobs)]
+        return [min(group, n_steps - i) for i in range(0, n_steps, group)]
 
     def jobs_of(n_steps):
-        """The lane jobs of n_steps benchmark steps: the layouts of up to `group` consecutive steps per job."""
-        if group == 1:
+        """The lane jobs of n_steps benchmark steps: the layouts of the steps a job takes at once share its UNet calls."""
+        if len(step_jobs) > 1:
             return step_jobs * n_steps
-        out, left = [], n_steps
-        while left > 0:
-            out.append(lays * min(group, left))
-            left -= min(group, left)
-        return out
+        return [lays * g for g in job_sizes(n_steps)]
 
     # launch plans, GEMM kernel attributes and captured hipGraphs of every batch bucket this rank will use are built
     # BEFORE the timed barrier even with --warmup 0, lane by lane: a 2-step pass over the same layouts has the same
@@ -504,12 +604,14 @@ def main():
         ln.sampler.pass_counts.clear()
     ldist.barrier()
     torch.cuda.synchronize()
+    clock = ClockSampler(local_rank)
     t0 = time.perf_counter()
     it_on = it_all = 0
-    for outs in lane_pool.map(one_step, jobs_of(args.steps)):
-        it_all += sum(o["guidance_iters"] for o in outs)
-        it_on += sum(o["guidance_iters_fuser_on"] for o in outs)
-    torch.cuda.synchronize()
+    with clock:
+        for outs in lane_pool.map(one_step, jobs_of(args.steps)):
+            it_all += sum(o["guidance_iters"] for o in outs)
+            it_on += sum(o["guidance_iters_fuser_on"] for o in outs)
+        torch.cuda.synchronize()
     busy = time.perf_counter() - t0
     ldist.barrier()
     dt = ldist.max_over_ranks(time.perf_counter() - t0)
@@ -540,7 +642,8 @@ def main():
         mains = sorted({nb for (k, f, nb) in counts if k == "main"})
         guides = sorted({nb for (k, f, nb) in counts if k == "guide"})
         for kind, fz, nb_, fn in sm.profile_passes(cfg.sample_size, T, cfg.use_gated_attention, main_batches=mains,
-                                                   guide_batches=guides):
+                                                   guide_batches=guides,
+                                                   ratio_energy=args.workload == "backward_guidance"):
             n_runs = counts.get((kind, fz, nb_), 0)
             if not n_runs:
                 continue
@@ -555,9 +658,10 @@ def main():
             for dst, summ in ((agg, prof.summary()), (tag_agg, prof.summary(by_tag=True)),
                               (shape_agg, prof.summary(by_shape=True) if args.shape_profile else {})):
                 for k, v in summ.items():
-                    a = dst.setdefault(k, dict(ms=0.0, flops=0.0, n=0.0, raw_ms=0.0, raw_n=0))
+                    a = dst.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, n=0.0, raw_ms=0.0, raw_n=0))
                     a["ms"] += v["ms"] * w
                     a["flops"] += v["flops"] * w
+                    a["bytes"] += v["bytes"] * w
                     a["n"] += v["n"] * w
                     a["raw_ms"] += v["ms"]
                     a["raw_n"] += v["n"]
@@ -569,7 +673,9 @@ def main():
                                    tflops=round(v["flops"] / max(v["ms"] * 1e-3, 1e-12) / 1e12, 1))
                            for k, v in sorted(shape_agg.items(), key=lambda kv: -kv[1]["ms"])}, fh, indent=1)
         if agg:
-            name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+            # dominant kernel = the MFMA-bound kernel family with the most time (the HBM-bound ones — norms, copies —
+            # are listed in all_kernels with their GB/s; none of them comes near the GEMM / attention families)
+            name, a = max(((k, v) for k, v in agg.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
             ach = a["flops"] / (a["ms"] * 1e-3)
             # HBM bytes per launch come from a committed PMC summary of THIS command's short form (PMC passes serialise
             # every dispatch: they cannot run inside the timed region) — the source file is named in the record
@@ -588,13 +694,12 @@ def main():
             ap_ = tag_agg.get("attn_path")
             roofline = dict(bound="mfma", kernel=name, achieved=round(ach / 1e12, 2), peak=MFMA_PEAK_F16 / 1e12,
                             unit="TFLOP/s", frac=round(ach / MFMA_PEAK_F16, 4), traffic=traffic,
-                            avg_launch_us=round(a["raw_ms"] * 1e3 / a["raw_n"], 2),
-                            launches_per_image=round(a["n"]), est_ms_per_image=round(a["ms"], 1),
+                            # weighted like est_ms_per_image (each pass by how often the timed region ran it), so that
+                            # avg_launch_us x launches_per_image = est_ms_per_image
+                            avg_launch_us=round(a["ms"] * 1e3 / a["n"], 2),
+                            launches_per_image=round(a["n"], 1), est_ms_per_image=round(a["ms"], 1),
                             traffic_note=traffic_note, traffic_source=traffic_source,
-                            rocprof_summary="profiles/r04b_bench_lanes1_kernel_stats.csv (one launch sequence alone: its "
-                                            "per-launch averages are the ones comparable with avg_launch_us); "
-                                            "profiles/r04b_bench_4lanes_kernel_stats.csv (this command with 4 lanes: "
-                                            "durations of kernels that overlap each other)",
+                            rocprof_summary=ROCPROF_SUMMARY,
                             method="HIP events around each launch, eager replay of the benchmark's plans right after "
                                    "the timed region, ONE launch sequence alone on the GPU (the timed region itself "
                                    "replays hipGraphs, on config.lanes_per_gpu streams side by side — kernels of "
@@ -604,15 +709,27 @@ def main():
                             runner_up=(lambda k2, a2: dict(kernel=k2, achieved=round(a2["flops"] / (a2["ms"] * 1e-3) / 1e12, 2),
                                                           frac=round(a2["flops"] / (a2["ms"] * 1e-3) / MFMA_PEAK_F16, 4),
                                                           est_ms_per_image=round(a2["ms"], 1)))(
-                                *sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[1]) if len(agg) > 1 else None,
+                                *sorted(((k, v) for k, v in agg.items() if v["flops"] > 0), key=lambda kv: -kv[1]["ms"])[1])
+                            if sum(1 for v in agg.values() if v["flops"] > 0) > 1 else None,
                             all_gemm_tflops=round(gemm_tf, 1) if gemm_tf else None,
                             attention_path=(dict(what="q/k/v/out projections + SDPA (self, GLIGEN fuser, cross)",
                                                  ms_per_image=round(ap_["ms"], 1),
                                                  tflops=round(ap_["flops"] / (ap_["ms"] * 1e-3) / 1e12, 1),
                                                  frac_of_mfma_peak=round(ap_["flops"] / (ap_["ms"] * 1e-3) / MFMA_PEAK_F16, 4))
                                             if ap_ else None),
-                            all_kernels={k: dict(ms_per_image=round(v["ms"], 1), launches_per_image=round(v["n"]),
-                                                 tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1))
+                            attention_backward=(lambda b_: dict(what="flash backward (dQ, dK/dV) + cross-attention dQ of the guidance "
+                                                                     "iterations; 10 B H Sq Sk d per self-attention",
+                                                                ms_per_image=round(b_["ms"], 1),
+                                                                tflops=round(b_["flops"] / (b_["ms"] * 1e-3) / 1e12, 1))
+                                                )(tag_agg["attn_path_bwd"]) if tag_agg.get("attn_path_bwd") else None,
+                            # every entry point of a step is profiled (GEMMs incl. their split-K reduction, attention
+                            # forward and backward, norms, energy, update kernels, plan-internal copies): the sum is the
+                            # image's kernel time on one launch sequence
+                            all_kernels_ms_per_image=round(sum(v["ms"] for v in agg.values()), 1),
+                            all_kernels={k: (dict(ms_per_image=round(v["ms"], 1), launches_per_image=round(v["n"]),
+                                                  tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)) if v["flops"] > 0 else
+                                             dict(ms_per_image=round(v["ms"], 1), launches_per_image=round(v["n"]),
+                                                  gb_per_s=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)))
                                          for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])})
     tf = None
     if args.config == "sd14_gligen" and args.workload != "backward_guidance":
@@ -626,7 +743,7 @@ def main():
             f"{n_total} layouts of the lmd_v0.1 cache (0-5 boxes, mean {mean_boxes:.2f}) cost-balanced over {world} rank(s)")
     method = {"backward_guidance": "layout-guidance baseline (generation/backward_guidance.py), ",
               "lmd": "training-free LMD stage 2 (generation/lmd.py defaults: per-box AND overall cross-attention guidance, "
-                     "max_index_step 30, reference-attention transfer, frozen_step_ratio 0.4), "}.get(args.workload, "LMD+ stage 2, ")
+                     "max_index_step 30, reference-attention transfer, frozen_step_ratio 0.5, so_center_box + align_with_overall_bboxes), "}.get(args.workload, "LMD+ stage 2, ")
     arch = {"sd14_gligen": "SD1.4+GLIGEN architecture", "sd21": "SD2.1-768 architecture, v-prediction",
             "sd15": "SD1.5 architecture"}.get(args.config, args.config)
     metric = {"backward_guidance": f"images/sec (50-step SD2.1 {side}^2, backward guidance)",
@@ -647,7 +764,7 @@ def main():
                            # how the step's generations are packed into UNet calls: a lane job = the layouts of
                            # `steps_per_lane_job` steps; their per-box / overall generations are chunked into calls of at
                            # most this many images (CFG batch = 2x), padded to a bucket of LMDSampler.BUCKETS
-                           steps_per_lane_job=group,
+                           steps_per_lane_job=job_sizes(args.steps),
                            images_per_unet_call=dict(unguided_max=lanes[0].sampler.max_batch,
                                                      guided_max=lanes[0].sampler.max_batch_guided,
                                                      timed_region={f"{k_}{'+fuser' if f_ else ''} x{nb_}": n_
@@ -660,6 +777,7 @@ def main():
                            weight_broadcast_s=round(bcast_s, 3), prebuild_s=round(prebuild_s, 2),
                            per_rank_busy_s=[round(b, 3) for b in per_rank_busy],
                            per_rank_idle_s=[round(max(dt - b, 0.0), 3) for b in per_rank_busy],
+                           sustained_gfx_clock=clock.summary(),
                            host=dict(torch_threads=1, rank0_cpu_affinity=(f"{pinned[0]}-{pinned[-1]}" if pinned else "unpinned"))),
                roofline=roofline)
     if tf:

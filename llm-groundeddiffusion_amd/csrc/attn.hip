@@ -16,6 +16,7 @@
 //
 // Map capture (attention_processor.py:440-480): two passes over the keys — pass 1 row max / row sum,
 // pass 2 normalised probabilities, which are written to the fp32 map and fed to the PV product.
+#include <atomic>
 #include "common.h"
 #include "../../include/lgd_hip.h"
 #include "attn_w4.h"
@@ -37,10 +38,18 @@ int attn32_mode() {
   return g_attn32;
 }
 
-int g_attn_w4 = -1;        // round-4 kernel for d = 40 (attn_w4.hip): 1 = default, 0 = never (A/B timing), 2 = for every size (tests)
+// round-4 kernel for d = 40 (attn_w4.hip): 1 = default, 0 = never (A/B timing), 2 = for every size (tests).  Read by
+// every lane thread at launch time: an atomic whose first reader takes LGD_ATTN_W4 once (no torn lazy initialisation)
+std::atomic<int> g_attn_w4{-1};
 int attn_w4_mode() {
-  if (g_attn_w4 < 0) { const char* e = getenv("LGD_ATTN_W4"); g_attn_w4 = e ? atoi(e) : 1; }
-  return g_attn_w4;
+  int v = g_attn_w4.load(std::memory_order_relaxed);
+  if (v < 0) {
+    static const int env = [] { const char* e = getenv("LGD_ATTN_W4"); return e ? atoi(e) : 1; }();
+    int expect = -1;
+    g_attn_w4.compare_exchange_strong(expect, env, std::memory_order_relaxed);
+    v = g_attn_w4.load(std::memory_order_relaxed);
+  }
+  return v;
 }
 
 constexpr int KV_T = 64;         // keys per tile
@@ -1079,7 +1088,7 @@ extern "C" int lgd_set_option(const char* name, int value) {
   if (!name) return LGD_ERR_ARG;
   if (!strcmp(name, "gn_fused") && value >= 0 && value <= 4096) { lgd_gn_set_fused_hw(value); return LGD_OK; }
   if (!strcmp(name, "attn32")) { g_attn32 = value; return LGD_OK; }
-  if (!strcmp(name, "attn_w4") && value >= 0 && value <= 2) { g_attn_w4 = value; return LGD_OK; }
+  if (!strcmp(name, "attn_w4") && value >= 0 && value <= 2) { g_attn_w4.store(value, std::memory_order_relaxed); return LGD_OK; }
   if (!strcmp(name, "attn_w4_pipe") && (value == 0 || value == 1)) { lgd_attn_w4_set_pipe(value); return LGD_OK; }
   if (!strcmp(name, "attn32_nw") && (value == 4 || value == 8)) { g_attn32_nw = value; return LGD_OK; }
   if (!strcmp(name, "attn32_var") && value >= 0 && value <= 2) { g_attn32_var = value; return LGD_OK; }

@@ -24,7 +24,9 @@
 #include "common.h"
 #include "../../include/lgd_hip.h"
 #include "attn_w4.h"
+#include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 #include <utility>
 
@@ -562,11 +564,28 @@ __global__ __launch_bounds__(256, PIPE ? 1 : 2) void attn_w4_kernel(const AttnW4
 
 }  // namespace
 
-static int g_w4_pipe = -1;
-void lgd_attn_w4_set_pipe(int v) { g_w4_pipe = v ? 1 : 0; }
+// lane threads launch concurrently (lanes.py): the option is an atomic whose first reader takes LGD_W4_PIPE once
+static std::atomic<int> g_w4_pipe{-1};
+void lgd_attn_w4_set_pipe(int v) { g_w4_pipe.store(v ? 1 : 0, std::memory_order_relaxed); }
+static int w4_pipe() {
+  int v = g_w4_pipe.load(std::memory_order_relaxed);
+  if (v < 0) {
+    static const int env = [] { const char* e = getenv("LGD_W4_PIPE"); return e ? (atoi(e) ? 1 : 0) : 1; }();
+    int expect = -1;
+    g_w4_pipe.compare_exchange_strong(expect, env, std::memory_order_relaxed);
+    v = g_w4_pipe.load(std::memory_order_relaxed);
+  }
+  return v;
+}
 
 int lgd_attn_w4_supported(const AttnW4Args& a) {
-  return a.d == D && a.Sq >= 1 && a.Sk >= 1 && (a.ldq % 8) == 0 && (a.ldk % 8) == 0 && (a.ldv % 8) == 0 && (a.ldo % 4) == 0;
+  // K / V rows travel by global_load_lds_dwordx4 and Q by 16-byte loads: leading dimensions in units of 8 halves are not
+  // enough, the BASE pointers (and the per-image strides) must be 16-byte aligned too; O leaves as 8-byte half4 stores.
+  // Anything else falls back to the round-3 kernel (attn.hip), which only needs 2-byte alignment.
+  auto al = [](const void* p, uintptr_t n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
+  return a.d == D && a.Sq >= 1 && a.Sk >= 1 && (a.ldq % 8) == 0 && (a.ldk % 8) == 0 && (a.ldv % 8) == 0 && (a.ldo % 4) == 0 &&
+         al(a.q, 16) && al(a.k, 16) && al(a.v, 16) && al(a.o, 8) && (a.q_bs % 8) == 0 && (a.k_bs % 8) == 0 &&
+         (a.v_bs % 8) == 0 && (a.o_bs % 4) == 0;
 }
 
 int lgd_attn_w4_launch(const AttnW4Args& a, hipStream_t st) {
@@ -590,8 +609,7 @@ int lgd_attn_w4_launch(const AttnW4Args& a, hipStream_t st) {
   // variant (lgd_set_option("attn_w4_pipe", v); initial value from LGD_W4_PIPE): 1 = one wave per SIMD with the in-wave
   // software pipeline (default), 0 = two waves per SIMD.  Measured equal within 2 % on MI355X (B = 16: 497 vs 500 us,
   // B = 8: 264 vs 259 us) — both sit at the SUM of their MFMA and softmax-VALU time, see DESIGN.md.
-  if (g_w4_pipe < 0) { const char* e = getenv("LGD_W4_PIPE"); g_w4_pipe = e ? atoi(e) : 1; }
-  if (g_w4_pipe) hipLaunchKernelGGL((attn_w4_kernel<0, true>), grid, dim3(256), 0, st, a);
+  if (w4_pipe()) hipLaunchKernelGGL((attn_w4_kernel<0, true>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((attn_w4_kernel<0, false>), grid, dim3(256), 0, st, a);
   return lgd_check_launch();
 }

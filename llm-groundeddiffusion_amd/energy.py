@@ -176,7 +176,7 @@ class EnergyTables:
         mp, gp, maps, gmaps = self._ptrs
         if with_grad and gmaps is not None:
             for k in self.keys:
-                gmaps[k].zero_()
+                ops.zero_(gmaps[k])
         stride = self.refs[0].numel() if self.refs is not None else 0
         ops.ca_energy(mp, gp if with_grad else None, self.map_hw, self.items, self.coefs, self.masks,
                       self.refs, stride, dyn, self.groups, self.n_groups, self.n_items, self.heads, self.T,

@@ -54,7 +54,6 @@ def workspace(device) -> torch.Tensor:
     return ws
 
 
-COUNTERS = {}             # (device, host thread) -> int32 zeros: split-K arrival counters (left at zero by every launch)
 N_COUNTERS = 1 << 16
 import os as _os
 # In-launch split-K combine ("last arriver reduces", LgdGemmDesc.cnt): implemented, bit-identical, and MEASURED SLOWER on
@@ -65,11 +64,13 @@ SPLITK_IN_LAUNCH = _os.environ.get("LGD_SPLITK_IN_LAUNCH", "0") == "1"
 
 def splitk_counters(device):
     # one buffer per host thread = per lane = per stream: the header allows one counter buffer to serve the GEMMs of ONE
-    # stream only (concurrent launches of one shape on two streams would share ticket slots)
-    key = (torch.device(device), _threading.get_ident())
-    if key not in COUNTERS:
-        COUNTERS[key] = torch.zeros(N_COUNTERS, device=key[0], dtype=torch.int32)
-    return COUNTERS[key]
+    # stream only (concurrent launches of one shape on two streams would share ticket slots).  Thread-local, like the
+    # split-K scratch: the buffer goes away with its lane thread instead of accumulating under dead thread ids
+    dev = torch.device(device)
+    cnt = getattr(_TLS, "cnt", None)
+    if cnt is None or cnt.device != dev:
+        cnt = _TLS.cnt = torch.zeros(N_COUNTERS, device=dev, dtype=torch.int32)
+    return cnt
 
 
 def choose_splits(M, N, K, batches=1):
@@ -118,6 +119,8 @@ def gemm_desc(a0, w, c, M, N, K, *, a1=None, lda0=None, lda1=0, c0=None, c1=0, t
     ent = tuning_table().get(shape_key(d)) if (splits is None or not tile) else None
     if splits is None:
         splits = ent["splits"] if ent else choose_splits(M, N, K, nb_o * nb_i)
+    if ent and not _table_tile_applies(ent["tile"], d, splits, epi, n_out):
+        ent = None                                        # same M/N/K key, but an epilogue form that tile does not have
     if not tile:
         tile = ent["tile"] if (ent and ent["splits"] == splits) else choose_tile(M, N, nb_o * nb_i * max(splits, 1), bool(epi & EPI_GEGLU), K,
                                                                              pipe_ok=(K % 64 == 0 and d.c0 % 64 == 0 and d.c1 % 64 == 0))
@@ -137,6 +140,23 @@ def gemm_desc(a0, w, c, M, N, K, *, a1=None, lda0=None, lda1=0, c0=None, c1=0, t
         if nb_o * nb_i * ((M + 31) // 32) * ((N + 63) // 64) <= N_COUNTERS:
             d.cnt = splitk_counters(c.device).data_ptr()
     return d
+
+
+def _table_tile_applies(tile, d, splits, epi, n_out) -> bool:
+    """The tuning table is keyed by shape_key (M, N, K, gather, GEGLU flag), not by the whole epilogue form.  The two-stage
+    ring tiles of round 4 take plain single-source contractions only, and the 256 x 256 one (44) leaves through the LDS
+    epilogue alone: one split, fp16 rows of N % 8 = 0 with an 8-aligned leading dimension and a 16-byte aligned base, no
+    fp32 output / residual, not GEGLU together with a residual (launch_gemm_pipe returns LGD_ERR_ARG otherwise).  A caller
+    with the same M/N/K but such an epilogue must get the heuristic tile, not a RuntimeError."""
+    if tile not in (44, 45):
+        return True
+    if d.taps != 1 or d.c1 != 0:
+        return False
+    if tile == 45:
+        return True
+    if splits != 1 or (epi & (EPI_OUT_F32 | EPI_RES_F32)) or ((epi & EPI_GEGLU) and d.res):
+        return False
+    return n_out % 8 == 0 and d.ldc % 8 == 0 and d.c % 16 == 0
 
 
 _TILE_DIMS = {1: (4, 4), 2: (4, 2), 3: (2, 4), 4: (2, 2), 5: (1, 4), 6: (4, 5), 7: (2, 5)}
@@ -194,7 +214,10 @@ _TUNING = {}
 # 4 streams at once, tools/tune_gemm.py LGD_TUNE_STREAMS=4): fewer split-K slabs, larger tiles — a launch may leave CUs
 # idle, another lane fills them.  Plans read the table when they are BUILT.
 TUNING_MODE = _os.environ.get("LGD_TUNING_MODE", "latency")
-_TUNING_FILES = {"latency": ("tuning_gfx950.json",), "throughput": ("tuning_gfx950.json", "tuning_gfx950_lanes.json")}
+# "heuristic": no table at all — choose_tile / choose_splits for every shape: a launch configuration that does not move
+# when the tables are re-tuned (the pinned reference point of the full-width gradient gate, tests/test_bench_path_gpu.py)
+_TUNING_FILES = {"latency": ("tuning_gfx950.json",), "throughput": ("tuning_gfx950.json", "tuning_gfx950_lanes.json"),
+                 "heuristic": ()}
 _TUNING_TLS = _threading.local()
 
 
@@ -292,6 +315,26 @@ class LaunchProfiler:
 PROFILER = None
 
 
+def _prof(name, nbytes, fn, *, flops=0.0, tag=None, shape=None):
+    """Runs `fn` (one kernel launch, or the few launches of one C-ABI entry point); under a LaunchProfiler the launch is
+    bracketed by HIP events and booked under `name` with its ALGORITHMIC bytes / flops.  Every entry point a UNet plan
+    or a sampler step enqueues goes through here or through gemm_launch / attn_fwd, so that the profiler's kernels sum
+    to the launch sequence's time (bench.py `roofline.all_kernels`)."""
+    if PROFILER is not None:
+        return PROFILER.wrap(name, flops, nbytes, fn, tag, shape)
+    return fn()
+
+
+def copy_(dst, src):
+    """dst.copy_(src) on the current stream, visible to the launch profiler (plan-internal copies: CFG duplication of the
+    latents, first-writer gradient copies of residual branches, captured-map slices)."""
+    return _prof("copy", 2.0 * dst.numel() * dst.element_size(), lambda: dst.copy_(src))
+
+
+def zero_(t):
+    return _prof("fill", float(t.numel() * t.element_size()), lambda: t.zero_())
+
+
 def gemm_launch(desc, tag=None, flops=None):
     """`flops`: algorithmic work when it differs from 2*M*N*K of the launch (conv_in multiplies a zero / remainder-padded K)."""
     if PROFILER is not None:
@@ -364,7 +407,8 @@ def nchw_to_nhwc8(x_nchw, out=None):
     B, C_, H, W = x_nchw.shape
     if out is None:
         out = torch.empty((B * H * W, 8), device=x_nchw.device, dtype=F16)
-    _call("lgd_nchw_to_nhwc8_f16", _p(x_nchw), _p(out), B, C_, H * W, _stream())
+    _prof("nchw_to_nhwc8_kernel", 4.0 * x_nchw.numel() + 2.0 * out.numel(),
+          lambda: _call("lgd_nchw_to_nhwc8_f16", _p(x_nchw), _p(out), B, C_, H * W, _stream()))
     return out
 
 
@@ -373,8 +417,9 @@ def conv_out(x, w, bias, B, L, out=None, out_scale=1.0):
     Cout = w.shape[0]
     if out is None:
         out = torch.empty((B, Cout, L, L), device=x.device, dtype=F32)
-    _call("lgd_conv_out_f16", _p(x), _p(w), _p(bias), _p(out), B, Cin, L, Cout, float(out_scale),
-          _stream())
+    _prof("conv_out_kernel", 2.0 * x.numel() + 4.0 * out.numel(),
+          lambda: _call("lgd_conv_out_f16", _p(x), _p(w), _p(bias), _p(out), B, Cin, L, Cout, float(out_scale), _stream()),
+          flops=2.0 * B * L * L * Cout * 9 * Cin)
     return out
 
 
@@ -396,8 +441,10 @@ def groupnorm(x, B, HW, G, eps, gamma, beta, silu, *, x1=None, out=None, part=No
         out = torch.empty((B * HW, C_), device=x.device, dtype=F16)
     if part is None:
         part = torch.empty((B, nchunk, G, 2), device=x.device, dtype=F32)
-    _call("lgd_groupnorm_f16", _p(x), _p(x1), c0, c1, B, HW, G, float(eps), _p(gamma), _p(beta),
-          1 if silu else 0, _p(out), _p(part), nchunk, _p(stats), _stream())
+    # algorithmic bytes: the map read once for the statistics, once for the apply, written once
+    _prof("groupnorm (gn_stats + gn_apply | gn_fused)", 6.0 * B * HW * C_,
+          lambda: _call("lgd_groupnorm_f16", _p(x), _p(x1), c0, c1, B, HW, G, float(eps), _p(gamma), _p(beta),
+                        1 if silu else 0, _p(out), _p(part), nchunk, _p(stats), _stream()), shape=f"B{B}_HW{HW}_C{C_}")
     return out
 
 
@@ -412,9 +459,10 @@ def groupnorm_bwd(gy, x, B, HW, G, gamma, beta, silu, stats, *, x1=None, gx0=Non
         gx1 = torch.empty_like(x1)
     if part is None:
         part = torch.empty((B, nchunk, G, 2), device=x.device, dtype=F32)
-    _call("lgd_groupnorm_bwd_f16", _p(gy), _p(x), _p(x1), c0, c1, B, HW, G, _p(gamma), _p(beta),
-          1 if silu else 0, _p(stats), _p(gx0), _p(gx1), _p(part), nchunk, 1 if accumulate else 0,
-          _stream())
+    _prof("groupnorm_bwd (gn_bwd_stats + gn_bwd_apply)", (10.0 + (2.0 if accumulate else 0.0)) * B * HW * (c0 + c1),
+          lambda: _call("lgd_groupnorm_bwd_f16", _p(gy), _p(x), _p(x1), c0, c1, B, HW, G, _p(gamma), _p(beta),
+                        1 if silu else 0, _p(stats), _p(gx0), _p(gx1), _p(part), nchunk, 1 if accumulate else 0, _stream()),
+          shape=f"B{B}_HW{HW}_C{c0 + c1}")
     return gx0, gx1
 
 
@@ -425,8 +473,9 @@ def layernorm(x, gamma, beta, eps=1e-5, *, out=None, ldy=None, stats=None, rows_
         rows = x.numel() // C_
     if out is None:
         out = torch.empty((rows, C_), device=x.device, dtype=F16)
-    _call("lgd_layernorm_f16", _p(x), ldx or C_, _p(out), ldy or C_, rows, C_, float(eps), _p(gamma),
-          _p(beta), _p(stats), rows_per_batch, x_bs, y_bs, _stream())
+    _prof("layernorm_rows_kernel", 4.0 * rows * C_,
+          lambda: _call("lgd_layernorm_f16", _p(x), ldx or C_, _p(out), ldy or C_, rows, C_, float(eps), _p(gamma),
+                        _p(beta), _p(stats), rows_per_batch, x_bs, y_bs, _stream()), shape=f"R{rows}_C{C_}")
     return out
 
 
@@ -437,8 +486,9 @@ def layernorm_stats(x, C_, eps=1e-5, *, stats=None, rows=None, ldx=None):
         rows = x.numel() // C_
     if stats is None:
         stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
-    _call("lgd_layernorm_f16", _p(x), ldx or C_, _p(None), C_, rows, C_, float(eps), _p(None), _p(None), _p(stats),
-          0, 0, 0, _stream())
+    _prof("layernorm_rows_kernel (statistics only)", 2.0 * rows * C_,
+          lambda: _call("lgd_layernorm_f16", _p(x), ldx or C_, _p(None), C_, rows, C_, float(eps), _p(None), _p(None),
+                        _p(stats), 0, 0, 0, _stream()), shape=f"R{rows}_C{C_}")
     return stats
 
 
@@ -449,8 +499,10 @@ def layernorm_bwd(gy, x, gamma, stats, *, gx=None, rows=None, ldgy=None, ldx=Non
         rows = x.numel() // C_
     if gx is None:
         gx = torch.empty((rows, C_), device=x.device, dtype=F16)
-    _call("lgd_layernorm_bwd_f16", _p(gy), ldgy or C_, _p(x), ldx or C_, _p(gx), ldgx or C_, rows, C_,
-          _p(gamma), _p(stats), rows_per_batch, gy_bs, x_bs, gx_bs, 1 if accumulate else 0, _stream())
+    _prof("layernorm_bwd_kernel", (6.0 + (2.0 if accumulate else 0.0)) * rows * C_,
+          lambda: _call("lgd_layernorm_bwd_f16", _p(gy), ldgy or C_, _p(x), ldx or C_, _p(gx), ldgx or C_, rows, C_,
+                        _p(gamma), _p(stats), rows_per_batch, gy_bs, x_bs, gx_bs, 1 if accumulate else 0, _stream()),
+          shape=f"R{rows}_C{C_}")
     return gx
 
 
@@ -481,9 +533,13 @@ def attn_bwd(q, k, v, o, go, lse, delta, gq, gk, gv, B, H, Sq, Sk, d, scale, *, 
     qv, kv, vv = q_view or dq_, k_view or dk_, v_view or dk_
     ov, gov = o_view or dq_, go_view or dq_
     gqv, gkv, gvv = gq_view or dq_, gk_view or dk_, gv_view or dk_
-    _call("lgd_attn_bwd_f16", _p(q), qv[0], qv[1], _p(k), kv[0], kv[1], _p(v), vv[0], vv[1], _p(o),
-          ov[0], ov[1], _p(go), gov[0], gov[1], _p(lse), _p(delta), _p(gq), gqv[0], gqv[1], _p(gk),
-          gkv[0], gkv[1], _p(gv), gvv[0], gvv[1], B, H, Sq, Sk, d, float(scale), _stream())
+    # flash backward with recompute: QK^T twice (dQ and dK/dV passes), dP = dO V^T twice, dV, dK, dQ -> 14 B H Sq Sk d
+    # executed; the ALGORITHMIC work of an attention backward is 5 contractions = 10 B H Sq Sk d (DESIGN.md kernel table)
+    _prof(f"attn_bwd_dq + attn_bwd_dkv d={d}", 2.0 * B * H * d * (4 * Sq + 4 * Sk),
+          lambda: _call("lgd_attn_bwd_f16", _p(q), qv[0], qv[1], _p(k), kv[0], kv[1], _p(v), vv[0], vv[1], _p(o),
+                        ov[0], ov[1], _p(go), gov[0], gov[1], _p(lse), _p(delta), _p(gq), gqv[0], gqv[1], _p(gk),
+                        gkv[0], gkv[1], _p(gv), gvv[0], gvv[1], B, H, Sq, Sk, d, float(scale), _stream()),
+          flops=10.0 * B * H * Sq * Sk * d, tag="attn_path_bwd", shape=f"B{B}_H{H}_Sq{Sq}_Sk{Sk}")
 
 
 def cross_attn_fwd(q, k, v, o, B, H, Sq, Sk, d, scale, *, probs=None, tok=-1, cond_only=False,
@@ -552,9 +608,11 @@ def cross_attn_bwd(q, k, v, go, gp, gq, B, H, Sq, Sk, d, scale, *, q_view=None, 
     dk_ = (H * d, Sk * H * d)
     qv, kv, vv = q_view or dq_, k_view or dk_, v_view or dk_
     gov, gqv = go_view or dq_, gq_view or dq_
-    _call("lgd_cross_attn_bwd_f16", _p(q), qv[0], qv[1], _p(k), kv[0], kv[1], _p(v), vv[0], vv[1],
-          _p(go), gov[0], gov[1], _p(gp), _p(gq), gqv[0], gqv[1], B, H, Sq, Sk, d, float(scale),
-          _stream())
+    # dQ only (text K / V are constants of the run): recomputed scores, dP = dO V^T (+ the map gradient), dQ = dS K
+    _prof(f"cross_attn_bwd_mfma_kernel d={d}", 2.0 * B * H * d * (3 * Sq + 2 * Sk) + (4.0 * B * H * Sq * Sk if gp is not None else 0.0),
+          lambda: _call("lgd_cross_attn_bwd_f16", _p(q), qv[0], qv[1], _p(k), kv[0], kv[1], _p(v), vv[0], vv[1],
+                        _p(go), gov[0], gov[1], _p(gp), _p(gq), gqv[0], gqv[1], B, H, Sq, Sk, d, float(scale), _stream()),
+          flops=(6.0 if go is not None else 4.0) * B * H * Sq * Sk * d, tag="attn_path_bwd")
     return gq
 
 
@@ -565,7 +623,8 @@ def geglu_bwd(h, gy, gh=None):
     rows, n2 = h.shape
     if gh is None:
         gh = torch.empty_like(h)
-    _call("lgd_geglu_bwd_f16", _p(h), _p(gy), _p(gh), rows, n2 // 2, _stream())
+    _prof("geglu_bwd_kernel", 2.0 * rows * (n2 + n2 // 2 + n2),
+          lambda: _call("lgd_geglu_bwd_f16", _p(h), _p(gy), _p(gh), rows, n2 // 2, _stream()))
     return gh
 
 
@@ -573,7 +632,8 @@ def geglu_fwd(h, out=None):
     rows, n2 = h.shape
     if out is None:
         out = torch.empty((rows, n2 // 2), device=h.device, dtype=F16)
-    _call("lgd_geglu_fwd_f16", _p(h), _p(out), rows, n2 // 2, _stream())
+    _prof("geglu_fwd_kernel", 2.0 * rows * (n2 + n2 // 2),
+          lambda: _call("lgd_geglu_fwd_f16", _p(h), _p(out), rows, n2 // 2, _stream()))
     return out
 
 
@@ -588,7 +648,7 @@ def softmax_rows(x, scale=1.0, out=None):
 def add(a, b, out=None):
     if out is None:
         out = torch.empty_like(a)
-    _call("lgd_add_f16", _p(a), _p(b), _p(out), a.numel(), _stream())
+    _prof("add_kernel", 6.0 * a.numel(), lambda: _call("lgd_add_f16", _p(a), _p(b), _p(out), a.numel(), _stream()))
     return out
 
 
@@ -602,15 +662,17 @@ def scale(x, alpha, out=None):
 def upsample2x_bwd(gy, B, H, W, C_, out=None):
     if out is None:
         out = torch.empty((B * H * W, C_), device=gy.device, dtype=F16)
-    _call("lgd_upsample2x_bwd_f16", _p(gy), _p(out), B, H, W, C_, _stream())
+    _prof("upsample2x_bwd_kernel", 2.0 * 5 * B * H * W * C_,
+          lambda: _call("lgd_upsample2x_bwd_f16", _p(gy), _p(out), B, H, W, C_, _stream()))
     return out
 
 
 def cfg_ddim_step(eps, x, x_out, coef_table, dyn, *, frozen_ref=None, mask=None, hist=None):
     """dyn: device int32[2] = {step, frozen_steps}."""
     B, C_, L, _ = x.shape
-    _call("lgd_cfg_ddim_step_f32", _p(eps), _p(x), _p(x_out), _p(coef_table), _p(dyn),
-          _p(frozen_ref), _p(mask), _p(hist), B, C_, L * L, _stream())
+    _prof("cfg_ddim_kernel", 4.0 * x.numel() * 6,
+          lambda: _call("lgd_cfg_ddim_step_f32", _p(eps), _p(x), _p(x_out), _p(coef_table), _p(dyn),
+                        _p(frozen_ref), _p(mask), _p(hist), B, C_, L * L, _stream()))
     return x_out
 
 
@@ -624,8 +686,9 @@ def cfg_multistep_step(eps, x, x_out, x0_prev, coef_table, dyn, *, frozen_ref=No
 
 def axpy(g, x, coef_table, step_idx, col, active=None):
     per = x.numel() // x.shape[0] if active is not None else 0
-    _call("lgd_axpy_f32", _p(g), _p(x), _p(coef_table), _p(step_idx), int(col), _p(active), per, x.numel(),
-          _stream())
+    _prof("axpy_kernel", 12.0 * x.numel(),
+          lambda: _call("lgd_axpy_f32", _p(g), _p(x), _p(coef_table), _p(step_idx), int(col), _p(active), per, x.numel(),
+                        _stream()))
 
 
 def scale_rows(x, out, table, dyn, col, reps=1):
@@ -636,11 +699,13 @@ def scale_rows(x, out, table, dyn, col, reps=1):
 
 
 def select_row(table, idx, out):
-    _call("lgd_select_row_f32", _p(table), _p(idx), _p(out), out.numel(), _stream())
+    _prof("select_row_kernel", 8.0 * out.numel(),
+          lambda: _call("lgd_select_row_f32", _p(table), _p(idx), _p(out), out.numel(), _stream()))
 
 
 def ca_energy(map_ptrs, gmap_ptrs, map_hw, items, coefs, masks, refs, refs_step_stride, dyn, groups, n_groups,
               n_items, H, T, max_hw, partial, loss, grad_scale=1.0, n_samples=1):
-    _call("lgd_ca_energy_f32", _p(map_ptrs), _p(gmap_ptrs), _p(map_hw), _p(items), _p(coefs),
-          _p(masks), _p(refs), int(refs_step_stride), _p(dyn), _p(groups), n_groups, n_items, n_samples, H, T,
-          max_hw, float(grad_scale), _p(partial), _p(loss), _stream())
+    _prof("ca_energy_kernel + energy_sum_kernel", 4.0 * n_groups * H * max_hw * 2,
+          lambda: _call("lgd_ca_energy_f32", _p(map_ptrs), _p(gmap_ptrs), _p(map_hw), _p(items), _p(coefs),
+                        _p(masks), _p(refs), int(refs_step_stride), _p(dyn), _p(groups), n_groups, n_items, n_samples, H, T,
+                        max_hw, float(grad_scale), _p(partial), _p(loss), _stream()))

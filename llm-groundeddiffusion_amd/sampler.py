@@ -107,6 +107,27 @@ class _State:
         self.graphs = {}
 
 
+def plan_chunks(n: int, cap: int, buckets: Sequence[int], max_pad: float = 0.25) -> List[Tuple[int, int]]:
+    """How `n` independent images are packed into UNet calls: a list of (images, bucket) with bucket >= images, bucket in
+    `buckets`, bucket <= cap.  A call is padded up to its bucket with inert copies (so that only a handful of launch
+    plans, captured graphs and tuned GEMM shapes exist), but only while the padding stays within `max_pad` of the call;
+    otherwise the largest bucket that FITS is split off and the remainder is planned again: 5 -> 4 + 1 (0 padded)
+    instead of 8 (3 padded), 11 -> 8 + 3(+1), 7 -> 8.  Pure function: the CPU dry run of bench.py prices a rank's padded
+    work with it."""
+    bs = sorted(b for b in buckets if b <= max(cap, 1)) or [1]
+    out: List[Tuple[int, int]] = []
+    left = int(n)
+    while left > 0:
+        up = next((b for b in bs if b >= left), None)
+        if up is not None and (up - left) <= max_pad * up:
+            out.append((left, up))
+            break
+        down = max(b for b in bs if b <= left)
+        out.append((down, down))
+        left -= down
+    return out
+
+
 class Job:
     """One image of a batched denoising call."""
 
@@ -122,8 +143,9 @@ class LMDSampler:
                  grad_scale: float = 1024.0, use_graphs: bool = True, max_batch: int = 8,
                  max_batch_guided: int = 4):
         """max_batch / max_batch_guided: images per UNet call for unguided / guided denoising calls; longer
-        job lists are chunked, and every chunk is padded to the next size in BUCKETS so that only a handful
-        of launch plans, captured graphs and (tuned) GEMM shapes ever exist."""
+        job lists are chunked (`plan_chunks`), and a chunk is padded to the next size in BUCKETS — by at most
+        `max_pad` of the call, else it is split — so that only a handful of launch plans, captured graphs and
+        (tuned) GEMM shapes ever exist."""
         self.max_batch = max(1, min(int(max_batch), engine.max_text_batch // 2))
         self.max_batch_guided = max(1, min(int(max_batch_guided), self.max_batch))
         self.eng = engine
@@ -132,7 +154,8 @@ class LMDSampler:
         self.vae = vae
         self.grad_scale = grad_scale
         self.use_graphs = use_graphs
-        self.stats = dict(unet_main=0, guidance_iters=0)
+        self.max_pad = 0.25          # plan_chunks: a call is padded by at most this fraction of its bucket
+        self.stats = dict(unet_main=0, guidance_iters=0, images=0, padded_images=0)
         self.pass_counts: Dict[Tuple, int] = {}      # (kind, fuser on?, images) -> launches of that plan
         self._states = {}
 
@@ -280,24 +303,49 @@ class LMDSampler:
         return st.lat.clone(), (gs.loss if gs is not None else None), gs
 
     # ------------------------------------------------------------------------------------------
-    def profile_passes(self, L: int, T: int, gligen: bool, main_batches=(1,), guide_batches=(1,), guidance_keys=None):
+    def profile_passes(self, L: int, T: int, gligen: bool, main_batches=(1,), guide_batches=(1,), guidance_keys=None,
+                       ratio_energy: bool = False):
         """Eager (non-graph) launch sequences of the plans the sampler replays, for per-kernel HIP-event
-        timing by bench.py: [(kind, fuser, images, callable)].  Uses whatever run constants are loaded."""
+        timing by bench.py: [(kind, fuser, images, callable)].  Uses whatever run constants are loaded.
+        ratio_energy: the layout-guidance baseline's energy (ratio branch, no reference maps) instead of LMD / LMD+'s."""
         eng = self.eng
         keys = [tuple(k) for k in (guidance_keys or DEFAULT_GUIDANCE_ATTN_KEYS)]
         plan_keys = sorted({OBJ_KEY_DEFAULT, *DEFAULT_GUIDANCE_ATTN_KEYS})
         out = []
         for f in ([True, False] if gligen else [False]):
             for nb in main_batches:
-                out.append(("main", f, nb, eng.plan(2 * nb, L, fuser=f, save_keys=plan_keys).forward))
+                plan = eng.plan(2 * nb, L, fuser=f, save_keys=plan_keys)
+                st_m = self._state(nb, eng.cfg.in_channels, L, T)
+
+                def main(plan=plan, st=st_m, nb=nb):                       # as _denoise_chunk's main_fn
+                    ops.copy_(plan.latents_in[:nb], st.lat)
+                    ops.copy_(plan.latents_in[nb:], st.lat)
+                    plan.forward()
+                    ops.cfg_ddim_step(plan.eps_out, st.lat, st.lat, st.ctab, eng.dyn, frozen_ref=st.frozen_ref,
+                                      mask=st.mask, hist=st.hist)
+                out.append(("main", f, nb, main))
             for nb in guide_batches:
                 st = self._state(nb, eng.cfg.in_channels, L, T)
                 pg = eng.plan(nb, L, grad=True, fuser=f, stop_key=eng.last_key(keys), save_keys=keys,
                               text_batch_offset=nb)
 
-                def guide(pg=pg, st=st):
+                # the energy launch between the two halves: a canonical two-box layout per image (its cost depends on
+                # the item count only, 2 boxes x 3 tokens x 4 keys + reference terms, not on the boxes)
+                boxes = [[0.15, 0.35, 0.5, 0.8], [0.6, 0.38, 0.98, 0.8]]
+                refs = None if ratio_energy else torch.full((T, 2, len(keys), self.heads_of(keys[0]),
+                                                             max(self.map_hw(L)[k] for k in keys)), 1e-3, device=self.dev)
+                en = [self.make_guidance(L, [[b] for b in boxes], [[1, 2, 3], [5, 6, 7]], guidance_attn_keys=keys,
+                                         use_ratio_based_loss=ratio_energy, word_token_indices=[3, 7],
+                                         ref_ca_word_token_only=True, ref_maps=refs, max_index_step=1).energy
+                      for _ in range(nb)]
+                energy = en[0] if nb == 1 else EnergyTables.merged(en)
+                energy.bind(pg.maps, pg.gmaps)
+
+                def guide(pg=pg, st=st, energy=energy):
                     pg.forward(st.lat)
+                    energy.run(eng.dyn, grad_scale=self.grad_scale)
                     pg.backward(self.grad_scale)
+                    ops.axpy(pg.g_latents, st.lat, st.gtab, eng.dyn, 0, active=st.active)
                 out.append(("guide", f, nb, guide))
         return out
 
@@ -316,13 +364,16 @@ class LMDSampler:
         out: List[Optional[dict]] = [None] * len(jobs)
         for guided, cap in ((True, self.max_batch_guided), (False, self.max_batch)):
             idx = [i for i, j in enumerate(jobs) if (j.guidance is not None) == guided]
-            for c0 in range(0, len(idx), cap):
-                part = idx[c0:c0 + cap]
+            c0 = 0
+            for count, nb in plan_chunks(len(idx), cap, self.BUCKETS, self.max_pad):
+                part = idx[c0:c0 + count]
+                c0 += count
                 chunk = [jobs[i] for i in part]
-                nb = next((b for b in self.BUCKETS if b >= len(chunk)), len(chunk))
                 last = chunk[-1]
                 pad = [Job(last.latents, last.text, last.gligen, None, last.frozen_mask, last.token)
-                       for _ in range(min(nb, cap) - len(chunk))]
+                       for _ in range(nb - len(chunk))]
+                self.stats["images"] += len(chunk)
+                self.stats["padded_images"] += len(pad)
                 res = self._denoise_chunk(chunk + pad, num_inference_steps, **kw)
                 for i, r in zip(part, res):
                     out[i] = r
@@ -409,8 +460,8 @@ class LMDSampler:
             plan = plans_main[f] = eng.plan(2 * nb, L, fuser=f, save_keys=plan_keys)
 
             def main_fn(plan=plan):
-                plan.latents_in[:nb].copy_(st.lat)                           # torch.cat([latents]*2)
-                plan.latents_in[nb:].copy_(st.lat)
+                ops.copy_(plan.latents_in[:nb], st.lat)                      # torch.cat([latents]*2)
+                ops.copy_(plan.latents_in[nb:], st.lat)
                 plan.forward()
                 if multistep:
                     ops.cfg_multistep_step(plan.eps_out, st.lat, st.lat, st.x0_prev, st.mtab, eng.dyn,

@@ -46,12 +46,16 @@ class Act:
 
 
 class Op:
-    def __init__(self, fwd, make_bwd=None, gouts=()):
+    def __init__(self, fwd, make_bwd=None, gouts=(), passthrough=None):
         self.fwd = fwd
         self.make_bwd = make_bwd    # (acc flags for gouts) -> callable
         self.gouts = list(gouts)    # Acts whose .g this op's backward writes, in write order
         self.acc = None
         self.bwd = None
+        # (res, y): this op computes y = f(x) + res, so d/d res = d/d y unchanged.  When this op is the FIRST writer of
+        # res.g, res.g simply IS y.g's buffer (Plan._finalize_backward) instead of a copy of it: y.g is complete when this
+        # op's backward runs and is never read after it, so later accumulations into it are safe
+        self.passthrough = passthrough
 
 
 choose_splits = ops.choose_splits
@@ -98,8 +102,9 @@ class Plan:
     def _act(self, rows, C):
         return Act(self._new(rows, C))
 
-    def _add(self, fwd, make_bwd=None, gouts=()):
-        self.ops.append(Op(fwd, make_bwd if self.grad else None, gouts if self.grad else ()))
+    def _add(self, fwd, make_bwd=None, gouts=(), passthrough=None):
+        self.ops.append(Op(fwd, make_bwd if self.grad else None, gouts if self.grad else (),
+                           passthrough if self.grad else None))
 
     def _ws(self, n_floats):
         return self.eng.workspace(n_floats)
@@ -133,15 +138,16 @@ class Plan:
             if res is None:
                 return lambda: ops.gemm_launch(dd)
             racc = acc[1]
+            aliased = res.g.data_ptr() == y.g.data_ptr()
 
             def run():
                 ops.gemm_launch(dd)
                 if racc:
                     ops.add(res.g, y.g, res.g)
-                else:
-                    res.g.copy_(y.g)
+                elif not aliased:
+                    ops.copy_(res.g, y.g)
             return run
-        self._add(fwd, make_bwd, gouts)
+        self._add(fwd, make_bwd, gouts, passthrough=(res, y) if res is not None else None)
         return y
 
     def conv(self, x: Act, name: str, H: int, *, x1: Optional[Act] = None, res: Optional[Act] = None,
@@ -207,9 +213,12 @@ class Plan:
                 runs.append(lambda: (ops.gemm_launch(dd), ops.upsample2x_bwd(tmp, B, H, H, c0, out=x.g)))
             if res is not None:
                 racc = acc[-1]
-                runs.append((lambda: ops.add(res.g, y.g, res.g)) if racc else (lambda: res.g.copy_(y.g)))
+                if racc:
+                    runs.append(lambda: ops.add(res.g, y.g, res.g))
+                elif res.g.data_ptr() != y.g.data_ptr():
+                    runs.append(lambda: ops.copy_(res.g, y.g))
             return lambda: [r() for r in runs]
-        self._add(fwd, make_bwd, gouts)
+        self._add(fwd, make_bwd, gouts, passthrough=(res, y) if res is not None else None)
         return y
 
     def shortcut(self, x: Act, x1: Optional[Act], name: str) -> Act:
@@ -295,7 +304,9 @@ class Plan:
         LGD_EPI_ROWNORM).  Grad plans keep the two ops: the backward needs the LayerNorm's own node."""
         eng = self.eng
         has_b = f"{name}.b" in eng.w.f
-        if self.grad or not eng.fold_ln:
+        # the statistics-only form of lgd_layernorm_f16 (y = NULL) exists in the row kernels only: widths up to 1536
+        # (every SD 1.x / 2.x / SDXL-refiner transformer); wider rows keep the two ops
+        if self.grad or not eng.fold_ln or x.C > 1536:
             y = self.layernorm(x, norm)
             if geglu:
                 return self.linear(y, name, geglu=True)
@@ -344,7 +355,7 @@ class Plan:
 
             def run():
                 if pad:
-                    gq_tail.zero_()
+                    ops.zero_(gq_tail)
                 ops.attn_bwd(qt, kt, vt, o.t, o.g, lse, delta, gq, gk, gv, B, heads, S, Sk, d, scale,
                              q_view=view, k_view=view, v_view=view, gq_view=view, gk_view=view, gv_view=view)
             return run
@@ -531,7 +542,12 @@ class Plan:
             op.acc = []
             for a in op.gouts:
                 if a.g is None:
-                    a.g = self._alloc(tuple(a.t.shape), a.t.dtype)   # first writer overwrites (acc flags below)
+                    pt = op.passthrough
+                    if pt is not None and a is pt[0] and pt[1].g is not None and pt[1].g.shape == a.t.shape \
+                            and os.environ.get("LGD_RES_GRAD_ALIAS", "1") != "0":
+                        a.g = pt[1].g                                # first writer of a pass-through gradient: no copy
+                    else:
+                        a.g = self._alloc(tuple(a.t.shape), a.t.dtype)   # first writer overwrites (acc flags below)
                 op.acc.append(id(a) in seen)
                 seen.add(id(a))
         # every consumed activation now owns a .g, so the closures can bind output gradients
@@ -584,8 +600,9 @@ class UNetEngine:
             if weights.cfg != cfg or torch.device(weights.device) != self.device or state_dict is not None:
                 raise ValueError("shared weights must come from an engine of the same configuration and device")
             self.w = weights
+            self.fold_ln = self.fold_ln and getattr(weights, "fold_ln", True)   # a store without the folded twins
         else:
-            self.w = WeightStore(cfg, self.device)
+            self.w = WeightStore(cfg, self.device, fold_ln=self.fold_ln)
             if state_dict is not None:
                 self.w.load_state_dict(state_dict)
         self.text_len = text_len

@@ -49,7 +49,12 @@ def pack_conv_dgrad(w: torch.Tensor) -> torch.Tensor:
 
 
 class WeightStore:
-    def __init__(self, cfg: UNetConfig, device):
+    def __init__(self, cfg: UNetConfig, device, fold_ln: bool = True):
+        """fold_ln: also lay out (and fill) the LayerNorm-folded twins of the linears behind a LayerNorm (`_lnlin`: 12 of
+        a transformer block's 20 linear weights a second time, 0.5 GB for SD1.4+GLIGEN, ~1 GB for the SDXL refiner) —
+        the no-grad plans of an engine with `fold_ln` read them; an engine built with LGD_FOLD_LN=0 neither stores nor
+        broadcasts them."""
+        self.fold_ln = bool(fold_ln)
         if cfg.in_channels > 4:
             raise ValueError(f"in_channels = {cfg.in_channels}: conv_in runs as an implicit GEMM over an 8-channel copy of the "
                              "latents (value + fp16 rounding remainder of <= 4 channels); inpainting UNets are not supported")
@@ -104,6 +109,8 @@ class WeightStore:
     def _lnlin(self, name, n, k):
         """The LayerNorm-folded twin of a linear layer whose input is a LayerNorm (no-grad plans; LGD_EPI_ROWNORM in
         include/lgd_hip.h): wln = W * gamma per input channel, cs = row sums of wln AS STORED (fp16), bln = b + W beta."""
+        if not self.fold_ln:
+            return
         self._e16(f"{name}.wln", (n, k))
         self._e32(f"{name}.cs", (n,))
         self._e32(f"{name}.bln", (n,))
@@ -223,6 +230,8 @@ class WeightStore:
 
         def fold(dst, norm):
             # after lin()/geglu(): the rows are already in kernel order, the fold runs along K
+            if not self.fold_ln:
+                return
             w = h16[f"{dst}.w"].to(F16).float()                      # the values the unfolded GEMM multiplies by
             g, bt = sd[f"{norm}.weight"].float(), sd[f"{norm}.bias"].float()
             wln = (w * g[None, :]).to(F16)

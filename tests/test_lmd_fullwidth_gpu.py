@@ -120,8 +120,10 @@ def test_sd15_stage_b_partial_frozen_with_reference_attention_vs_oracle(dev):
     s = setup(dev)
     saved_ref, _ = oracle_stage_a(s)
     g = torch.Generator().manual_seed(5)
+    # the overall generation starts from its OWN noise (composed latents in the pipeline): started from stage A's latents
+    # with stage A's text, object 0's map would EQUAL its reference and the L1 transfer term's sign(A - R) would be
+    # rounding noise on both sides
     hist_in = torch.randn((T + 1, 1, 4, 64, 64), generator=g)
-    hist_in[0] = s["x"]
     fm = torch.zeros(64, 64, dtype=torch.bool)
     fm[22:52, 10:32] = True
     hw = {k: saved_ref[0][k].shape[2] for k in KEYS}

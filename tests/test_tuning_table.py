@@ -71,3 +71,32 @@ def test_every_table_mode_has_a_gpu_parity_case():
             b = s.M // (s.hout * s.hout)
             assert b >= 1 and b * s.hout * s.hout == s.M
             assert s.hout == ((2 * s.hin if s.ups else s.hin) - 1) // s.stride + 1
+
+
+def test_table_tile_44_is_not_handed_to_an_epilogue_it_does_not_have():
+    """The table is keyed by (M, N, K, gather, GEGLU): a caller with the same key but an fp32 output, an fp32 residual, a
+    narrow / unaligned output or a second source must get the heuristic tile, not the 256 x 256 ring (which would
+    return LGD_ERR_ARG at launch)."""
+    import torch
+    key44 = None
+    for mode in ("latency", "throughput"):
+        with ops.tuning(mode):
+            for k, e in ops.tuning_table().items():
+                if e["tile"] == 44 and k.endswith("_e0_b1"):
+                    key44, mode44 = k, mode
+                    break
+        if key44:
+            break
+    if key44 is None:
+        return                                             # no such entry in this table version: nothing to guard
+    m = re.match(r"M(\d+)_N(\d+)_K(\d+)_", key44)
+    M, N, K = (int(m.group(i)) for i in (1, 2, 3))
+    a = torch.empty(1, dtype=torch.float16)                 # descriptors only hold addresses; nothing is launched here
+    with ops.tuning(mode44):
+        plain = ops.gemm_desc(a, a, a, M, N, K)
+        assert plain.tile == 44 and plain.splits == 1
+        assert ops.gemm_desc(a, a, a, M, N, K, epi=ops.EPI_OUT_F32).tile != 44
+        assert ops.gemm_desc(a, a, a, M, N, K, res=a, ldr=N, epi=ops.EPI_RES_F32).tile != 44
+        assert ops.gemm_desc(a, a, a, M, N, K, ldc=N + 4).tile != 44
+        assert ops.gemm_desc(a[0:0].new_empty(9)[1:], a, a, M, N, K).tile == 44      # the OPERAND's alignment is not the rule
+        assert ops.gemm_desc(a, a, torch.empty(9, dtype=torch.float16)[1:], M, N, K).tile != 44   # output base not 16-byte aligned

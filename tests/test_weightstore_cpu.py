@@ -46,3 +46,18 @@ def test_every_folded_site_has_its_three_entries():
     per_block = 4                                                         # qkv, to_q, ff, fuser ff
     n_blocks = sum(a.depth for b in ws.blocks for a in b.attns)
     assert len(names) == per_block * n_blocks
+
+
+def test_store_without_the_fold_carries_no_twins():
+    """LGD_FOLD_LN=0 engines (and anything else that never builds a folded no-grad plan) neither store nor broadcast the
+    folded twins: same unfolded entries, smaller arenas, load_state_dict still fills everything it laid out."""
+    cfg = weights.CONFIGS["tiny_gligen"]
+    sd = weights.synth_state_dict(cfg, 3)
+    full, lean = WeightStore(cfg, "cpu"), WeightStore(cfg, "cpu", fold_ln=False)
+    lean.load_state_dict(sd)
+    full.load_state_dict(sd)
+    assert not any(k.endswith(".wln") for k in lean.h) and not any(k.endswith((".cs", ".bln")) for k in lean.f)
+    assert lean.arena16.numel() < full.arena16.numel() and lean.arena32.numel() < full.arena32.numel()
+    assert set(lean.h) == {k for k in full.h if not k.endswith(".wln")}
+    for k in lean.h:
+        assert torch.equal(lean.h[k], full.h[k]), k

@@ -31,6 +31,17 @@ PY
       LGD_TUNE_TOP=$TOP timeout ${TUNE_TIMEOUT:-480} python tools/tune_gemm.py sd14_gligen $OUT/latency.json > $OUT/tune.log 2>&1
     fi
     echo "tune rc=$?"; tail -n 4 $OUT/tune.log ;;
+  tune_big)   # round 5: the GEMM shapes of the 16- / 32-image main plans and 8- / 16-image guidance plans (bigger UNet
+              # calls, bench.py --group / --max-batch) added to the shared-GPU table; args: [streams]
+    STREAMS=${1:-2}
+    python - <<'PY'
+import json
+a = json.load(open("llm-groundeddiffusion_amd/tuning_gfx950.json")); a.update(json.load(open("llm-groundeddiffusion_amd/tuning_gfx950_lanes.json")))
+json.dump(a, open("gpurun_out/tune_big/lanes_full.json", "w"), indent=0, sort_keys=True)
+PY
+    LGD_TUNE_BATCHES=${TUNE_MAIN:-16,32} LGD_TUNE_GUIDE_BATCHES=${TUNE_GUIDE:-8,16} LGD_TUNE_STREAMS=$STREAMS \
+      timeout ${TUNE_TIMEOUT:-560} python tools/tune_gemm.py sd14_gligen $OUT/lanes_full.json > $OUT/tune.log 2>&1
+    echo "tune rc=$?"; grep -c "TF/s" $OUT/tune.log; tail -n 3 $OUT/tune.log ;;
   sweep)      # round 5: (lanes x steps per lane job x images per UNet call) on the default workload; args = bench flags
     for cfg in "4 1 8 4" "2 2 16 8" "4 2 16 8" "1 4 32 16" "2 4 32 16"; do
       set -- $cfg

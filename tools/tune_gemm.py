@@ -19,7 +19,7 @@ out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "llm-grounde
 dev = torch.device("cuda:0")
 cfg = weights.CONFIGS[cfg_name]
 XL = cfg.addition_embed_type == "text_time"        # SDXL-refiner pass: shapes of one CFG UNet call + VAE encode / decode
-eng = UNetEngine(cfg, dev, None, **(dict(max_text_batch=2) if XL else {}))      # zero weights are fine for timing shapes
+eng = UNetEngine(cfg, dev, None, **(dict(max_text_batch=2) if XL else dict(max_text_batch=64)))      # zero weights are fine for timing shapes
 eng.w.refresh_scalars()
 L = cfg.sample_size
 
@@ -48,8 +48,10 @@ else:
     sm = LMDSampler(eng, use_graphs=False)
     eng.prepare_timesteps([500]); eng.set_step(0)
     batches = [int(x) for x in os.environ.get("LGD_TUNE_BATCHES", "1,2,4,8").split(",")]
+    gbatches = [int(x) for x in os.environ["LGD_TUNE_GUIDE_BATCHES"].split(",") if x] if "LGD_TUNE_GUIDE_BATCHES" in os.environ \
+        else [b for b in batches if b <= 4]
     for kind, fz, nb, fn in sm.profile_passes(L, 50, cfg.use_gated_attention, main_batches=batches,
-                                              guide_batches=[b for b in batches if b <= 4]):
+                                              guide_batches=gbatches):
         fn()
 torch.cuda.synchronize()
 ops.gemm_launch = orig
