@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LGD_ABI_VERSION 8
+#define LGD_ABI_VERSION 9
 int lgd_abi_version(void);
 /* Kernel-variant switches of the library (A/B timing and tests; the defaults are what the benchmark runs).  No
  * counterpart in the reference.  "attn32": self-attention forward without map capture — 0 = the 16x16x32 kernel,
@@ -307,6 +307,28 @@ int lgd_ca_energy_f32(const float* const* maps, float* const* gmaps, const int32
                       int64_t refs_step_stride, const int32_t* dyn, const int32_t* groups, int n_groups,
                       int n_items, int n_samples, int H, int T, int max_hw, float grad_scale, float* partial,
                       float* loss, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BoxDiff energy (ABI v9) and its gradient on the probability maps, one launch, one workgroup per image:
+ * utils/boxdiff.py:20-101 (_compute_max_attention_per_index: x100 token soft-max of the layer- and head-averaged map
+ * without its first and last token, reflect-padded 3x3 smoothing, inner- / outer-box top-k means, corner terms),
+ * :104-118 (_compute_loss), :121-196 (compute_ca_loss_boxdiff), times amp_loss_scale (:224).  Replaces that Python loop
+ * over objects x phrase tokens and the autograd graph through it (torch.cat / mean over the maps included).
+ *   maps / gmaps: device arrays of n_maps pointers to fp32 [n_samples][H][side*side][T] (all maps of ONE resolution:
+ *          generation/boxdiff.py:33-39 lists five 16x16 keys); gmaps pre-zeroed or NULL (value only)
+ *   items: int32 [n_items][8] = {token (index in the 77-token prompt), mask_id, k_fg, k_bg, 0, 0, 0, 0}, the items of an
+ *          image adjacent; k = (mask.sum() * P).long() as :80,:85 compute it; k = 0 drops that term (Python's
+ *          max(0, nan) = 0, :107-109)
+ *   groups: int32 [n_samples][2] = {first item, item count} per image; max_items = the largest count (sizes the LDS)
+ *   masks: fp32 [n_masks][3][side*side]: row 0 the union of the object's boxes; row 1 corner_mask_x[side] |
+ *          corner_mask_y[side] (:64-67); row 2 gt_proj_x[side] | gt_proj_y[side] (:90-91)
+ *   smooth: 9 fp32 weights of GaussianSmoothing(kernel_size 3, sigma) (utils/attn.py:92-110) or NULL (no smoothing)
+ *   loss: fp32 [n_samples] = loss_scale * energy; the map gradients carry loss_scale * grad_scale.
+ * Returns LGD_ERR_UNSUPPORTED for side > 32, T > 128 or more items per image than fit the LDS (70 at 16x16).
+ * ------------------------------------------------------------------------------------------- */
+int lgd_boxdiff_energy_f32(const float* const* maps, float* const* gmaps, int n_maps, int side, const int32_t* items,
+                           const float* masks, const float* smooth, const int32_t* groups, int n_samples,
+                           int max_items, int H, int T, float loss_scale, float grad_scale, float* loss, void* stream);
 
 #ifdef __cplusplus
 }

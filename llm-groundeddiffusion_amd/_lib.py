@@ -14,7 +14,7 @@ import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgd_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -82,6 +82,7 @@ SIGNATURES = {
     "lgd_sam_relpos_qkv_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "lgd_sam_window_merge_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgd_ca_energy_f32": [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P],
+    "lgd_boxdiff_energy_f32": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P],
 }
 
 _lib = None

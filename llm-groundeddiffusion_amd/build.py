@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblgd_hip.so")
 STAMP = OUT + ".stamp"
-SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "attn_w4.hip", "attn_bwd.hip", "misc.hip", "energy.hip", "sam.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "attn_w4.hip", "attn_bwd.hip", "misc.hip", "energy.hip", "boxdiff.hip", "sam.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-Wno-unused-value"]
 # Per-file extras.  The attention kernels run softmax VALU work on MFMA results every key tile: keep

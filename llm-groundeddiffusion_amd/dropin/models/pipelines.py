@@ -3,8 +3,9 @@ return tuples, executed by lgd_amd.sampler.LMDSampler (captured hipGraphs of the
 
 Implemented: latent_backward_guidance :16-82, decode :117-127, generate_semantic_guidance :129-247,
 gligen_enable_fuser :280-283, prepare_gligen_condition :285-321, generate_gligen :323-473,
-generate_partial_frozen :541-599.  Not on the hot path and not provided: encode / invert (DDIM
-inversion, unused by LMD / LMD+), generate (plain SD), BoxDiff (`use_boxdiff`)."""
+generate_partial_frozen :541-599, and their `use_boxdiff=True` branch (:187-188, :564-565: one gradient step on the
+BoxDiff energy of utils/boxdiff.py per denoising step, csrc/boxdiff.hip).  Not on the hot path and not provided:
+encode / invert (DDIM inversion, unused by LMD / LMD+), generate (plain SD)."""
 import numpy as np
 import torch
 
@@ -19,6 +20,20 @@ def _sampler(model_dict):
     if sm is None:
         raise RuntimeError("model_dict has no HIP sampler; build it with models.build_model_dict/load_synthetic/load_sd")
     return sm
+
+
+def _boxdiff_dict(bboxes, object_positions, kwargs):
+    """semantic_guidance_kwargs as latent_backward_guidance_boxdiff receives them (utils/boxdiff.py:199): the
+    reference-attention arguments are accepted and must be inert, as generation/boxdiff.py:100-110 passes them."""
+    g = dict(kwargs or {})
+    if g.pop("ref_ca_saved_attns", None) is not None:
+        raise NotImplementedError("BoxDiff with a reference-attention term (utils/boxdiff.py:155-167 warns that the "
+                                  "original method has none) is outside the HIP path")
+    for drop in ("verbose", "clear_cache", "ref_ca_word_token_only", "ref_ca_last_token_only", "word_token_indices",
+                 "ref_ca_loss_weight", "cross_attention_kwargs"):
+        g.pop(drop, None)
+    g.update(bboxes=bboxes, object_positions=object_positions, use_boxdiff=True)
+    return g
 
 
 def _guidance_dict(bboxes, object_positions, kwargs):
@@ -163,13 +178,15 @@ def generate_semantic_guidance(model_dict, latents, input_embeddings, num_infere
                                save_all_latents=False, dynamic_num_inference_steps=False, fast_after_steps=None,
                                fast_rate=2, use_boxdiff=False):
     """pipelines.py:129-247 -> (latents, images[, saved_attns][, pil][, latents_all])."""
-    if use_boxdiff or return_cross_attn:
-        raise NotImplementedError("use_boxdiff / return_cross_attn are outside the HIP path")
+    if return_cross_attn:
+        raise NotImplementedError("return_cross_attn is outside the HIP path")
     sm = _sampler(model_dict)
     text_embeddings, _, _ = input_embeddings
     T, L = num_inference_steps, latents.shape[-1]
     guid = None
-    if bboxes:
+    if bboxes and use_boxdiff:                               # pipelines.py:187-188
+        guid = _boxdiff_dict(bboxes, object_positions, semantic_guidance_kwargs)
+    elif bboxes:
         g, ref = _guidance_dict(bboxes, object_positions, semantic_guidance_kwargs)
         keys = [tuple(k) for k in (g.get("guidance_attn_keys") or DEFAULT_GUIDANCE_ATTN_KEYS)]
         g["ref_maps"] = _ref_maps_from_saved(sm, ref, bboxes, keys, L, T)
@@ -222,13 +239,13 @@ def generate_partial_frozen(model_dict, latents_all, frozen_mask, input_embeddin
                             guidance_scale=7.5, bboxes=None, phrases=None, object_positions=None,
                             semantic_guidance_kwargs=None, offload_guidance_cross_attn_to_cpu=False, use_boxdiff=False):
     """pipelines.py:541-599 -> (latents, images)."""
-    if use_boxdiff:
-        raise NotImplementedError("BoxDiff is outside the HIP path")
     sm = _sampler(model_dict)
     text_embeddings, _, _ = input_embeddings
     T, L = num_inference_steps, latents_all.shape[-1]
     guid = None
-    if bboxes:
+    if bboxes and use_boxdiff:                               # pipelines.py:564-565
+        guid = _boxdiff_dict(bboxes, object_positions, semantic_guidance_kwargs)
+    elif bboxes:
         g, ref = _guidance_dict(bboxes, object_positions, semantic_guidance_kwargs)
         keys = [tuple(k) for k in (g.get("guidance_attn_keys") or DEFAULT_GUIDANCE_ATTN_KEYS)]
         g["ref_maps"] = _ref_maps_from_saved(sm, ref, bboxes, keys, L, T)

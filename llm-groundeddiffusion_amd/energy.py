@@ -182,3 +182,131 @@ class EnergyTables:
                       self.refs, stride, dyn, self.groups, self.n_groups, self.n_items, self.heads, self.T,
                       self.max_hw, self.partial, self.loss, grad_scale=grad_scale, n_samples=self.n_samples)
         return self.loss
+
+
+# =================================================================================================
+# BoxDiff (utils/boxdiff.py) — the energy of the `boxdiff` stage-2 baseline (generation/boxdiff.py)
+# =================================================================================================
+def gaussian_kernel(kernel_size=3, sigma=0.5) -> torch.Tensor:
+    """utils/attn.py:92-110 (GaussianSmoothing, dim = 2): per axis 1 / (std sqrt(2 pi)) exp(-((x - mean) / (2 std))^2) —
+    the (2 std) sits INSIDE the square there — multiplied over both axes, normalised to sum 1; fp32 as the reference."""
+    ax = torch.arange(kernel_size, dtype=F32)
+    kernel = torch.ones((kernel_size, kernel_size), dtype=F32)
+    for mg in torch.meshgrid([ax, ax], indexing="ij"):
+        mean = (kernel_size - 1) / 2
+        kernel = kernel * (1 / (sigma * math.sqrt(2 * math.pi)) * torch.exp(-((mg - mean) / (2 * sigma)) ** 2))
+    return kernel / torch.sum(kernel)
+
+
+class BoxDiffTables:
+    """Host side of the BoxDiff energy for one layout: masks, corner masks, projections, top-k counts and the item list
+    that `lgd_boxdiff_energy_f32` consumes (utils/boxdiff.py:20-101).  Same interface as EnergyTables (`keys`, `bind`,
+    `run`, `merged`), so the sampler's guidance loop drives either."""
+
+    def __init__(self, device, bboxes, object_positions, guidance_attn_keys: Sequence[Tuple], map_hw: Dict[Tuple, int],
+                 heads: int, text_len: int = 77, *, loss_scale=10.0, P=0.2, L=1, smooth_attentions=True, sigma=0.5,
+                 kernel_size=3):
+        self.device, self.heads, self.T = device, heads, text_len
+        self.keys = [tuple(k) for k in guidance_attn_keys]
+        hws = {map_hw[k] for k in self.keys}
+        if len(hws) != 1:
+            # compute_ca_loss_boxdiff concatenates the maps of all keys over heads and averages them (:152)
+            raise RuntimeError(f"BoxDiff averages the maps of its guidance keys: they must share one resolution, got {sorted(hws)}")
+        self.hw = hws.pop()
+        self.side = int(math.sqrt(self.hw))
+        if kernel_size != 3 and smooth_attentions:
+            raise RuntimeError("BoxDiff smoothing: only the reference's 3x3 kernel is implemented")
+        self.max_hw = self.hw
+        self.loss_scale = float(loss_scale)
+        self.n_obj = len(bboxes)
+        self.smooth_host = gaussian_kernel(kernel_size, sigma).reshape(-1) if smooth_attentions else None
+        S = self.side
+        items, masks = [], []
+        for o in range(self.n_obj):
+            obj_boxes = bboxes[o]
+            if not isinstance(obj_boxes[0], Iterable):
+                obj_boxes = [obj_boxes]
+            m = torch.zeros(S, S)
+            cx, cy = torch.zeros(S), torch.zeros(S)
+            for b in obj_boxes:
+                x0, y0, x1, y1 = scale_proportion(b, S, S)
+                m[y0:y1, x0:x1] = 1
+                cx[max(x0 - L, 0):min(x0 + L + 1, S)] = 1.                    # utils/boxdiff.py:64-67
+                cx[max(x1 - L, 0):min(x1 + L + 1, S)] = 1.
+                cy[max(y0 - L, 0):min(y0 + L + 1, S)] = 1.
+                cy[max(y1 - L, 0):min(y1 + L + 1, S)] = 1.
+            k_fg = int((m.sum() * P).long())                                   # :80
+            k_bg = int(((1 - m).sum() * P).long())                             # :85
+            rows = torch.zeros(3, self.hw)
+            rows[0] = m.reshape(-1)
+            rows[1, :S], rows[1, S:2 * S] = cx, cy
+            rows[2, :S], rows[2, S:2 * S] = m.max(dim=0).values, m.max(dim=1).values      # :90-91
+            mid = len(masks)
+            masks.append(rows)
+            for p in object_positions[o]:
+                if not 1 <= int(p) <= text_len - 2:
+                    # the reference indexes attention_for_text[:, :, p - 1] of the [1:-1] slice (:46): p = 0 would wrap
+                    raise RuntimeError(f"BoxDiff phrase token {p} outside 1..{text_len - 2}")
+                items.append([int(p), mid, k_fg, k_bg, 0, 0, 0, 0])
+        self._host = (items, masks)
+        self.n_samples = 1
+        self._groups_host = [[0, len(items)]]
+        self._finalize()
+
+    def _finalize(self):
+        items, masks = self._host
+        dev = self.device
+        self.n_items = len(items)
+        self.items = torch.tensor(items if items else [[0] * 8], dtype=torch.int32, device=dev)
+        self.masks = (torch.stack(masks) if masks else torch.zeros(1, 3, self.hw)).to(dev, F32).contiguous()
+        self.groups = torch.tensor(self._groups_host, dtype=torch.int32, device=dev)
+        self.max_items = max(c for _, c in self._groups_host)
+        self.smooth = self.smooth_host.to(dev, F32).contiguous() if self.smooth_host is not None else None
+        self.loss = torch.zeros(self.n_samples, dtype=F32, device=dev)
+        self.refs = None
+        self._ptrs = None
+
+    @classmethod
+    def merged(cls, tables: "List[Optional[BoxDiffTables]]") -> "BoxDiffTables":
+        """One table for a batch of images (None = an image without guidance: zero items, loss 0)."""
+        first = next(t for t in tables if t is not None)
+        m = cls.__new__(cls)
+        for k in ("device", "heads", "T", "keys", "hw", "side", "max_hw", "loss_scale", "smooth_host"):
+            setattr(m, k, getattr(first, k))
+        items, masks, groups = [], [], []
+        for t in tables:
+            if t is None:
+                groups.append([len(items), 0])
+                continue
+            assert t.keys == m.keys and t.hw == m.hw and t.loss_scale == m.loss_scale
+            assert (t.smooth_host is None) == (m.smooth_host is None)
+            it, ma = t._host
+            groups.append([len(items), len(it)])
+            for row in it:
+                r = list(row)
+                r[1] += len(masks)
+                items.append(r)
+            masks += ma
+        m.n_obj = sum(t.n_obj for t in tables if t is not None)
+        m._host, m._groups_host, m.n_samples = (items, masks), groups, len(tables)
+        m._finalize()
+        return m
+
+    def bind(self, maps: Dict[Tuple, torch.Tensor], gmaps: Optional[Dict[Tuple, torch.Tensor]]):
+        mp = torch.tensor([maps[k].data_ptr() for k in self.keys], dtype=torch.int64, device=self.device)
+        gp = None
+        if gmaps is not None:
+            gp = torch.tensor([gmaps[k].data_ptr() for k in self.keys], dtype=torch.int64, device=self.device)
+        self._ptrs = (mp, gp, maps, gmaps)
+
+    def run(self, dyn: torch.Tensor = None, grad_scale: float = 1.0, with_grad: bool = True) -> torch.Tensor:
+        """Launches the energy (+ map gradients into the bound gmaps, zeroed here: tokens 0 and T-1 get no gradient).
+        Returns the device losses [n_samples], already multiplied by amp_loss_scale (utils/boxdiff.py:224)."""
+        mp, gp, maps, gmaps = self._ptrs
+        if with_grad and gmaps is not None:
+            for k in self.keys:
+                ops.zero_(gmaps[k])
+        ops.boxdiff_energy(mp, gp if with_grad else None, len(self.keys), self.side, self.items, self.masks, self.smooth,
+                           self.groups, self.n_samples, self.max_items, self.heads, self.T, self.loss_scale, grad_scale,
+                           self.loss)
+        return self.loss

@@ -709,3 +709,12 @@ def ca_energy(map_ptrs, gmap_ptrs, map_hw, items, coefs, masks, refs, refs_step_
           lambda: _call("lgd_ca_energy_f32", _p(map_ptrs), _p(gmap_ptrs), _p(map_hw), _p(items), _p(coefs),
                         _p(masks), _p(refs), int(refs_step_stride), _p(dyn), _p(groups), n_groups, n_items, n_samples, H, T,
                         max_hw, float(grad_scale), _p(partial), _p(loss), _stream()))
+
+
+def boxdiff_energy(map_ptrs, gmap_ptrs, n_maps, side, items, masks, smooth, groups, n_samples, max_items, H, T,
+                   loss_scale, grad_scale, loss):
+    """BoxDiff energy + map gradients (lgd_boxdiff_energy_f32, include/lgd_hip.h; utils/boxdiff.py:20-196)."""
+    _prof("boxdiff_energy_kernel", 4.0 * 2 * n_maps * n_samples * H * side * side * T * 2,
+          lambda: _call("lgd_boxdiff_energy_f32", _p(map_ptrs), _p(gmap_ptrs), int(n_maps), int(side), _p(items), _p(masks),
+                        _p(smooth), _p(groups), int(n_samples), int(max_items), int(H), int(T), float(loss_scale),
+                        float(grad_scale), _p(loss), _stream()))

@@ -390,3 +390,39 @@ def backward_guidance_generate_batch(sampler: LMDSampler, lays: List[CachedLayou
     images = sampler.decode(torch.cat([r["latents"] for r in res])) if decode else [None] * len(lays)
     return [dict(image=images[i], latents=r["latents"], guidance_iters=r["guidance_iters"],
                  guidance_iters_fuser_on=0) for i, r in enumerate(res)]
+
+
+def boxdiff_generate(sampler: LMDSampler, lay: CachedLayout, **kw):
+    """BoxDiff baseline for one layout (generation/boxdiff.py:46-131)."""
+    return boxdiff_generate_batch(sampler, [lay], **kw)[0]
+
+
+def boxdiff_generate_batch(sampler: LMDSampler, lays: List[CachedLayout], *, num_inference_steps=50, guidance_scale=7.5,
+                           max_index_step=25, height=512, width=512, decode=True, guidance_attn_keys=None, first_step=0,
+                           n_steps=None, start=None, trace=None, **boxdiff_kw):
+    """The `boxdiff` stage-2 baseline (generation/boxdiff.py:46-131): ONE generate_semantic_guidance call
+    per layout on seeded noise with `use_boxdiff=True` (models/pipelines.py:187-188) — before each of the first
+    `max_index_step` denoising steps one gradient step on the BoxDiff energy (utils/boxdiff.py:199-259: the five 16x16
+    cross-attention maps averaged over layers and heads, x100 token soft-max, smoothed, inner- / outer-box top-k and
+    corner terms; csrc/boxdiff.hip), no per-box stage, no reference-attention term (generation/boxdiff.py:104,108 pass
+    None / weight 0).  `boxdiff_kw` may carry latent_backward_guidance_boxdiff's own arguments (amp_loss_scale,
+    latent_scale, scale_range, P, L, smooth_attentions, sigma); the plugin passes none.
+    `first_step` / `n_steps` / `start` / `trace`: a slice of the schedule from given latents (teacher-forced tests)."""
+    from .sampler import BOXDIFF_GUIDANCE_ATTN_KEYS
+    L = height // 8
+    C = sampler.eng.cfg.in_channels
+    keys = [tuple(k) for k in (guidance_attn_keys or BOXDIFF_GUIDANCE_ATTN_KEYS)]
+    jobs = []
+    for lay in lays:
+        lat = seeded_noise(lay.bg_seed, C, L, L) if start is None else torch.as_tensor(start[len(jobs)]).float()
+        overall_bboxes = [[list(lay.boxes[i]) for i in grp] for grp in lay.overall_groups]
+        guid = None
+        if overall_bboxes:
+            guid = dict(bboxes=overall_bboxes, object_positions=lay.overall_object_positions, use_boxdiff=True,
+                        max_index_step=max_index_step, guidance_attn_keys=keys, **boxdiff_kw)
+        jobs.append(Job(lat, torch.cat([lay.overall_uncond, lay.overall_cond]), guidance=guid))
+    res = sampler.denoise_batch(jobs, num_inference_steps, guidance_scale=guidance_scale, save_all_latents=False,
+                                first_step=first_step, n_steps=n_steps, trace=trace)
+    images = sampler.decode(torch.cat([r["latents"] for r in res])) if decode else [None] * len(lays)
+    return [dict(image=images[i], latents=r["latents"], guidance_iters=r["guidance_iters"], guidance_iters_fuser_on=0)
+            for i, r in enumerate(res)]

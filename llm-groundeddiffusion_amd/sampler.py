@@ -20,7 +20,7 @@ import threading
 import torch
 
 from . import ops
-from .energy import EnergyTables
+from .energy import BoxDiffTables, EnergyTables
 from .lanes import GATE
 from .scheduler import DDIMScheduler
 from .unet import N_OBJ_TOKENS, UNetEngine
@@ -28,6 +28,7 @@ from .unet import N_OBJ_TOKENS, UNetEngine
 F32 = torch.float32
 DEFAULT_GUIDANCE_ATTN_KEYS = [("mid", 0, 0, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 1, 2, 0)]  # pipelines.py:14
 OBJ_KEY_DEFAULT = ("down", 2, 1, 0)                                                                  # lmd_plus.py:380
+BOXDIFF_GUIDANCE_ATTN_KEYS = [("down", 2, 0, 0), ("down", 2, 1, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 1, 2, 0)]  # generation/boxdiff.py:33-39
 
 
 def prepare_gligen_condition(bboxes, phrase_embeddings, device, positive_len=768):
@@ -50,10 +51,14 @@ def prepare_gligen_condition(bboxes, phrase_embeddings, device, positive_len=768
 class GuidanceState:
     """Everything the guidance inner loop needs for one image (layout)."""
 
-    def __init__(self, energy: EnergyTables, loss_scale, loss_threshold, max_iter, max_index_step):
+    def __init__(self, energy, loss_scale, loss_threshold, max_iter, max_index_step, kind="lmd", step_scale=None):
         self.energy = energy
         self.loss_scale, self.loss_threshold = float(loss_scale), float(loss_threshold)
         self.max_iter, self.max_index_step = max_iter, int(max_index_step)
+        # "lmd": latent_backward_guidance (pipelines.py:16-82: loss-thresholded inner loop, step sqrt(1 - abar_t));
+        # "boxdiff": utils/boxdiff.py:199-259 (ONE step per denoising step, step_scale(index, n_timesteps) de-scaled by
+        # the amp loss scale)
+        self.kind, self.step_scale = kind, step_scale
         self.loss = 10000.0             # carried across steps; pipelines.py:161,375,552
         self.iterations = 0
         self.iterations_fuser_on = 0    # of which: taken while the GLIGEN fuser was enabled (accounting only)
@@ -182,6 +187,9 @@ class LMDSampler:
         caller does not switch it off.  ref_maps: fp32 [T][n_boxes_flat][n_keys][heads][max_hw] or None."""
         if not bboxes or max_index_step <= 0:
             return None
+        if kw.get("use_boxdiff"):
+            return self.make_boxdiff_guidance(L, bboxes, object_positions, max_index_step=max_index_step,
+                                              guidance_attn_keys=guidance_attn_keys, **kw)
         keys = [tuple(k) for k in (guidance_attn_keys or DEFAULT_GUIDANCE_ATTN_KEYS)]
         heads = self.heads_of(keys[0])
         assert all(self.heads_of(k) == heads for k in keys), "guidance keys with different head counts"
@@ -194,6 +202,23 @@ class LMDSampler:
             T = ref_maps.shape[0]
             en.set_refs(ref_maps.reshape(T, -1, heads, en.max_hw))
         return GuidanceState(en, loss_scale, loss_threshold, max_iter, max_index_step)
+
+    def make_boxdiff_guidance(self, L, bboxes, object_positions, *, max_index_step=25, guidance_attn_keys=None,
+                              amp_loss_scale=10, latent_scale=20, scale_range=(1., 0.5), **kw) -> GuidanceState:
+        """latent_backward_guidance_boxdiff's arguments (utils/boxdiff.py:199): one gradient step per denoising step while
+        index < max_index_step — no loss threshold, no inner loop — of size latent_scale * sqrt(ramp(index)), the loss
+        scaled by amp_loss_scale and the step de-scaled by it (:224,:236-238)."""
+        keys = [tuple(k) for k in (guidance_attn_keys or BOXDIFF_GUIDANCE_ATTN_KEYS)]
+        heads = self.heads_of(keys[0])
+        assert all(self.heads_of(k) == heads for k in keys), "guidance keys with different head counts"
+        ekw = {k: kw[k] for k in ("P", "L", "smooth_attentions", "sigma", "kernel_size") if k in kw}
+        en = BoxDiffTables(self.dev, bboxes, object_positions, keys, self.map_hw(L), heads, self.eng.text_len,
+                           loss_scale=amp_loss_scale, **ekw)
+        lo, hi = float(scale_range[0]), float(scale_range[1])
+
+        def step_scale(index, n_timesteps):
+            return latent_scale * (lo + (hi - lo) * index / max(n_timesteps - 1, 1)) ** 0.5 / amp_loss_scale
+        return GuidanceState(en, amp_loss_scale, float("-inf"), 1, max_index_step, kind="boxdiff", step_scale=step_scale)
 
     # ------------------------------------------------------------------------------------------
     MAX_STATES = 12
@@ -290,6 +315,9 @@ class LMDSampler:
         g = dict(guidance)
         gkeys = [tuple(k) for k in (g.get("guidance_attn_keys") or DEFAULT_GUIDANCE_ATTN_KEYS)]
         gs = g.pop("state", None) or self.make_guidance(L, g.pop("bboxes"), g.pop("object_positions"), **g)
+        if gs is not None and gs.kind == "boxdiff":
+            gkeys = [tuple(k) for k in (g.get("guidance_attn_keys") or BOXDIFF_GUIDANCE_ATTN_KEYS)]
+            st.gtab[:T, 0].copy_(torch.tensor([gs.step_scale(i, T) for i in range(T)], dtype=F32))
         eng.prepare_timesteps([int(t) for t in sch.timesteps])
         cond = cond_embeddings.to(dev)
         eng.prepare_text(torch.cat([torch.zeros_like(cond), cond]))
@@ -436,7 +464,8 @@ class LMDSampler:
                 gstates.append(None)
                 continue
             g = dict(j.guidance)
-            jk = [tuple(k) for k in (g.get("guidance_attn_keys") or DEFAULT_GUIDANCE_ATTN_KEYS)]
+            jk = [tuple(k) for k in (g.get("guidance_attn_keys") or
+                                     (BOXDIFF_GUIDANCE_ATTN_KEYS if g.get("use_boxdiff") else DEFAULT_GUIDANCE_ATTN_KEYS))]
             if gkeys is not None and jk != gkeys:
                 raise RuntimeError("jobs guided in one batch must share guidance_attn_keys")
             gkeys = jk
@@ -444,8 +473,15 @@ class LMDSampler:
         guided = any(gs is not None for gs in gstates)
         energy = None
         if guided:
+            kinds = {gs.kind for gs in gstates if gs is not None}
+            if len(kinds) != 1:
+                raise RuntimeError("jobs guided in one batch must share the energy (LMD guidance or BoxDiff)")
+            tables = BoxDiffTables if kinds == {"boxdiff"} else EnergyTables
+            if kinds == {"boxdiff"}:             # utils/boxdiff.py:236-238: the update's own step table (all jobs alike)
+                gs0 = next(gs for gs in gstates if gs is not None)
+                st.gtab[:Tr, 0].copy_(torch.tensor([gs0.step_scale(i, Tr) for i in range(Tr)], dtype=F32))
             energy = gstates[[gs is not None for gs in gstates].index(True)].energy if nb == 1 else \
-                EnergyTables.merged([gs.energy if gs is not None else None for gs in gstates])
+                tables.merged([gs.energy if gs is not None else None for gs in gstates])
         max_guided = max([gs.max_index_step for gs in gstates if gs is not None] + [0])
 
         # ---- per-run constants (before graph capture so that warm-up launches see valid inputs)

@@ -35,7 +35,7 @@ OBJ_KEY = ("down", 2, 1, 0)
 BOXES = [[0.15, 0.35, 0.5, 0.8], [0.6, 0.38, 0.98, 0.8]]
 OBJ_POS = [[1, 2, 3], [5, 6, 7]]
 # gates of the pinned (table-free, fold-free) guidance iteration: 3x the values measured for it on MI355X (round 5)
-PINNED_COS, PINNED_L2 = 0.9994, 2.7e-2
+PINNED_COS, PINNED_L2 = 0.99988, 2.7e-2      # measured 0.99996 / 9.6e-3
 
 
 def relerr(a, b):

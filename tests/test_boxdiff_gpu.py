@@ -1,0 +1,204 @@
+"""BoxDiff on MI355X: csrc/boxdiff.hip against goldens recorded from the reference's OWN
+utils/boxdiff.py (value + map gradients), the sampler's one-step-per-denoising-step guidance against the reference's own
+generation/boxdiff.run teacher-forced step by step, and the drop-in plugin `generation.boxdiff`."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import lgd_amd  # noqa: E402,F401
+from lgd_amd import weights  # noqa: E402
+from lgd_amd.energy import BoxDiffTables  # noqa: E402
+from lgd_amd.sampler import BOXDIFF_GUIDANCE_ATTN_KEYS as KEYS, LMDSampler  # noqa: E402
+from lgd_amd.scheduler import DDIMScheduler  # noqa: E402
+from lgd_amd.unet import UNetEngine  # noqa: E402
+from conftest import gate  # noqa: E402
+from fake_text import FakeTextEncoder, FakeTokenizer  # noqa: E402
+
+CASES = ("hw256", "hw64", "two_boxes", "edge", "tiny_box")
+SPEC = dict(prompt="A realistic image of a white deer and a gray bear in an empty factory scene",
+            gen_boxes=[("a white deer", [37, 88, 91, 117]), ("a gray bear", [157, 96, 94, 108])],
+            bg_prompt="A realistic image of an empty factory scene", extra_neg_prompt="")
+SPEC3 = dict(prompt="A photo of two apples on a table",
+             gen_boxes=[("an apple", [20, 120, 80, 80]), ("an apple", [140, 110, 90, 90]), ("a wooden spoon", [60, 30, 120, 40])],
+             bg_prompt="A photo of a table", extra_neg_prompt="cartoon")
+
+
+def relerr(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-20))
+
+
+def _tables(dev, g, name):
+    spec = json.loads(str(g[f"{name}_spec"]))
+    hw = {k: spec["side"] ** 2 for k in KEYS}
+    return spec, BoxDiffTables(dev, spec["bboxes"], spec["pos"], KEYS, hw, spec["heads"], loss_scale=1.0)
+
+
+def test_boxdiff_kernel_vs_reference_golden(dev):
+    """Value and the gradient on all five maps vs the reference's own compute_ca_loss_boxdiff + autograd (fp32 on both
+    sides; the kernel sums the 40 (layer, head) maps sequentially, torch pairwise: the x100 token soft-max amplifies that
+    round-off to ~1e-5, and a top-k element at the threshold may change sides)."""
+    g = np.load(os.path.join(GOLD, "boxdiff_energy.npz"))
+    for name in CASES:
+        spec, t = _tables(dev, g, name)
+        maps = {k: torch.from_numpy(g[f"{name}_map{i}"]).to(dev).contiguous() for i, k in enumerate(KEYS)}
+        gmaps = {k: torch.full_like(v, float("nan")) for k, v in maps.items()}
+        t.bind(maps, gmaps)
+        loss = t.run(grad_scale=1.0)
+        torch.cuda.synchronize()
+        gate(f"[boxdiff {name}] loss rel. error", abs(float(loss[0]) - float(g[f"{name}_loss"])) / abs(float(g[f"{name}_loss"])), 3e-5)
+        for i, k in enumerate(KEYS):
+            ref = g[f"{name}_grad{i}"]
+            assert bool(torch.isfinite(gmaps[k]).all())
+            gate(f"[boxdiff {name}] map gradient {k} rel-L2", rel_l2(gmaps[k], ref), 2e-3)
+            gate(f"[boxdiff {name}] map gradient {k} max error / max", relerr(gmaps[k], ref), 5e-3)
+        # value only (no gradient maps bound), and the amp / grad scales
+        t.bind(maps, None)
+        assert abs(float(t.run()[0]) - float(loss[0])) == 0.0
+        t.loss_scale = 10.0
+        t.bind(maps, gmaps)
+        l10 = t.run(grad_scale=64.0)
+        torch.cuda.synchronize()
+        assert abs(float(l10[0]) - 10 * float(loss[0])) <= 1e-5 * abs(10 * float(loss[0]))
+        gate(f"[boxdiff {name}] scaled gradient", rel_l2(gmaps[KEYS[0]] / 640.0, g[f"{name}_grad0"]), 2e-3)
+
+
+def test_boxdiff_kernel_batched_images_match_single(dev):
+    """merged tables (one workgroup per image, an unguided image in between) reproduce the single-image results bit for
+    bit; no smoothing path (`smooth_attentions=False`) runs and differs."""
+    g = np.load(os.path.join(GOLD, "boxdiff_energy.npz"))
+    names = ("hw256", "two_boxes", "edge")
+    singles, tabs, maps = [], [], []
+    for name in names:
+        spec, t = _tables(dev, g, name)
+        m = {k: torch.from_numpy(g[f"{name}_map{i}"]).to(dev) for i, k in enumerate(KEYS)}
+        gm = {k: torch.zeros_like(v) for k, v in m.items()}
+        t.bind(m, gm)
+        singles.append((float(t.run()[0]), {k: v.clone() for k, v in gm.items()}))
+        tabs.append(t)
+        maps.append(m)
+    both = BoxDiffTables.merged([tabs[0], tabs[1], None, tabs[2]])
+    zero = {k: torch.zeros_like(v) for k, v in maps[0].items()}
+    mb = {k: torch.cat([maps[0][k], maps[1][k], zero[k] + 1.0 / 77, maps[2][k]]).contiguous() for k in KEYS}
+    gb = {k: torch.zeros_like(v) for k, v in mb.items()}
+    both.bind(mb, gb)
+    loss = both.run()
+    torch.cuda.synchronize()
+    assert float(loss[2]) == 0.0 and float(gb[KEYS[0]][2].abs().max()) == 0.0
+    for j, b in ((0, 0), (1, 1), (2, 3)):
+        assert float(loss[b]) == singles[j][0]
+        for k in KEYS:
+            assert torch.equal(gb[k][b], singles[j][1][k][0]), (names[j], k)
+    spec = json.loads(str(g["hw256_spec"]))
+    t2 = BoxDiffTables(dev, spec["bboxes"], spec["pos"], KEYS, {k: 256 for k in KEYS}, spec["heads"], loss_scale=1.0,
+                       smooth_attentions=False)
+    t2.bind(maps[0], None)
+    assert abs(float(t2.run()[0]) - singles[0][0]) > 1e-4
+
+
+def _engine(dev):
+    cfg = weights.CONFIGS["tiny"]
+    return cfg, UNetEngine(cfg, dev, weights.synth_state_dict(cfg, 0))
+
+
+def test_boxdiff_steps_teacher_forced_vs_reference_run_golden(dev):
+    """Every step of the reference's own generation/boxdiff.run (tiny network, CPU fp32), replayed ONE AT A TIME from the
+    reference's latents of that step: the BoxDiff gradient step (loss, latents leaving it) and the whole step (+ CFG +
+    DDIM) must land on the reference's next latents; then the free-running generation."""
+    from lgd_amd.pipeline import CachedLayout, boxdiff_generate, convert_box
+    gold = np.load(os.path.join(GOLD, "run_boxdiff_tiny.npz"))
+    cfg, eng = _engine(dev)
+    sm = LMDSampler(eng, DDIMScheduler())
+    for tag in "ab":
+        kw = json.loads(str(gold[f"{tag}_kwargs"]))
+        n = kw["overall_max_index_step"]
+        bboxes, pos = json.loads(str(gold[f"{tag}_bboxes"])), json.loads(str(gold[f"{tag}_object_positions"]))
+        ehs = torch.from_numpy(gold[f"{tag}_text_embeddings"])
+        starts, guided, losses = gold[f"{tag}_starts"], gold[f"{tag}_guided"], gold[f"{tag}_losses"]
+        gd = dict(bboxes=bboxes, object_positions=pos, use_boxdiff=True, max_index_step=n)
+        for i in range(n):
+            tr = []
+            lat, loss, gs = sm.guidance_only(torch.from_numpy(starts[i]), ehs[1:2], 8, i, dict(gd), trace=tr)
+            assert len(tr) == 1 and gs.kind == "boxdiff"
+            gate(f"[boxdiff run {tag}] step {i}: loss rel. error", abs(tr[0]["loss"] - losses[i]) / abs(losses[i]), 3e-3)
+            gate(f"[boxdiff run {tag}] step {i}: latents leaving the BoxDiff step", relerr(lat, guided[i]), 1.5e-2)
+            upd_h, upd_r = lat.cpu() - torch.from_numpy(starts[i]), torch.from_numpy(guided[i] - starts[i])
+            cos = float((upd_h.double().reshape(-1) @ upd_r.double().reshape(-1)) / (upd_h.double().norm() * upd_r.double().norm()))
+            gate(f"[boxdiff run {tag}] step {i}: latent update cosine", cos, 0.999, at_least=True)
+        for i in range(8):
+            out = sm.denoise(torch.from_numpy(starts[i]), ehs, 8, guidance=dict(gd), first_step=i, n_steps=1)
+            want = starts[i + 1] if i < 7 else gold[f"{tag}_final_latents"]
+            assert out["guidance_iters"] == (1 if i < n else 0)
+            gate(f"[boxdiff run {tag}] step {i} teacher-forced ({'guided' if i < n else 'plain'})",
+                 relerr(out["latents_all"][i + 1], want), 3e-2 if i < n else 1e-3)
+        out = sm.denoise(torch.from_numpy(gold[f"{tag}_latents_in"]), ehs, 8, guidance=dict(gd))
+        assert out["guidance_iters"] == n
+        gate(f"[boxdiff run {tag}] free-running final latents", relerr(out["latents"], gold[f"{tag}_final_latents"]), 8e-2)
+    # batched layouts share UNet calls and the energy launch; each image keeps its own result
+    lays = [CachedLayout.synthetic(cfg, [("a cat", [20, 60, 90, 120]), ("a dog", [140, 50, 90, 140])], index=7 + i) for i in range(3)]
+    kwb = dict(num_inference_steps=4, max_index_step=2, height=256, width=256, decode=False)
+    from lgd_amd.pipeline import boxdiff_generate_batch
+    many = boxdiff_generate_batch(sm, lays, **kwb)
+    for lay, rb in zip(lays, many):
+        rs = boxdiff_generate(sm, lay, **kwb)
+        assert rb["guidance_iters"] == rs["guidance_iters"] == 2
+        gate("[boxdiff] batched vs single layout", relerr(rb["latents"], rs["latents"]), 3e-2)
+
+
+def test_boxdiff_plugin_run_and_pipelines_entry(dev):
+    """The drop-in plugin `generation.boxdiff` (version, run(spec, bg_seed, overall_max_index_step) -> .image) and
+    `pipelines.generate_semantic_guidance(..., use_boxdiff=True)` with the kwargs generation/boxdiff.py:100-110 builds:
+    same final latents as the reference's own run() within the free-running tolerance."""
+    sys.path.insert(0, os.path.join(ROOT, "llm-groundeddiffusion_amd", "dropin"))
+    sys.modules.pop("inflect", None)
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "stubs"))
+    import models
+    keep = models.model_dict
+    try:
+        cfg = weights.CONFIGS["tiny"]
+        from lgd_amd.vae import HipVAEDecoder, VAEDecoder
+        torch.manual_seed(5)
+        vae = HipVAEDecoder(VAEDecoder(ch=(128, 64, 64, 64), layers=1).float().eval(), dev)
+        models.model_dict = models.build_model_dict(cfg, weights.synth_state_dict(cfg, 0), vae=vae, tokenizer=FakeTokenizer(),
+                                                    text_encoder=FakeTextEncoder(cfg.cross_attention_dim))
+        import warnings
+        import generation.boxdiff as g
+        from models import pipelines
+        assert g.version == "boxdiff" and [tuple(k) for k in g.overall_guidance_attn_keys] == KEYS
+        g.height = g.width = 256
+        g.num_inference_steps = 8
+        gold = np.load(os.path.join(GOLD, "run_boxdiff_tiny.npz"))
+        for tag, spec in (("a", SPEC), ("b", SPEC3)):
+            kw = json.loads(str(gold[f"{tag}_kwargs"]))
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                out = g.run(spec, **kw)
+            assert out.image.dtype == np.uint8 and out.image.shape == (256, 256, 3)
+            gk = json.loads(str(gold[f"{tag}_guidance_kwargs"]))
+            gk["guidance_attn_keys"] = [tuple(k) for k in gk["guidance_attn_keys"]]
+            ehs = torch.from_numpy(gold[f"{tag}_text_embeddings"])
+            lat, images = pipelines.generate_semantic_guidance(
+                models.model_dict, torch.from_numpy(gold[f"{tag}_latents_in"]), (ehs, ehs[0:1], ehs[1:2]), 8,
+                bboxes=json.loads(str(gold[f"{tag}_bboxes"])), phrases=None,
+                object_positions=json.loads(str(gold[f"{tag}_object_positions"])), guidance_scale=7.5,
+                semantic_guidance_kwargs=dict(gk, ref_ca_saved_attns=None), use_boxdiff=True)[:2]
+            gate(f"[boxdiff plugin {tag}] pipelines.generate_semantic_guidance(use_boxdiff=True) final latents",
+                 relerr(lat, gold[f"{tag}_final_latents"]), 8e-2)
+            # run() is that call on the same seed and prompt (its embeddings come from the plugin's own front end)
+            assert int(np.abs(images[0].astype(np.int32) - out.image.astype(np.int32)).max()) <= 2
+    finally:
+        models.model_dict = keep
