@@ -294,13 +294,17 @@ def test_fullsize_cfg_forward_throughput_table_vs_oracle(dev):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("nb", [4, 8])
+@pytest.mark.parametrize("nb", [4, 8, 16, 32])
 def test_fullsize_batched_plans_match_b2(dev, nb):
-    """The stage-B (B = 2*4) and stage-A (B = 2*8) plans of the benchmark: every image of the batch is the
-    B = 2 problem again, so each must reproduce the B = 2 result up to the accumulation order of the
-    differently tiled GEMMs."""
+    """The stage-B (B = 2*4) and stage-A (B = 2*8) plans of the benchmark, and the 16- / 32-image plans of its bigger
+    UNet calls (bench.py --group / --max-batch, round 5; built from the shared-GPU table as the lanes build them): every
+    image of the batch is the B = 2 problem again, so each must reproduce the B = 2 result up to the accumulation
+    order of the differently tiled GEMMs."""
     f = full(dev)
     cfg, eng = f["cfg"], f["eng"]
+    if nb > 8:
+        eng = UNetEngine(cfg, dev, weights=f["eng"].w, max_text_batch=2 * nb)
+        eng.tuning_mode = "throughput"
     if ("eps", True) not in _FULL:
         pytest.skip("needs test_fullsize_cfg_forward_vs_oracle[True] in the same session")
     x, ehs, _, gl = _inputs(cfg, dev)
@@ -323,6 +327,9 @@ def test_fullsize_batched_plans_match_b2(dev, nb):
         r = _FULL[("maps", True)][k]
         e = max(max(relerr(m[b], r[0]), relerr(m[nb + b], r[1])) for b in range(nb))
         gate(f"[full B={2 * nb}] map {k} vs B=2", e, 2.8e-2)
+    if nb > 8:                                   # the 48 / 96 GB activation arena of the big plans goes with the engine
+        del plan, eng, m
+        torch.cuda.empty_cache()
 
 
 def test_fullsize_guidance_iteration_vs_oracle(dev):
