@@ -171,6 +171,27 @@ def cpu_baseline(cfg, generations, n_steps, beta, iters_on, iters_off):
                         f"iterations (fuser on + off; VAE excluded)"))
 
 
+def d40_attention_bounds():
+    """What the SIMDs allow the d = 40 self-attention forward (csrc/attn_w4.hip), from MEASURED instruction costs and
+    counts: per 32-query x 32-key score block a wave issues 7 `v_mfma_f32_32x32x16_f16` (3 for Q K^T over d padded to 48,
+    4 for P V over d padded to 64) and 47.8 VALU wave-instructions, 16 of them `v_exp_f32` (one per 64 scores) — PMC of
+    the B = 16, S = 4096 launch: SQ_INSTS_MFMA 14.68 M, SQ_INSTS_VALU 100.26 M (profiles/r04_attn_d40_w4_kernel_pmc_summary.json);
+    cost per wave-instruction and SIMD at one wave per SIMD: MFMA 18.5 ns, v_exp_f32 5.04 ns, plain VALU 1.43 ns
+    (profiles/r03_ubench.txt, at the clock the chip sustains).  MFMA and VALU streams of a SIMD measured additive there
+    ("series"); "overlapped" is the bound if the shorter stream hid completely behind the longer one.  Algorithmic flops
+    of a block: 4 x 32 x 32 x 40."""
+    t_mfma = 7 * 18.5e-9
+    t_valu = 16 * 5.04e-9 + (47.8 - 16) * 1.43e-9
+    fl = 4.0 * 32 * 32 * 40
+    n_simd = 256 * 4
+    return dict(series_tflops=round(fl / (t_mfma + t_valu) * n_simd / 1e12, 1),
+                overlapped_tflops=round(fl / max(t_mfma, t_valu) * n_simd / 1e12, 1),
+                mfma_only_tflops=round(fl / t_mfma * n_simd / 1e12, 1),
+                mfma_ns_per_block=round(t_mfma * 1e9, 1), valu_ns_per_block=round(t_valu * 1e9, 1),
+                source="profiles/r04_attn_d40_w4_kernel_pmc_summary.json (instruction counts), profiles/r03_ubench.txt "
+                       "(ns per wave-instruction per SIMD); d padded 40 -> 48 / 64 costs 29 % of the MFMA slots")
+
+
 class ClockSampler:
     """Shader clock of this rank's GPU while the timed region runs: the current level of the driver's
     `pp_dpm_sclk` table (sysfs; a file read every 0.25 s from a host thread that otherwise sleeps), so that a line's
@@ -680,7 +701,8 @@ def main():
             # HBM bytes per launch come from a committed PMC summary of THIS command's short form (PMC passes serialise
             # every dispatch: they cannot run inside the timed region) — the source file is named in the record
             traffic, traffic_note, traffic_source = None, "no PMC summary for this kernel under profiles/", None
-            for fname in ("r04_bench_traffic_pmc.json", "r03_bench_traffic_pmc.json", "r02_bench_traffic_pmc.json"):
+            for fname in ("r05_bench_traffic_pmc.json", "r04_bench_traffic_pmc.json", "r03_bench_traffic_pmc.json",
+                          "r02_bench_traffic_pmc.json"):
                 tpath = os.path.join(ROOT, "profiles", fname)
                 if not os.path.exists(tpath):
                     continue
@@ -715,7 +737,13 @@ def main():
                             attention_path=(dict(what="q/k/v/out projections + SDPA (self, GLIGEN fuser, cross)",
                                                  ms_per_image=round(ap_["ms"], 1),
                                                  tflops=round(ap_["flops"] / (ap_["ms"] * 1e-3) / 1e12, 1),
-                                                 frac_of_mfma_peak=round(ap_["flops"] / (ap_["ms"] * 1e-3) / MFMA_PEAK_F16, 4))
+                                                 frac_of_mfma_peak=round(ap_["flops"] / (ap_["ms"] * 1e-3) / MFMA_PEAK_F16, 4),
+                                                 # the kernel that carries 60 % of the path's time, against what its
+                                                 # instruction mix allows (the 40 % target reads against THIS, not 2.5 PF)
+                                                 d40_self_attention=dict(
+                                                     measured_tflops=(lambda v: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v else None)(
+                                                         agg.get("attn_self_kernel d=40")),
+                                                     **d40_attention_bounds()))
                                             if ap_ else None),
                             attention_backward=(lambda b_: dict(what="flash backward (dQ, dK/dV) + cross-attention dQ of the guidance "
                                                                      "iterations; 10 B H Sq Sk d per self-attention",

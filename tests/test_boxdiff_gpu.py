@@ -58,9 +58,9 @@ def test_boxdiff_kernel_vs_reference_golden(dev):
         maps = {k: torch.from_numpy(g[f"{name}_map{i}"]).to(dev).contiguous() for i, k in enumerate(KEYS)}
         gmaps = {k: torch.full_like(v, float("nan")) for k, v in maps.items()}
         t.bind(maps, gmaps)
-        loss = t.run(grad_scale=1.0)
+        l1 = float(t.run(grad_scale=1.0)[0])                 # (run() returns the tables' own loss buffer)
         torch.cuda.synchronize()
-        gate(f"[boxdiff {name}] loss rel. error", abs(float(loss[0]) - float(g[f"{name}_loss"])) / abs(float(g[f"{name}_loss"])), 3e-5)
+        gate(f"[boxdiff {name}] loss rel. error", abs(l1 - float(g[f"{name}_loss"])) / abs(float(g[f"{name}_loss"])), 3e-5)
         for i, k in enumerate(KEYS):
             ref = g[f"{name}_grad{i}"]
             assert bool(torch.isfinite(gmaps[k]).all())
@@ -68,12 +68,12 @@ def test_boxdiff_kernel_vs_reference_golden(dev):
             gate(f"[boxdiff {name}] map gradient {k} max error / max", relerr(gmaps[k], ref), 5e-3)
         # value only (no gradient maps bound), and the amp / grad scales
         t.bind(maps, None)
-        assert abs(float(t.run()[0]) - float(loss[0])) == 0.0
+        assert float(t.run()[0]) == l1
         t.loss_scale = 10.0
         t.bind(maps, gmaps)
-        l10 = t.run(grad_scale=64.0)
+        l10 = float(t.run(grad_scale=64.0)[0])
         torch.cuda.synchronize()
-        assert abs(float(l10[0]) - 10 * float(loss[0])) <= 1e-5 * abs(10 * float(loss[0]))
+        assert abs(l10 - 10 * l1) <= 1e-5 * abs(10 * l1)
         gate(f"[boxdiff {name}] scaled gradient", rel_l2(gmaps[KEYS[0]] / 640.0, g[f"{name}_grad0"]), 2e-3)
 
 
@@ -88,7 +88,7 @@ def test_boxdiff_kernel_batched_images_match_single(dev):
         m = {k: torch.from_numpy(g[f"{name}_map{i}"]).to(dev) for i, k in enumerate(KEYS)}
         gm = {k: torch.zeros_like(v) for k, v in m.items()}
         t.bind(m, gm)
-        singles.append((float(t.run()[0]), {k: v.clone() for k, v in gm.items()}))
+        singles.append((float(t.run()[0]), {k: v.clone() for k, v in gm.items()}))          # float(): a copy of the value
         tabs.append(t)
         maps.append(m)
     both = BoxDiffTables.merged([tabs[0], tabs[1], None, tabs[2]])

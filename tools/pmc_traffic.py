@@ -5,8 +5,9 @@
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB-like units of the TCC request counters; on gfx950
 FETCH_SIZE counts 128-B read requests at 64 B (MI355X_MICROARCH.md, HBM section), so fetched bytes are
 doubled here; WRITE_SIZE is left as reported (uncalibrated, per the same section)."""
-import csv, json, sys
+import csv, json, os, sys
 from collections import defaultdict
+BY_GRID = os.environ.get("PMC_BY_GRID", "0") == "1"     # one entry per (kernel, grid size): separates the launch shapes
 out = sys.argv[1]
 agg = defaultdict(lambda: defaultdict(float))
 cnt = defaultdict(lambda: defaultdict(int))
@@ -14,6 +15,8 @@ for path in sys.argv[2:]:
     with open(path) as fh:
         for r in csv.DictReader(fh):
             k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
+            if BY_GRID and r.get("Grid_Size"):
+                k += f" grid={r['Grid_Size']}"
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[k][r["Counter_Name"]] += 1
 res = {}
