@@ -195,14 +195,24 @@ def d40_attention_bounds():
 class ClockSampler:
     """Shader clock of this rank's GPU while the timed region runs: the current level of the driver's
     `pp_dpm_sclk` table (sysfs; a file read every 0.25 s from a host thread that otherwise sleeps), so that a line's
-    TF/s can be read against the clock the chip actually held (the 2.5 PF peak is quoted at 2.4 GHz).  Reports
-    None where the file is absent or has no current-level mark."""
+    TF/s can be read against the clock the chip actually held (the 2.5 PF peak is quoted at 2.4 GHz).  The file lists
+    "0: min, 1: CURRENT *, 2: max" on this driver (fine-grained DPM).  Reports None where the file is absent, the device's
+    PCI address cannot be matched or there is no current-level mark."""
 
     def __init__(self, index: int, period: float = 0.25):
         import glob
         import threading
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.path = cards[index] if index < len(cards) else None
+        # the box may expose the sysfs nodes of every GPU of the node: take the card whose PCI address is THIS device's
+        self.path = None
+        try:
+            import torch
+            p = torch.cuda.get_device_properties(index)
+            want = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}."
+            for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+                if want in os.path.realpath(os.path.dirname(f)):
+                    self.path = f
+        except Exception:          # noqa: BLE001 - no PCI identity, no clock record
+            pass
         self.period, self.samples, self._stop = period, [], threading.Event()
         self._thread = threading.Thread(target=self._run, name="lgd-clock-sampler", daemon=True)
 
@@ -415,7 +425,9 @@ def main():
                          "0 = auto: the steps split evenly over the lanes, at most --group-max per job")
     ap.add_argument("--group-max", type=int, default=5, help="--group 0: most steps a lane job may take")
     ap.add_argument("--max-batch", type=int, default=8, help="images per UNet call, unguided generations (LMDSampler.max_batch)")
-    ap.add_argument("--max-batch-guided", type=int, default=4, help="images per UNet call, guided generations")
+    ap.add_argument("--max-batch-guided", type=int, default=8,
+                    help="images per UNet call, guided generations (the default workload has 4 per step; the guided per-box "
+                         "stage of --workload lmd has 8: one call of 8 measured +5.8 %% over two of 4)")
     ap.add_argument("--min-layouts-per-lane", type=int, default=8,
                     help="lmd_v0.1: a lane is added per this many layouts of the rank's share (at most --lanes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -46,6 +46,11 @@ def main():
     import generation.lmd as g
     from utils import utils as ref_utils
     assert g.height == g.width == 512 and g.H == g.W == 64
+    # As written the reference cannot run this configuration: get_token_attnv2 averages the maps saved from step
+    # `attn_aggregation_step_start` = 10 on (generation/lmd.py:36,124-131; utils/attn.py:15-19), which is an empty stack
+    # at 10 steps ("RuntimeError: stack expects a non-empty TensorList", reproduced here).  The module constant is
+    # lowered to 5; its only consumer is the SAM point prompt, which the box-mask stand-in below ignores.
+    g.attn_aggregation_step_start = 5
     rec = dict(phrase_calls=[], compose=[], gens=[])
     o_so = g.generate_single_object_with_box
 
@@ -75,6 +80,12 @@ def main():
             cur["starts"], cur["iters"], cur["losses"] = [], [], []
             t0 = time.time()
             out = fn(*a, **k)
+            if kind == "overall":          # the reference maps of the transfer term, as lmd.run hands them over (aligned)
+                rec["refs"] = k["semantic_guidance_kwargs"]["ref_ca_saved_attns"]
+                rec["sg_kwargs"] = {kk: vv for kk, vv in k["semantic_guidance_kwargs"].items() if kk != "ref_ca_saved_attns"}
+                rec["frozen"] = dict(frozen_steps=a[5], frozen_mask=a[2].detach().clone(), latents_all=a[1].detach().clone())
+            else:
+                rec.setdefault("so_kwargs", []).append(dict(k["semantic_guidance_kwargs"]))
             rec["gens"].append(dict(kind=kind, seconds=time.time() - t0, starts=torch.stack(cur["starts"]), iters=list(cur["iters"]),
                                     losses=list(cur["losses"]), final=out[0].detach().clone(),
                                     latents_in=(a[1][0] if kind == "overall" else a[1]).detach().clone(),
@@ -113,6 +124,20 @@ def main():
         outs[f"g{i}_seconds"] = np.array(x["seconds"])
         print(f"generation {i} ({x['kind']}): {x['seconds']:.1f} s, guidance iterations per step {x['iters']}, "
               f"losses {[round(v, 4) for v in x['losses'][:6]]} ...")
+    # overall stage: reference maps per object / step / key [T, heads, HW] (one box per object in this layout), the
+    # frozen-blend inputs, the guidance kwargs of both stages
+    keys = [tuple(kk) for kk in rec["sg_kwargs"]["guidance_attn_keys"]]
+    for o, per_obj in enumerate(rec["refs"]):
+        boxes = per_obj if isinstance(per_obj[0], list) else [per_obj]
+        assert len(boxes) == 1
+        for ki, kk in enumerate(keys):
+            outs[f"ov_ref_o{o}_k{ki}"] = torch.stack([boxes[0][t][kk][0, :, :, 0] for t in range(STEPS)]).numpy()
+    outs["ov_frozen_steps"] = np.array(rec["frozen"]["frozen_steps"])
+    outs["ov_frozen_mask"] = rec["frozen"]["frozen_mask"].numpy()
+    outs["ov_latents_all"] = rec["frozen"]["latents_all"].numpy()
+    js = lambda d: json.dumps({kk: (vv if not torch.is_tensor(vv) else vv.tolist()) for kk, vv in d.items()}, default=lambda o_: list(o_))
+    outs["ov_guidance_kwargs"] = np.array(js(rec["sg_kwargs"]))
+    outs["so_guidance_kwargs"] = np.array(json.dumps([json.loads(js(d)) for d in rec["so_kwargs"]]))
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "run_lmd_sd15_config1.npz"), **outs)
     summary = dict(what="BASELINE config[0]: the reference's own generation/lmd.run, SD1.5 architecture (seeded synthetic weights), "
                         "fp32, CPU, 1 cached layout (2 boxes), 10 DDIM steps, default arguments, SAM = box masks, VAE = stub",

@@ -50,5 +50,22 @@ PY
       echo "lanes=$1 group=$2 max_batch=$3/$4: $(grep '^{' $OUT/l$1_g$2_b$3.log | tail -1 | cut -c1-130)"
       grep '^{' $OUT/l$1_g$2_b$3.log | tail -1 > $OUT/l$1_g$2_b$3.json
     done ;;
+  final)      # end-of-round validation: full GPU suite + smoke, then the bench lines DESIGN.md / README.md quote (tag = $1)
+    T=${1:-r05}
+    timeout 1200 python -m pytest tests -q -m gpu -x -rP > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+    grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -n 3
+    timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -n 1 $OUT/smoke.log
+    line() { # name, bench args...
+      n=$1; shift
+      timeout 900 python bench.py "$@" > $OUT/$n.log 2>&1
+      grep '^{' $OUT/$n.log | tail -1 > $OUT/${T}_${n}_bench_line.json; echo "$n: $(cut -c1-150 $OUT/${T}_${n}_bench_line.json)"
+    }
+    line bench_driver_command --gpus 1 --steps 20 --warmup 5
+    line bench_default
+    line lmd --workload lmd --steps 8 --warmup 2
+    line lmd_v0.1_100prompts --workload lmd_v0.1 --prompts 100 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline
+    line lmd_v0.1_400prompts --workload lmd_v0.1 --prompts 400 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline
+    line backward_guidance_sd21 --workload backward_guidance --steps 4 --warmup 1 --no-cpu-baseline
+    line sdxl_refiner --workload sdxl_refiner --steps 2 --warmup 1 --no-cpu-baseline ;;
   *) echo "unknown stage $STAGE"; exit 2 ;;
 esac
