@@ -90,7 +90,10 @@ def main():
                                     losses=list(cur["losses"]), final=out[0].detach().clone(),
                                     latents_in=(a[1][0] if kind == "overall" else a[1]).detach().clone(),
                                     text_embeddings=(a[3][0] if kind == "overall" else a[2][0]).detach().clone(),
-                                    bboxes=k.get("bboxes"), object_positions=k.get("object_positions")))
+                                    # the per-box stage passes bboxes / phrases / object_positions positionally
+                                    # (lmd.py:99-106), the overall stage by keyword (lmd.py:538-540)
+                                    bboxes=k["bboxes"] if "bboxes" in k else a[4],
+                                    object_positions=k["object_positions"] if "object_positions" in k else a[6]))
             return out
         return inner
 

@@ -10,8 +10,9 @@ latents, the final latents.  Here the HIP engine (fp16 compute, INTEGRATION.md "
     (per-box: the box energy; overall: + reference-attention transfer), CFG pass, DDIM update, frozen blend;
   * the whole `run()` free-running through `lgd_amd.pipeline.lmd_generate` (= the plugin's body) from the same seeds.
 
-Tolerances: teacher-forced steps as the guided GLIGEN twin of tests/test_bench_path_gpu.py; the free-running run
-inherits the chaos of ~35 guidance iterations per generation behind the energy's top-k selection."""
+Tolerances: teacher-forced steps at 3x what MI355X measured against the reference's own states (overall generation: every
+guidance loss <= 2.3e-4, latents 8.0e-3 after step 0, <= 8.3e-4 after every later step); the free-running run inherits the
+chaos of ~35 guidance iterations per generation behind the energy's top-k selection."""
 import json
 import os
 import sys
@@ -75,12 +76,13 @@ def _check_steps(sm, tag, starts, final, iters, losses, loss_scale, ehs, lim_gui
         if iters[s]:
             got = np.array([x["loss"] for x in tr]) / loss_scale
             ref = losses[n0:n0 + int(iters[s])]
-            gate(f"[config 1, {tag}] step {s}: {int(iters[s])} guidance losses, max rel. error", float(np.abs(got - ref).max() / np.abs(ref).max()), 2e-2)
+            gate(f"[config 1, {tag}] step {s}: {int(iters[s])} guidance losses, max rel. error", float(np.abs(got - ref).max() / np.abs(ref).max()), 1e-3)
         n0 += int(iters[s])
         e = relerr(out["latents_all"][s + 1], want)
         worst = max(worst, e)
+        # step 0 starts from noise with the largest updates (4 iterations x sqrt(1 - abar) ~ 1): its own limit
         gate(f"[config 1, {tag}] step {s} teacher-forced ({int(iters[s])} guidance iterations): latents relerr", e,
-             lim_guided if iters[s] else 1e-3)
+             (lim_guided if s == 0 else lim_guided / 10) if iters[s] else 1e-3)
     return worst
 
 
@@ -95,7 +97,7 @@ def test_config1_per_box_generations_teacher_forced_vs_the_reference_run(dev):
         ehs = torch.from_numpy(g[f"g{i}_text_embeddings"])
         assert relerr(g[f"g{i}_starts"][0], g[f"g{i}_latents_in"]) == 0.0
         _check_steps(sm, f"per-box generation {i}", g[f"g{i}_starts"], g[f"g{i}_final"], g[f"g{i}_iters"], g[f"g{i}_losses"],
-                     gd["loss_scale"], ehs, 6e-2, guidance=gd, saved_cross_attn_keys=[OBJ_KEY, *gd["guidance_attn_keys"]],
+                     gd["loss_scale"], ehs, 3e-2, guidance=gd, saved_cross_attn_keys=[OBJ_KEY, *gd["guidance_attn_keys"]],
                      return_cond_ca_only=True, return_token_ca_only=gd["object_positions"][0][-1])
 
 
@@ -126,8 +128,9 @@ def test_config1_overall_generation_teacher_forced_vs_the_reference_run(dev):
         h = hist_ref.clone()
         h[0] = torch.from_numpy(g["g2_starts"][step])
         return h
+    # measured on MI355X: losses <= 2.3e-4; latents 8.0e-3 after step 0 (4 iterations from noise), <= 8.3e-4 after every later step
     _check_steps(sm, "overall generation", g["g2_starts"], g["g2_final"], g["g2_iters"], g["g2_losses"], kw["loss_scale"], ehs,
-                 6e-2, guidance=gd, frozen_steps=fs, frozen_mask=fm, hist=hist)
+                 2.5e-2, guidance=gd, frozen_steps=fs, frozen_mask=fm, hist=hist)
 
 
 def test_config1_whole_run_free_running_vs_the_reference_run(dev):
