@@ -52,7 +52,7 @@ PY
     done ;;
   final)      # end-of-round validation: full GPU suite + smoke, then the bench lines DESIGN.md / README.md quote (tag = $1)
     T=${1:-r05}
-    timeout 1200 python -m pytest tests -q -m gpu -x -rP > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+    timeout 1500 python -m pytest tests -q -m gpu -rP > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
     grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -n 3
     timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -n 1 $OUT/smoke.log
     line() { # name, bench args...
