@@ -301,6 +301,8 @@ int lgd_sam_window_merge_f16(const void* oa, void* out, int B, int Hs, int Ws, i
  *   partial: fp32 [n_items*H] workspace; loss: fp32[1] = sum of all terms.
  *   grad_scale multiplies the map gradients only (static loss scaling for the fp16 backward pass;
  *   undone by the out_scale of the final conv_in dgrad).
+ *   max_hw <= 4096 (ABI v9; 1024 before): guidance keys at the 64x64 level of a 512^2 SD 1.x network are legal, as
+ *   utils/guidance.py accepts any `guidance_attn_keys`; larger maps return LGD_ERR_ARG.
  * ------------------------------------------------------------------------------------------- */
 int lgd_ca_energy_f32(const float* const* maps, float* const* gmaps, const int32_t* map_hw,
                       const int32_t* items, const float* coefs, const float* masks, const float* refs,

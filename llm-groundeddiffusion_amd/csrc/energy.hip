@@ -8,12 +8,12 @@
 // loss_scale at models/pipelines.py:48.
 //
 // grid = (heads, n_groups); one workgroup evaluates, for one head, all items that touch the same column
-// (map, image, token) of <= 1024 spatial positions, one after the other, accumulating their map gradients in
+// (map, image, token) of <= 4096 spatial positions (round 5: 64x64 guidance keys), one after the other, accumulating their map gradients in
 // LDS and storing the column once: no atomics, so the gradient (and through it the data-dependent
 // iteration count of the guidance loop) is bit-reproducible however many terms share a token column (a
 // phrase with several boxes contributes one reference term per box on top of its box term).
 // top-k is done by exact ranking (count of greater elements, index tie-break) from LDS — k-independent,
-// deterministic, O(HW^2/256) per thread with HW<=1024.
+// deterministic, O(HW^2/256) per thread (HW = 256: 256 comparisons per position; HW = 4096: 16 positions x 4096 each).
 // Every normalisation of the reference (1/len(tokens), 1/(n_obj*n_keys), mean over heads for the
 // reference term, loss_scale) is folded into the per-item coefficients by the host.
 #include "common.h"
@@ -21,7 +21,7 @@
 
 namespace {
 
-constexpr int E_MAXHW = 1024;
+constexpr int E_MAXHW = 4096;     // 3 x 16 KB of LDS: every cross-attention map of SD 1.x at 512^2 (the 64x64 level included)
 constexpr float REF_EPS = 1e-5f;  // guidance.py:150 (eps=1e-5)
 
 __global__ __launch_bounds__(256) void ca_energy_kernel(

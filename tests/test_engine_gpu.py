@@ -115,6 +115,45 @@ def test_energy_kernel_vs_reference_golden(dev):
             assert relerr(gmaps[k], g[f"grad_{tag}_{ks(k)}"][0]) < 1e-4, (tag, k)
 
 
+def test_energy_kernel_on_64x64_guidance_keys_vs_oracle(dev):
+    """`guidance_attn_keys` is a free argument of the reference (utils/guidance.py:244-286): keys at the 64x64 level of a
+    512^2 network have 4096 positions per map.  The kernel's per-column LDS arrays hold that since round 5 (1024 before:
+    LGD_ERR_ARG); value and map gradients vs oracle/restate.py (itself pinned to the reference's function) on a mix of a
+    64x64 and a 16x16 key, max-based branch with a reference-attention term and the ratio branch."""
+    import restate as R
+    keys = [("up", 3, 0, 0), ("up", 1, 1, 0)]
+    hw = {keys[0]: 4096, keys[1]: 256}
+    g = torch.Generator().manual_seed(11)
+    maps_cpu = {k: (torch.randn((1, 8, hw[k], 77), generator=g) * 1.5).softmax(dim=-1) for k in keys}
+    refs_cpu = [[{k: torch.rand((1, 8, hw[k], 1), generator=g) / hw[k] for k in keys}] for _ in range(2)]    # [obj][step]
+    dyn = torch.tensor([0, 0, 0, 0], dtype=torch.int32, device=dev)
+    for tag, kw, okw in (("max-based + reference term", dict(use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0,
+                                                            bg_weight=4.0, ref_boxes=True, ref_ca_loss_weight=2.0,
+                                                            ref_ca_word_token_only=True, word_token_indices=WORD_TOK),
+                          dict(use_ratio_based_loss=False, fg_top_p=0.2, bg_top_p=0.2, fg_weight=1.0, bg_weight=4.0,
+                               ref_ca_saved_attns=refs_cpu, ref_ca_loss_weight=2.0, ref_ca_word_token_only=True,
+                               word_token_indices=WORD_TOK, index=0)),
+                         ("ratio", dict(), dict())):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in maps_cpu.items()}
+        ref_loss = R.compute_ca_lossv3(leaves, BBOXES, OBJ_POS, keys, **okw)
+        ref_grads = torch.autograd.grad(ref_loss, [leaves[k] for k in keys])
+        en = EnergyTables(dev, BBOXES, OBJ_POS, keys, hw, 8, 77, loss_scale=1.0, **kw)
+        assert en.max_hw == 4096
+        if kw.get("ref_boxes"):
+            refs = torch.zeros(1, en.n_refs, 8, en.max_hw)
+            for rid, (o, bi, ki) in enumerate(en.ref_slots):
+                refs[0, rid, :, :hw[keys[ki]]] = refs_cpu[o][0][keys[ki]][0, :, :, 0]
+            en.set_refs(refs)
+        maps = {k: v[0].to(dev).contiguous() for k, v in maps_cpu.items()}
+        gmaps = {k: torch.zeros_like(v) for k, v in maps.items()}
+        en.bind(maps, gmaps)
+        loss = en.run(dyn, grad_scale=1.0)
+        torch.cuda.synchronize()
+        gate(f"[energy, 64x64 key, {tag}] value", relerr(loss, ref_loss.detach()), 1e-5)
+        for k, gr in zip(keys, ref_grads):
+            gate(f"[energy, 64x64 key, {tag}] map gradient {k}", relerr(gmaps[k], gr[0]), 1e-4)
+
+
 def test_ratio_energy_kernel_vs_reference_golden(dev):
     """The ratio-based branch (utils/guidance.py:118-130; the default of add_ca_loss_per_attn_map_to_loss and what
     generation/backward_guidance.py runs) against value + map gradients of the reference's OWN compute_ca_lossv3 called
