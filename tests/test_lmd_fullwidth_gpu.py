@@ -96,21 +96,24 @@ def test_sd15_stage_a_guided_semantic_guidance_with_map_saving_vs_oracle(dev):
     torch.cuda.synchronize()
     assert out["guidance_iters"] == 2
     for i in range(T):
-        gate(f"[sd15 stage A] latents after step {i} (free-running): relerr", relerr(out["latents_all"][i + 1], hist_ref[i + 1]), 1.5e-2)
-        gate(f"[sd15 stage A] latents after step {i} (free-running): rel-L2", rel_l2(out["latents_all"][i + 1], hist_ref[i + 1]), 5e-3)
+        # measured on MI355X: 4.2e-3 / 3.2e-3 after both steps; limits within 3x of that
+        gate(f"[sd15 stage A] latents after step {i} (free-running): relerr", relerr(out["latents_all"][i + 1], hist_ref[i + 1]), 1.2e-2)
+        gate(f"[sd15 stage A] latents after step {i} (free-running): rel-L2", rel_l2(out["latents_all"][i + 1], hist_ref[i + 1]), 8e-3)
     for k in [OBJ_KEY, *KEYS]:
         assert tuple(out["saved"][k].shape[1:]) == (1, 8, saved_ref[0][k].shape[2], 1)      # (T, 1, heads, HW, 1)
         # step 0's map sits behind ONE guided iteration from identical latents; step 1's behind the free-running state
-        gate(f"[sd15 stage A] saved map {k} step 0 rel-L2", rel_l2(out["saved"][k][0], saved_ref[0][k]), 1.5e-2)
-        gate(f"[sd15 stage A] saved map {k} step 1 rel-L2", rel_l2(out["saved"][k][1], saved_ref[1][k]), 3e-2)
+        # measured: step 0 3.7e-3 ... 1.04e-2, step 1 7.5e-3 ... 2.5e-2 (the 8x8 mid-block map moves most)
+        gate(f"[sd15 stage A] saved map {k} step 0 rel-L2", rel_l2(out["saved"][k][0], saved_ref[0][k]), 2.5e-2)
+        gate(f"[sd15 stage A] saved map {k} step 1 rel-L2", rel_l2(out["saved"][k][1], saved_ref[1][k]), 6e-2)
     # teacher-forced: step 1 alone, from the ORACLE's latents after step 0
     out1 = sm.denoise(hist_ref[1], s["ehs"], T, first_step=1, n_steps=1, **kw)
     torch.cuda.synchronize()
     assert out1["guidance_iters"] == 1
-    gate("[sd15 stage A] teacher-forced step 1: latents relerr", relerr(out1["latents_all"][2], hist_ref[2]), 1e-2)
-    gate("[sd15 stage A] teacher-forced step 1: latents rel-L2", rel_l2(out1["latents_all"][2], hist_ref[2]), 4e-3)
+    # measured: latents 1.3e-5 / 1.2e-5 (the guided update at step 1 is small against the latents), maps <= 8.9e-3
+    gate("[sd15 stage A] teacher-forced step 1: latents relerr", relerr(out1["latents_all"][2], hist_ref[2]), 1e-4)
+    gate("[sd15 stage A] teacher-forced step 1: latents rel-L2", rel_l2(out1["latents_all"][2], hist_ref[2]), 1e-4)
     for k in [OBJ_KEY, *KEYS]:
-        gate(f"[sd15 stage A] teacher-forced step 1: saved map {k} rel-L2", rel_l2(out1["saved"][k][1], saved_ref[1][k]), 1.5e-2)
+        gate(f"[sd15 stage A] teacher-forced step 1: saved map {k} rel-L2", rel_l2(out1["saved"][k][1], saved_ref[1][k]), 2.5e-2)
 
 
 def test_sd15_stage_b_partial_frozen_with_reference_attention_vs_oracle(dev):
@@ -152,8 +155,9 @@ def test_sd15_stage_b_partial_frozen_with_reference_attention_vs_oracle(dev):
                                   per_step=per_step, trace=tr)
     assert out["guidance_iters"] == 2 and len(tr) == 2
     for i in range(T):
-        gate(f"[sd15 stage B] latents after step {i}: relerr", relerr(out["latents_all"][i + 1], per_step[i]), 1.5e-2)
-        gate(f"[sd15 stage B] latents after step {i}: rel-L2", rel_l2(out["latents_all"][i + 1], per_step[i]), 5e-3)
+        # measured: 3.3e-3 / 3.1e-3
+        gate(f"[sd15 stage B] latents after step {i}: relerr", relerr(out["latents_all"][i + 1], per_step[i]), 1e-2)
+        gate(f"[sd15 stage B] latents after step {i}: rel-L2", rel_l2(out["latents_all"][i + 1], per_step[i]), 8e-3)
 
 
 def test_sd15_per_box_stage_at_benchmark_batch_matches_single(dev):
@@ -169,6 +173,7 @@ def test_sd15_per_box_stage_at_benchmark_batch_matches_single(dev):
     torch.cuda.synchronize()
     for b, r in enumerate(res):
         assert r["guidance_iters"] == 2
-        gate(f"[sd15 stage A, B=4] image {b} final latents vs B=1", relerr(r["latents"], one["latents"]), 1.5e-2)
+        # measured: 4.3e-3 / 1.16e-2 (differently tiled GEMMs in front of a guided step's top-k selection)
+        gate(f"[sd15 stage A, B=4] image {b} final latents vs B=1", relerr(r["latents"], one["latents"]), 1.3e-2)
         gate(f"[sd15 stage A, B=4] image {b} saved obj-key map (step 1) vs B=1 rel-L2",
-             rel_l2(r["saved"][OBJ_KEY][1], one["saved"][OBJ_KEY][1]), 2e-2)
+             rel_l2(r["saved"][OBJ_KEY][1], one["saved"][OBJ_KEY][1]), 3e-2)
