@@ -151,7 +151,8 @@ def test_boxdiff_steps_teacher_forced_vs_reference_run_golden(dev):
                  relerr(out["latents_all"][i + 1], want), (8e-2 if i == 0 else 4e-3) if i < n else 3e-4)
         out = sm.denoise(torch.from_numpy(gold[f"{tag}_latents_in"]), ehs, 8, guidance=dict(gd))
         assert out["guidance_iters"] == n
-        gate(f"[boxdiff run {tag}] free-running final latents", relerr(out["latents"], gold[f"{tag}_final_latents"]), 8e-2)
+        gate(f"[boxdiff run {tag}] free-running final latents", relerr(out["latents"], gold[f"{tag}_final_latents"]),
+             dict(a=8e-2, b=1.3e-1)[tag])                       # measured 2.9e-2 / 4.6e-2
     # batched layouts share UNet calls and the energy launch; each image keeps its own result
     lays = [CachedLayout.synthetic(cfg, [("a cat", [20, 60, 90, 120]), ("a dog", [140, 50, 90, 140])], index=7 + i) for i in range(3)]
     kwb = dict(num_inference_steps=4, max_index_step=2, height=256, width=256, decode=False)
@@ -201,7 +202,7 @@ def test_boxdiff_plugin_run_and_pipelines_entry(dev):
                 object_positions=json.loads(str(gold[f"{tag}_object_positions"])), guidance_scale=7.5,
                 semantic_guidance_kwargs=dict(gk, ref_ca_saved_attns=None), use_boxdiff=True)[:2]
             gate(f"[boxdiff plugin {tag}] pipelines.generate_semantic_guidance(use_boxdiff=True) final latents",
-                 relerr(lat, gold[f"{tag}_final_latents"]), 8e-2)
+                 relerr(lat, gold[f"{tag}_final_latents"]), dict(a=8e-2, b=1.3e-1)[tag])
             # run() is that call on the same seed and prompt (its embeddings come from the plugin's own front end)
             assert int(np.abs(images[0].astype(np.int32) - out.image.astype(np.int32)).max()) <= 2
     finally:

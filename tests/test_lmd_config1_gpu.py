@@ -11,8 +11,9 @@ latents, the final latents.  Here the HIP engine (fp16 compute, INTEGRATION.md "
   * the whole `run()` free-running through `lgd_amd.pipeline.lmd_generate` (= the plugin's body) from the same seeds.
 
 Tolerances: teacher-forced steps at 3x what MI355X measured against the reference's own states (overall generation: every
-guidance loss <= 2.3e-4, latents 8.0e-3 after step 0, <= 8.3e-4 after every later step); the free-running run inherits the
-chaos of ~35 guidance iterations per generation behind the energy's top-k selection."""
+guidance loss <= 2.3e-4, latents 8.0e-3 after step 0, <= 8.3e-4 after every later step; per-box generations 6.7e-3 / <= 2.4e-3);
+the free-running run — 3 x 35 guidance iterations behind the energy's top-k selection — lands on the reference's composed
+latents within 1.6e-2 and on its final latents within 7.6e-3 (rel-L2)."""
 import json
 import os
 import sys
@@ -64,7 +65,7 @@ def _so_guidance(g, i):
     return dict(bboxes=json.loads(str(g[f"g{i}_bboxes"])), object_positions=json.loads(str(g[f"g{i}_object_positions"])), **kw)
 
 
-def _check_steps(sm, tag, starts, final, iters, losses, loss_scale, ehs, lim_guided, **kw):
+def _check_steps(sm, tag, starts, final, iters, losses, loss_scale, ehs, lim_guided, lim_later, **kw):
     n0 = 0
     worst = 0.0
     for s in range(T):
@@ -82,7 +83,7 @@ def _check_steps(sm, tag, starts, final, iters, losses, loss_scale, ehs, lim_gui
         worst = max(worst, e)
         # step 0 starts from noise with the largest updates (4 iterations x sqrt(1 - abar) ~ 1): its own limit
         gate(f"[config 1, {tag}] step {s} teacher-forced ({int(iters[s])} guidance iterations): latents relerr", e,
-             (lim_guided if s == 0 else lim_guided / 10) if iters[s] else 1e-3)
+             (lim_guided if s == 0 else lim_later) if iters[s] else 1e-3)
     return worst
 
 
@@ -97,7 +98,7 @@ def test_config1_per_box_generations_teacher_forced_vs_the_reference_run(dev):
         ehs = torch.from_numpy(g[f"g{i}_text_embeddings"])
         assert relerr(g[f"g{i}_starts"][0], g[f"g{i}_latents_in"]) == 0.0
         _check_steps(sm, f"per-box generation {i}", g[f"g{i}_starts"], g[f"g{i}_final"], g[f"g{i}_iters"], g[f"g{i}_losses"],
-                     gd["loss_scale"], ehs, 3e-2, guidance=gd, saved_cross_attn_keys=[OBJ_KEY, *gd["guidance_attn_keys"]],
+                     gd["loss_scale"], ehs, 2e-2, 7e-3, guidance=gd,       # measured: step 0 6.7e-3 / 6.3e-3; later <= 2.4e-3 saved_cross_attn_keys=[OBJ_KEY, *gd["guidance_attn_keys"]],
                      return_cond_ca_only=True, return_token_ca_only=gd["object_positions"][0][-1])
 
 
@@ -130,7 +131,7 @@ def test_config1_overall_generation_teacher_forced_vs_the_reference_run(dev):
         return h
     # measured on MI355X: losses <= 2.3e-4; latents 8.0e-3 after step 0 (4 iterations from noise), <= 8.3e-4 after every later step
     _check_steps(sm, "overall generation", g["g2_starts"], g["g2_final"], g["g2_iters"], g["g2_losses"], kw["loss_scale"], ehs,
-                 2.5e-2, guidance=gd, frozen_steps=fs, frozen_mask=fm, hist=hist)
+                 2.5e-2, 2.5e-3, guidance=gd, frozen_steps=fs, frozen_mask=fm, hist=hist)
 
 
 def test_config1_whole_run_free_running_vs_the_reference_run(dev):
@@ -157,6 +158,7 @@ def test_config1_whole_run_free_running_vs_the_reference_run(dev):
     assert torch.equal(out["fg_idx"].cpu(), torch.from_numpy(g["fg_idx"]))
     assert out["so_guidance_iters"] == [int(g["g0_iters"].sum()), int(g["g1_iters"].sum())]
     assert out["guidance_iters"] == int(g["g2_iters"].sum())
-    gate("[config 1, run] composed latents (two free-running guided per-box generations)", relerr(out["composed"], g["composed"]), 2.5e-1)
-    gate("[config 1, run] composed latents rel-L2", rel_l2(out["composed"], g["composed"]), 8e-2)
-    gate("[config 1, run] final latents rel-L2 (free-running, 3 x 35 guidance iterations)", rel_l2(out["latents"], g["g2_final"]), 1.5e-1)
+    # measured on MI355X against the reference's own full-width fp32 run: 1.6e-2 / 1.0e-2 / 7.6e-3
+    gate("[config 1, run] composed latents (two free-running guided per-box generations)", relerr(out["composed"], g["composed"]), 5e-2)
+    gate("[config 1, run] composed latents rel-L2", rel_l2(out["composed"], g["composed"]), 3e-2)
+    gate("[config 1, run] final latents rel-L2 (free-running, 3 x 35 guidance iterations)", rel_l2(out["latents"], g["g2_final"]), 2.5e-2)
