@@ -50,6 +50,36 @@ PY
       echo "lanes=$1 group=$2 max_batch=$3/$4: $(grep '^{' $OUT/l$1_g$2_b$3.log | tail -1 | cut -c1-130)"
       grep '^{' $OUT/l$1_g$2_b$3.log | tail -1 > $OUT/l$1_g$2_b$3.json
     done ;;
+  retune_ab)  # re-tune the TOP most expensive shapes of the shared-GPU table (4 streams) and A/B it against the committed
+              # table with the driver's command, alternating arms on this box; the candidate table lands in $OUT
+    TOP=${1:-120}
+    cp llm-groundeddiffusion_amd/tuning_gfx950_lanes.json $OUT/lanes_old.json
+    python - <<'PY'
+import json
+a = json.load(open("llm-groundeddiffusion_amd/tuning_gfx950.json")); a.update(json.load(open("llm-groundeddiffusion_amd/tuning_gfx950_lanes.json")))
+json.dump(a, open("gpurun_out/retune_ab/lanes_full.json", "w"), indent=0, sort_keys=True)
+PY
+    arm() { timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/$1.log 2>&1; echo "$1: $(grep '^{' $OUT/$1.log | tail -1 | cut -c1-105)"; }
+    arm A1
+    LGD_TUNE_STREAMS=4 LGD_TUNE_TOP=$TOP timeout ${TUNE_TIMEOUT:-480} python tools/tune_gemm.py sd14_gligen $OUT/lanes_full.json > $OUT/tune.log 2>&1
+    echo "tune rc=$?"; tail -n 2 $OUT/tune.log
+    python - <<'PY'
+import json
+lat = json.load(open("llm-groundeddiffusion_amd/tuning_gfx950.json"))
+old = json.load(open("gpurun_out/retune_ab/lanes_old.json"))
+full = json.load(open("gpurun_out/retune_ab/lanes_full.json"))
+new = {k: v for k, v in full.items() if k not in lat or (lat[k]["tile"], lat[k]["splits"]) != (v["tile"], v["splits"])}
+for k, v in old.items():                     # entries the tuner did not visit stay as they were
+    if k not in new and (k not in lat or (lat[k]["tile"], lat[k]["splits"]) != (v["tile"], v["splits"])) and full.get(k, v) == v:
+        new[k] = v
+json.dump(new, open("gpurun_out/retune_ab/lanes_new.json", "w"), indent=0, sort_keys=True)
+ch = sum(1 for k in new if k not in old or (old[k]["tile"], old[k]["splits"]) != (new[k]["tile"], new[k]["splits"]))
+print("new lanes table:", len(new), "entries,", ch, "differ from the committed one;", sum(1 for k in old if k not in new), "dropped")
+PY
+    cp $OUT/lanes_new.json llm-groundeddiffusion_amd/tuning_gfx950_lanes.json; arm B1
+    cp $OUT/lanes_old.json llm-groundeddiffusion_amd/tuning_gfx950_lanes.json; arm A2
+    cp $OUT/lanes_new.json llm-groundeddiffusion_amd/tuning_gfx950_lanes.json; arm B2
+    cp $OUT/lanes_old.json llm-groundeddiffusion_amd/tuning_gfx950_lanes.json ;;
   final)      # end-of-round validation: full GPU suite + smoke, then the bench lines DESIGN.md / README.md quote (tag = $1)
     T=${1:-r05}
     timeout 1500 python -m pytest tests -q -m gpu -rP > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
