@@ -1481,6 +1481,334 @@ __global__ __launch_bounds__(64 * WM * WN, (pipe_occupancy<MI, NI, NS>())) void 
   }
 }
 
+// Main-loop variant 4 (round 6): PHASE-SPLIT 256-row tiles (256 x 256, 256 x 320), eight waves as 2 (M) x 4 (N).
+//   The lock-step loops above let both waves of a SIMD want the matrix pipe, the LDS and the barrier at the same
+//   moments (PMC, 256 x 128 family: MFMA pipe 29-47 % busy, waits 31-42 %).  Here the K tile is cut into FOUR phases
+//   (one quadrant of the wave's 128 x (64|80) output each, both k-halves), every phase is a LOAD interval (fragment
+//   ds_reads of that quadrant + one quarter of a future K tile's LDS-DMA) and an MFMA interval (16-24 back-to-back
+//   MFMAs under s_setprio 1), separated by bare s_barriers, and the two wave groups (waves 0-3 = rows 0-127 = one wave
+//   per SIMD, waves 4-7 = rows 128-255 = the other wave of each SIMD) run ONE interval apart: while one group
+//   multiplies, the other reads and issues.  One fragment register set suffices (a wave never reads while it
+//   multiplies), the LDS latency hides behind the partner's MFMAs instead of a software prefetch, and the matrix pipe
+//   sees one MFMA stream at a time.
+//   LDS: two stages, each [A_q0 | A_q1 | B_q0 | B_q1]: A_q(h) = the m-tiles h*MI/2.. of BOTH groups, B_q0 / B_q1 = the
+//   first NI0 / last NI1 n-tiles of all four wave columns.  A quarter is read in exactly ONE phase (p0: A_q0 + B_q0,
+//   p1: B_q1, p2: A_q1; B_q0 stays in registers for p3), so it can be re-filled two phases later — the DMA stream never
+//   pauses although there are only two stages (the round-4 two-stage ring issued during half of each K tile):
+//       (kt, p0) issues B_q1 of tile kt+1      (kt, p1) A_q1 of tile kt+1
+//       (kt, p2) issues B_q0 of tile kt+2      (kt, p3) A_q0 of tile kt+2
+//   i.e. every quarter flies for 4-5 phases (> one K tile), and `s_waitcnt vmcnt(T)` (T = DMA instructions per wave per
+//   K tile: "everything older than the last four quarters has landed") at the end of the load intervals of p3 / p0 /
+//   p1 is the only wait on the queue — it never drains.  Hazards (G0 = the early group, G1 one interval later):
+//     RAW  a quarter is read one phase after the vmcnt that retires it: every wave's wait sits in front of the barrier
+//          that closes its load interval, G0's next load interval and G1's lie behind G1's / G0's NEXT barrier;
+//     WAR  G1's reads of phase p retire (lgkmcnt(0)) at the start of its MFMA interval = global interval 2p+2; the
+//          earliest DMA into that quarter is G0's load interval of phase p+2 = global interval 2p+4.
+//   DMA = buffer_load_dwordx4 ... lds through a raw buffer descriptor: per-lane voffset is ONE register per operand
+//   (row order inside a quarter is chosen so that the rows of consecutive instructions differ by a wave-uniform
+//   stride), everything else — K position, tap, row group — is the SCALAR soffset; lanes of rows past M / N, of padded
+//   convolution taps and whole tiles past K get an out-of-range voffset / a zero-length descriptor and the hardware
+//   writes zeros (no zero line, no per-instruction 64-bit address arithmetic: the two-stage rings spent as many scalar as
+//   vector issue slots on it).  Plain single-source contractions and chunk-major 3x3 stride-1 convolutions.
+// ABL (tools only, -DLGD_GEMM_ABLATION; results wrong by design): 1 = no DMA in the loop, 2 = no fragment reads, 4 = no MFMA,
+// 16 = no epilogue, 32 = no s_setprio, 64 = no stagger (both groups in the same interval).
+template <int MI, int NI, bool CM, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void gemm_phase_kernel(const GemmArgs ga) {
+  constexpr int WM = 2, WN = 4;
+  static_assert(MI == 8, "128 rows per wave group");
+  constexpr int MH = MI / 2;                                  // m-tiles per A quarter and group
+  constexpr int NI0 = (NI + 1) / 2, NI1 = NI - NI0;           // n-tiles of a wave in B_q0 / B_q1
+  constexpr int BM = WM * 16 * MI, BN = WN * 16 * NI;
+  constexpr int AQ_B = 2 * 16 * MH * 128;                     // bytes of an A quarter (both groups)
+  constexpr int BQ0_B = 64 * NI0 * 128, BQ1_B = 64 * NI1 * 128;
+  constexpr int OFF_A1 = AQ_B, OFF_B0 = 2 * AQ_B, OFF_B1 = 2 * AQ_B + BQ0_B;
+  constexpr int STAGE_B = 2 * AQ_B + BQ0_B + BQ1_B;           // = (BM + BN) * 128
+  static_assert(STAGE_B == (BM + BN) * BK * 2 && 2 * STAGE_B <= 160 * 1024, "LDS");
+  constexpr int NA = 2;                                       // DMA instructions per wave per A quarter (one per group)
+  constexpr int T_DMA = 2 * NA + NI;                          // per wave per K tile
+  constexpr unsigned OOB = 0x80000000u;                       // >= num_records of every descriptor below
+  constexpr unsigned NREC = 0x80000000u;
+
+  extern __shared__ __attribute__((aligned(1024))) half_t smem[];
+  unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
+
+  const LgdGemmDesc& d = ga.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2, wn = wid & 3;                     // wave group (M half) / wave column
+
+  const int n_tiles_n = (d.N + BN - 1) / BN;
+  const int total_tiles = ((d.M + BM - 1) / BM) * n_tiles_n;
+  int m0, n0;
+  {
+    const int q = total_tiles >> 3, r = total_tiles & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    int tile_m, tile_n;
+    if (ga.group_m > 1) {
+      const int per_group = ga.group_m * n_tiles_n;
+      const int g = bid / per_group, in = bid - g * per_group;
+      const int n_tiles_m = total_tiles / n_tiles_n;
+      int rows = n_tiles_m - g * ga.group_m;
+      if (rows > ga.group_m) rows = ga.group_m;
+      tile_n = in / rows;
+      tile_m = g * ga.group_m + (in - tile_n * rows);
+    } else {
+      tile_m = bid / n_tiles_n;
+      tile_n = bid - tile_m * n_tiles_n;
+    }
+    // integer divisions run on the vector ALU: pin the (uniform) results to SGPRs, or under register pressure everything
+    // derived from them — base pointers, descriptors — stays in VGPRs and every DMA becomes a waterfall loop
+    m0 = __builtin_amdgcn_readfirstlane(tile_m * BM);
+    n0 = __builtin_amdgcn_readfirstlane(tile_n * BN);
+  }
+  // one matrix per launch (the launcher sees to it): blockIdx.z is the split, no batch offsets — their 64-bit products
+  // were computed on the vector ALU and dragged the base pointers, hence every descriptor, into VGPRs
+  const int split = blockIdx.z;
+  constexpr int batch = 0;
+  constexpr long a_off = 0, w_off = 0, c_off = 0, r_off = 0;
+
+  const int k_beg = split * ga.k_per_split;
+  int k_end = k_beg + ga.k_per_split;
+  if (k_end > d.K) k_end = d.K;
+  const int nk = __builtin_amdgcn_readfirstlane((k_end - k_beg) / BK);
+  const int cin = ga.cin;
+
+  // ---- DMA side.  Lane -> (row in the 8-row group, physical 16-B slot); the logical K segment it fetches carries the
+  // source-side swizzle of gemm_dma_kernel (the swizzle term of quarter row (8j + w) * 8 + lrow does not depend on j).
+  const int lrow = lane >> 3;
+  const int kseg = (lane & 7) ^ ((((wid & 1) << 2) + (lrow >> 1)) & 7);
+  const unsigned lda2 = (unsigned)d.lda0 * 2u, ldw2 = (unsigned)d.ldw * 2u;
+  // A quarter rows are [group][m-tile][16]: instruction j of wave w fills group j, rows h*64 + 8w + lrow of its 128
+  const int arow = wid * 8 + lrow;                            // tile row of (j = 0, h = 0)
+  // B quarter rows are [n-tile][wave column][16]: instruction j fills n-tile j, wave column w >> 1, rows 8 (w & 1) + lrow
+  const int bcol = (wid >> 1) * 16 * NI + (wid & 1) * 8 + lrow;   // tile column of (quarter 0, j = 0)
+  // convolution: the centre pixel of output row m is input pixel m (stride 1, same size), the tap is a uniform offset;
+  // the descriptor's base sits (win + 1) pixels in front of the map so that every tap offset is >= 0
+  const half_t* a_base = reinterpret_cast<const half_t*>(d.a0) + a_off - (CM ? (long)(d.win + 1) * d.lda0 : 0L);
+  const half_t* w_base = reinterpret_cast<const half_t*>(d.w) + w_off;
+  const unsigned voffA = (unsigned)(m0 + arow) * lda2 + kseg * 16;
+  const unsigned voffB = (unsigned)(n0 + bcol) * ldw2 + kseg * 16;
+  // validity bits: A (h, j, tap) -> amask[h] bit 9j + tap (plain: tap 0); B n-tile i of the wave column -> bit i
+  unsigned amask[2] = {0u, 0u};
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int m = m0 + j * 128 + h * 16 * MH + arow;
+      if (m >= d.M) continue;
+      if (CM) {
+        const int ox = m % d.wout, oy = (m / d.wout) % d.hout;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+          if (iy >= 0 && ix >= 0 && iy < d.hin && ix < d.win) amask[h] |= 1u << (9 * j + t);
+        }
+      } else {
+        amask[h] |= 1u << (9 * j);
+      }
+    }
+  unsigned bmask = 0;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+    if (n0 + bcol + i * 16 < d.N) bmask |= 1u << i;
+
+  // K position of a tile of the split's range: byte offsets into A and W, and the convolution tap
+  const int t0 = k_beg / BK;
+  auto k_pos = [&](int kt, unsigned& sa, unsigned& sw, int& tap) {
+    if (CM) {
+      const int t = t0 + kt, ch = __builtin_amdgcn_readfirstlane(t / 9);
+      tap = t - ch * 9;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      sa = (unsigned)(ky * d.win + kx) * lda2 + (unsigned)ch * (BK * 2);
+      sw = (unsigned)(tap * cin + ch * BK) * 2u;
+    } else {
+      tap = 0;
+      sa = sw = (unsigned)(k_beg + kt * BK) * 2u;
+    }
+  };
+  // one A quarter (h) / B quarter (q) of the tile at (sa | sw, tap), `live` = the tile exists, into stage offset so
+  auto dma_a = [&](int h, unsigned so, bool live, unsigned sa, int tap, bool inloop = true) {
+    if ((ABL & 1) && inloop) return;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a_base), 0, live ? NREC : 0u, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const unsigned vo = ((amask[h] >> (9 * j + tap)) & 1u) ? voffA : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(lds + so + (h ? OFF_A1 : 0) + (j * 8 + wid) * 1024), 16, vo,
+                                               sa + (unsigned)(j * 128 + h * 16 * MH) * lda2, 0, 0);
+    }
+  };
+  auto dma_b = [&](int q, unsigned so, bool live, unsigned sw, bool inloop = true) {
+    if ((ABL & 1) && inloop) return;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(w_base), 0, live ? NREC : 0u, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < (q ? NI1 : NI0); ++j) {
+      const int i = (q ? NI0 : 0) + j;
+      const unsigned vo = ((bmask >> i) & 1u) ? voffB : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(lds + so + (q ? OFF_B1 : OFF_B0) + (j * 8 + wid) * 1024), 16, vo,
+                                               sw + (unsigned)(i * 16) * ldw2, 0, 0);
+    }
+  };
+
+  // ---- MFMA side: fragment addresses (bytes, stage 0) of this lane, k-half 0 / 1
+  const int frow = lane & 15, fg = lane >> 4, fsw = (frow >> 1) & 7;
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  unsigned a_ad0 = lds0 + (grp * 16 * MH + frow) * 128 + ((0 + fg) ^ fsw) * 16;
+  unsigned a_ad1 = lds0 + (grp * 16 * MH + frow) * 128 + ((4 + fg) ^ fsw) * 16;
+  unsigned b_ad0 = lds0 + OFF_B0 + (wn * 16 + frow) * 128 + ((0 + fg) ^ fsw) * 16;
+  unsigned b_ad1 = lds0 + OFF_B0 + (wn * 16 + frow) * 128 + ((4 + fg) ^ fsw) * 16;
+  using seqA = std::make_integer_sequence<int, MH>;
+  using seqB0 = std::make_integer_sequence<int, NI0>;
+  using seqB1 = std::make_integer_sequence<int, NI1>;
+
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  half8_t af[2][MH], bf0[2][NI0], bf1[2][NI1];
+  if constexpr (ABL & 2) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int i = 0; i < MH; ++i) af[kk][i] = (half8_t){1, 1, 1, 1, 1, 1, 1, 1};
+#pragma unroll
+      for (int i = 0; i < NI0; ++i) bf0[kk][i] = (half8_t){1, 1, 1, 1, 1, 1, 1, 1};
+#pragma unroll
+      for (int i = 0; i < NI1; ++i) bf1[kk][i] = (half8_t){1, 1, 1, 1, 1, 1, 1, 1};
+    }
+  }
+
+  // MFMA interval of a phase: k-half outer, so that the two MFMAs of one accumulator are NI_*MH issues apart
+#define LGD_PH_MMA(BF, NB, NOFF, MOFF)                                                                              \
+  {                                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    if constexpr (!(ABL & 32)) __builtin_amdgcn_s_setprio(1);                                                       \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                \
+      _Pragma("unroll") for (int ni = 0; ni < NB; ++ni)                                                             \
+        _Pragma("unroll") for (int mi = 0; mi < MH; ++mi)                                                           \
+          if constexpr (ABL & 4) asm volatile("" : "+v"(acc[NOFF + ni][MOFF + mi]) : "v"(BF[kk][ni]), "v"(af[kk][mi]));                \
+          else acc[NOFF + ni][MOFF + mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[kk][ni], af[kk][mi], acc[NOFF + ni][MOFF + mi], 0, 0, 0); \
+    if constexpr (!(ABL & 32)) __builtin_amdgcn_s_setprio(0);                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+  }
+#define LGD_PH_BAR()                        \
+  {                                         \
+    __builtin_amdgcn_sched_barrier(0);      \
+    __builtin_amdgcn_s_barrier();           \
+    __builtin_amdgcn_sched_barrier(0);      \
+  }
+
+  if (nk > 0) {
+    // ---- prologue: tile 0 whole, the first two quarters of tile 1
+    {
+      unsigned sa, sw; int tap;
+      k_pos(0, sa, sw, tap);
+      dma_b(0, 0, true, sw, false);
+      dma_a(0, 0, true, sa, tap, false);
+      dma_b(1, 0, true, sw, false);
+      dma_a(1, 0, true, sa, tap, false);
+      k_pos(1, sa, sw, tap);
+      dma_b(0, STAGE_B, nk > 1, sw, false);
+      dma_a(0, STAGE_B, nk > 1, sa, tap, false);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T_DMA) : "memory");   // B_q0, A_q0 of tile 0 landed (own share)
+    LGD_PH_BAR();
+    if (grp == 1 && !(ABL & 64)) LGD_PH_BAR();                     // the late group starts one interval behind
+    unsigned so_cur = 0, so_nxt = STAGE_B;
+    int sdelta = STAGE_B;
+    for (int kt = 0; kt < nk; ++kt) {
+      unsigned sa1, sw1, sa2, sw2; int tap1, tap2;
+      k_pos(kt + 1, sa1, sw1, tap1);
+      k_pos(kt + 2, sa2, sw2, tap2);
+      const bool live1 = kt + 1 < nk, live2 = kt + 2 < nk;
+      // ---- phase 0: A_q0 x B_q0
+      if constexpr (!(ABL & 2)) lds_read_frags<0, 64 * 128>(bf0[0], b_ad0, seqB0{});
+      if constexpr (!(ABL & 2)) lds_read_frags<0, 64 * 128>(bf0[1], b_ad1, seqB0{});
+      if constexpr (!(ABL & 2)) lds_read_frags<0, 16 * 128>(af[0], a_ad0, seqA{});
+      if constexpr (!(ABL & 2)) lds_read_frags<0, 16 * 128>(af[1], a_ad1, seqA{});
+      dma_b(1, so_nxt, live1, sw1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T_DMA) : "memory");
+      LGD_PH_BAR();
+      LGD_PH_MMA(bf0, NI0, 0, 0);
+      LGD_PH_BAR();
+      // ---- phase 1: A_q0 x B_q1
+      if constexpr (!(ABL & 2)) lds_read_frags<BQ0_B, 64 * 128>(bf1[0], b_ad0, seqB1{});
+      if constexpr (!(ABL & 2)) lds_read_frags<BQ0_B, 64 * 128>(bf1[1], b_ad1, seqB1{});
+      dma_a(1, so_nxt, live1, sa1, tap1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T_DMA) : "memory");
+      LGD_PH_BAR();
+      LGD_PH_MMA(bf1, NI1, NI0, 0);
+      LGD_PH_BAR();
+      // ---- phase 2: A_q1 x B_q1
+      if constexpr (!(ABL & 2)) lds_read_frags<OFF_A1, 16 * 128>(af[0], a_ad0, seqA{});
+      if constexpr (!(ABL & 2)) lds_read_frags<OFF_A1, 16 * 128>(af[1], a_ad1, seqA{});
+      dma_b(0, so_cur, live2, sw2);
+      LGD_PH_BAR();
+      LGD_PH_MMA(bf1, NI1, NI0, MH);
+      LGD_PH_BAR();
+      // ---- phase 3: A_q1 x B_q0 (no reads)
+      dma_a(0, so_cur, live2, sa2, tap2);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T_DMA) : "memory");
+      LGD_PH_BAR();
+      LGD_PH_MMA(bf0, NI0, 0, MH);
+      LGD_PH_BAR();
+      // next K tile: the other stage
+      a_ad0 += sdelta; a_ad1 += sdelta; b_ad0 += sdelta; b_ad1 += sdelta;
+      sdelta = -sdelta;
+      const unsigned t = so_cur; so_cur = so_nxt; so_nxt = t;
+    }
+    if (grp == 0 && !(ABL & 64)) LGD_PH_BAR();
+    // zero-filling DMAs of the tiles past K are still writing LDS: drain before the epilogue reuses it
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    LGD_PH_BAR();
+  }
+#undef LGD_PH_MMA
+#undef LGD_PH_BAR
+
+  if constexpr (ABL & 16) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(acc[ni][mi]));
+    return;
+  }
+  if (d.splits > 1) {
+    // fp32 partials of this split, combined by splitk_reduce_kernel
+    const int m_l = lane & 15, n_l = (lane >> 4) * 4;
+    float* ws = d.ws + ((long)batch * d.splits + split) * (long)d.M * d.N;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + grp * 16 * MI + mi * 16 + m_l;
+      if (m >= d.M) continue;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + wn * 16 * NI + ni * 16 + n_l;
+        if (n >= d.N) continue;
+        const f32x4 v = acc[ni][mi];
+        *reinterpret_cast<float4*>(ws + (long)m * d.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    return;
+  }
+  // one split: fp16 rows through LDS (the launcher admits nothing else); both stages are free
+#define LGD_EPI_LDS(G, RS, RNORM) \
+  gemm_epilogue_lds<MI, NI, WM, WN, 2 * STAGE_B, G, true, RS, RNORM>(ga, acc, m0, n0, grp, wn, lane, tid, c_off, r_off, lds)
+  const bool rn_ = d.epi & LGD_EPI_ROWNORM;
+  if (d.epi & LGD_EPI_GEGLU) {
+    if constexpr (NI % 2 == 0) {
+      if (rn_) LGD_EPI_LDS(true, false, true); else LGD_EPI_LDS(true, false, false);
+    }
+  } else if (d.res) {
+    if (rn_) LGD_EPI_LDS(false, true, true); else LGD_EPI_LDS(false, true, false);
+  } else {
+    if (rn_) LGD_EPI_LDS(false, false, true); else LGD_EPI_LDS(false, false, false);
+  }
+#undef LGD_EPI_LDS
+}
+
 // Sums the split-K partials and applies the epilogue. One thread per 4 output channels.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs ga) {
   const LgdGemmDesc& d = ga.d;
@@ -1628,6 +1956,66 @@ int launch_gemm_pipe(const GemmArgs& ga, hipStream_t st) {
   }
 }
 
+// Phase-split 256-row tiles (gemm_phase_kernel): plain single-source contractions and 3x3 stride-1 same-size
+// convolutions; one split leaves through the LDS epilogue (fp16 rows of whole 16-byte pieces), several splits write fp32
+// partials for splitk_reduce_kernel.  Everything else is the caller's business (LGD_ERR_ARG; ops._table_tile_applies).
+template <int MI, int NI>
+int launch_gemm_phase(const GemmArgs& ga, hipStream_t st) {
+  constexpr int BM = 32 * MI, BN = 64 * NI;
+  constexpr int SMEM = 2 * (BM + BN) * BK * 2;
+  const LgdGemmDesc& d = ga.d;
+  const bool conv = d.taps == 9;
+  if (d.c1 > 0 || d.K < BK || d.nb_o * d.nb_i != 1) return LGD_ERR_ARG;
+  if (conv && (d.stride != 1 || d.ups != 0 || d.hin != d.hout || d.win != d.wout)) return LGD_ERR_ARG;
+  // 32-bit byte offsets inside one buffer descriptor (2 GB each)
+  if (((long)d.M + 2L * d.win + 2) * d.lda0 * 2 + 2L * d.K >= (1L << 31) || (long)d.N * d.ldw * 2 >= (1L << 31)) return LGD_ERR_ARG;
+  if (d.splits == 1) {
+    const long c_off_max = (long)(d.nb_o - 1) * d.c_bs_o + (long)(d.nb_i - 1) * d.c_bs_i;
+    if ((d.epi & LGD_EPI_OUT_F32) || (d.N & 7) || (d.ldc & 7) || (c_off_max & 7) || (d.c_bs_o & 7) || (d.c_bs_i & 7) ||
+        (reinterpret_cast<uintptr_t>(d.c) & 15) || ((d.epi & LGD_EPI_GEGLU) && (NI & 1)) ||
+        (d.res && (d.epi & (LGD_EPI_RES_F32 | LGD_EPI_GEGLU))))
+      return LGD_ERR_ARG;
+  } else if (d.cnt) {
+    return LGD_ERR_ARG;
+  }
+  long tiles = (long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+  dim3 grid((unsigned)tiles, 1, (unsigned)(d.nb_o * d.nb_i * d.splits));
+#ifdef LGD_GEMM_ABLATION
+  static const int abl = [] { const char* e = getenv("LGD_GEMM_ABL"); return e ? atoi(e) : 0; }();
+  if (abl) {
+    auto go = [&](auto kern) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+      hipLaunchKernelGGL(kern, grid, dim3(512), SMEM, st, ga);
+    };
+#define LGD_PH_ABL(A) case A: if (conv) go(&gemm_phase_kernel<MI, NI, true, A>); else go(&gemm_phase_kernel<MI, NI, false, A>); break;
+    switch (abl) {
+      LGD_PH_ABL(1) LGD_PH_ABL(2) LGD_PH_ABL(3) LGD_PH_ABL(4) LGD_PH_ABL(6) LGD_PH_ABL(16) LGD_PH_ABL(17) LGD_PH_ABL(20) LGD_PH_ABL(32) LGD_PH_ABL(64) LGD_PH_ABL(96)
+      default: break;
+    }
+#undef LGD_PH_ABL
+    return lgd_check_launch();
+  }
+#endif
+  if (conv) {
+    static const bool attr_set = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_phase_kernel<MI, NI, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+      return true;
+    }();
+    (void)attr_set;
+    hipLaunchKernelGGL((gemm_phase_kernel<MI, NI, true>), grid, dim3(512), SMEM, st, ga);
+  } else {
+    static const bool attr_set = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_phase_kernel<MI, NI, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+      return true;
+    }();
+    (void)attr_set;
+    hipLaunchKernelGGL((gemm_phase_kernel<MI, NI, false>), grid, dim3(512), SMEM, st, ga);
+  }
+  return lgd_check_launch();
+}
+
 }  // namespace
 
 extern "C" int lgd_abi_version(void) { return LGD_ABI_VERSION; }
@@ -1708,6 +2096,8 @@ extern "C" int lgd_gemm_f16(const LgdGemmDesc* desc, void* stream) {
       case 42: rc = launch_gemm_pipe<1, 2, 4, 2, 6>(ga, st); break;                         // 64x64,   6
       case 44: rc = launch_gemm_pipe<4, 8, 4, 2, 2>(ga, st); break;                         // 256x256, 2 stages, eight waves of 64x128
       case 45: rc = launch_gemm_pipe<2, 4, 4, 2, 2>(ga, st); break;                         // 128x128, 2 stages, two workgroups per CU
+      case 46: rc = launch_gemm_phase<8, 4>(ga, st); break;                                 // 256x256, phase-split (round 6)
+      case 47: rc = geglu ? LGD_ERR_ARG : launch_gemm_phase<8, 5>(ga, st); break;          // 256x320, phase-split
       default: return LGD_ERR_ARG;
     }
     if (rc) return rc;

@@ -135,7 +135,7 @@ def gemm_desc(a0, w, c, M, N, K, *, a1=None, lda0=None, lda1=0, c0=None, c1=0, t
     if log is not None:                                  # tests: which table entries a plan was built from
         log.append((shape_key(d), tile, splits))
     d.cnt = 0
-    if splits > 1 and SPLITK_IN_LAUNCH and torch.is_tensor(c) and c.is_cuda:
+    if splits > 1 and SPLITK_IN_LAUNCH and torch.is_tensor(c) and c.is_cuda and tile not in PHASE_TILES:   # phase tiles: reduce launch only
         # the smallest tile of the library is 32 rows x 64 columns: an upper bound of the launch's output tiles
         if nb_o * nb_i * ((M + 31) // 32) * ((N + 63) // 64) <= N_COUNTERS:
             d.cnt = splitk_counters(c.device).data_ptr()
@@ -148,6 +148,18 @@ def _table_tile_applies(tile, d, splits, epi, n_out) -> bool:
     epilogue alone: one split, fp16 rows of N % 8 = 0 with an 8-aligned leading dimension and a 16-byte aligned base, no
     fp32 output / residual, not GEGLU together with a residual (launch_gemm_pipe returns LGD_ERR_ARG otherwise).  A caller
     with the same M/N/K but such an epilogue must get the heuristic tile, not a RuntimeError."""
+    if tile in PHASE_TILES:
+        # round 6, phase-split 256-row tiles: plain single-source contractions and 3x3 stride-1 same-size convolutions;
+        # one split through the LDS epilogue (as tile 44), several splits through fp32 partials; no GEGLU on 256 x 320
+        if d.c1 != 0 or d.nb_o * d.nb_i != 1 or (d.taps == 9 and (d.stride != 1 or d.ups != 0 or d.hin != d.hout or d.win != d.wout)):
+            return False
+        if (epi & EPI_GEGLU) and tile == 47:
+            return False
+        if splits != 1:
+            return True
+        if (epi & (EPI_OUT_F32 | EPI_RES_F32)) or ((epi & EPI_GEGLU) and d.res):
+            return False
+        return n_out % 8 == 0 and d.ldc % 8 == 0 and d.c % 16 == 0
     if tile not in (44, 45):
         return True
     if d.taps != 1 or d.c1 != 0:
@@ -169,6 +181,9 @@ _PIPE_DIMS = {33: (4, 5, 3), 34: (4, 4, 3), 35: (4, 2, 4), 37: (2, 5, 4), 38: (2
 TILE_NAMES.update({t: f"gemm_pipe_kernel<{mi},{ni},4,2,{ns}> {64 * mi}x{32 * ni}" for t, (mi, ni, ns) in _PIPE_DIMS.items()})
 # round 4: 256 x 256, two-stage ring (plain single-source contractions only), eight waves of 64 x 128
 TILE_NAMES.update({44: "gemm_pipe_kernel<4,8,4,2,2> 256x256", 45: "gemm_pipe_kernel<2,4,4,2,2> 128x128 x2/CU"})
+# round 6: phase-split main loop (two wave groups one interval apart, four phases per K tile), 2 x 4 waves of 128 x (64 | 80)
+PHASE_TILES = {46: (256, 256), 47: (256, 320)}
+TILE_NAMES.update({46: "gemm_phase_kernel<8,4> 256x256", 47: "gemm_phase_kernel<8,5> 256x320"})
 
 
 def choose_tile(M, N, batches=1, geglu=False, K=64, pipe_ok=False):

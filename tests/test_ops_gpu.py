@@ -52,6 +52,12 @@ def pack_geglu(w, b):  # [2n,K] -> 16-row value/gate interleave
     # round 4, two-stage rings: 44 = 256x256 (eight waves of 64x128), 45 = 128x128 with two workgroups per CU
     (8192, 512, 320, 44, 1), (4100, 2560, 640, 44, 1), (300, 1280, 1280, 44, 1), (515, 1280, 1280, 45, 1), (4100, 640, 640, 45, 1),
     (8192, 320, 64, 44, 1), (8192, 320, 64, 45, 1),                      # one K tile: the ring's prologue alone
+    # round 6, phase-split tiles: 46 = 256x256, 47 = 256x320 (ragged M / N: zero-filled rows through the buffer descriptor's
+    # range check; one, two and three K tiles: prologue-only, one loop trip with both look-ahead tiles dead, odd trip counts;
+    # split-K through fp32 partials)
+    (8192, 512, 320, 46, 1), (4100, 2560, 640, 46, 1), (300, 1280, 1280, 46, 1), (8192, 320, 64, 46, 1), (515, 1000, 128, 46, 1),
+    (8192, 320, 320, 47, 1), (4100, 640, 640, 47, 1), (300, 1280, 1280, 47, 1), (8192, 320, 64, 47, 1), (515, 968, 192, 47, 1),
+    (2048, 640, 2560, 46, 2), (2048, 640, 2560, 47, 3), (300, 1280, 5120, 47, 4),
 ])
 def test_gemm_plain(dev, M, N, K, tile, splits):
     x = rnd(M, K, dev=dev, seed=1).half()
@@ -75,7 +81,8 @@ def test_gemm_out_f32_bias2(dev):
 
 @pytest.mark.parametrize("M,dim,splits,tile", [(4096, 320, 1, 0), (300, 640, 1, 0), (128, 1280, 2, 0),
                                                (4096, 320, 1, 17), (300, 640, 1, 19), (128, 1280, 2, 20),
-                                               (4100, 320, 1, 44), (300, 640, 1, 44), (4100, 320, 1, 45), (300, 640, 2, 45)])
+                                               (4100, 320, 1, 44), (300, 640, 1, 44), (4100, 320, 1, 45), (300, 640, 2, 45),
+                                               (4100, 320, 1, 46), (300, 640, 1, 46), (300, 640, 2, 46)])
 def test_gemm_geglu(dev, M, dim, splits, tile):
     inner = 4 * dim
     x = rnd(M, dim, dev=dev, seed=1).half()
@@ -96,6 +103,7 @@ def test_gemm_geglu(dev, M, dim, splits, tile):
     (515, 1280, 1280, False, 37, 1), (515, 320, 320, False, 2, 1), (515, 640, 640, False, 18, 1),
     (128, 1280, 1280, False, 20, 4),                                                                    # split-K, both reducers
     (4100, 320, 2560, True, 44, 1), (4100, 640, 1920, False, 44, 1), (515, 640, 1920, False, 45, 1), (515, 320, 2560, True, 45, 1),
+    (4100, 320, 2560, True, 46, 1), (4100, 640, 1920, False, 46, 1), (4100, 320, 960, False, 47, 1), (515, 1280, 1280, False, 47, 2),
 ])
 def test_gemm_rownorm_is_layernorm_then_linear(dev, M, C, N, geglu, tile, splits):
     """LGD_EPI_ROWNORM (ABI v8): statistics pass + GEMM on the raw rows with gamma-folded weights == LayerNorm
@@ -174,6 +182,24 @@ def test_conv3x3_8wave_tiles(dev, tile):
                     tile=tile, splits=1)
     ref = F.conv2d(x.float(), w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout) + res.float()
     assert relerr(y, ref) < 3e-3
+
+
+@pytest.mark.parametrize("tile,B,H,C,Cout,splits", [(47, 5, 32, 320, 320, 1), (46, 3, 48, 128, 256, 1), (47, 2, 16, 1280, 640, 2),
+                                                     (47, 9, 8, 640, 1280, 3), (46, 1, 64, 64, 320, 1)])
+def test_conv3x3_phase_tiles(dev, tile, B, H, C, Cout, splits):
+    """Round 6: 3x3 stride-1 convolution on the phase-split tiles — chunk-major K walk, padded taps and rows past M
+    zero-filled by the buffer descriptor's range check (image borders, several images per tile at 8x8 / 16x16, a tile
+    that straddles images, ragged M), fp32 partials for split-K."""
+    x = rnd(B, C, H, H, dev=dev, seed=1).half()
+    w = rnd(Cout, C, 3, 3, dev=dev, seed=2, scale=(9 * C) ** -0.5).half()
+    b = rnd(Cout, dev=dev, seed=3)
+    xl = x.permute(0, 2, 3, 1).reshape(B * H * H, C).contiguous()
+    res = rnd(B * H * H, Cout, dev=dev, seed=7).half()
+    y = ops.conv3x3(xl, pack_conv_w(w), B, H, H, bias=b, res=res, tile=tile, splits=splits)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout) + res.float()
+    assert relerr(y, ref) < 3e-3
+    y2 = ops.conv3x3(xl, pack_conv_w(w), B, H, H, bias=b, res=res, tile=tile, splits=splits)
+    assert torch.equal(y, y2)
 
 
 @pytest.mark.parametrize("M,N,K,tile", [

@@ -80,12 +80,16 @@ for (M, N, K, taps, cin, h, geglu) in SHAPES:
     c = torch.empty(M, n_out, device=dev, dtype=torch.float16)
     descs = {}
     for tile, sp in tiles:
-        if geglu and (((tile & 15) in (6, 7, 9) and tile < 32) or tile in (33, 37, 40)):
+        if geglu and (((tile & 15) in (6, 7, 9) and tile < 32) or tile in (33, 37, 40, 47)):
             continue
         if sp > 1 and K // 64 < 2 * sp:
             continue
-        d = ops.gemm_desc(a0, w, c, M, N, K, c0=cin, lda0=cin, bias=bias, res=res, ldr=n_out, epi=geglu | (int(os.environ.get("EPI_ABL", "0")) << 16), ldc=n_out,
-                          tile=tile, splits=None if tile == 0 else sp, **kw)
+        try:
+            d = ops.gemm_desc(a0, w, c, M, N, K, c0=cin, lda0=cin, bias=bias, res=res, ldr=n_out, epi=geglu | (int(os.environ.get("EPI_ABL", "0")) << 16), ldc=n_out,
+                              tile=tile, splits=None if tile == 0 else sp, **kw)
+        except RuntimeError as e:
+            print(f"  tile {tile}/s{sp}: {e}")
+            continue
         c.zero_()
         try:
             ops.gemm_launch(d)

@@ -31,6 +31,31 @@ PY
       LGD_TUNE_TOP=$TOP timeout ${TUNE_TIMEOUT:-480} python tools/tune_gemm.py sd14_gligen $OUT/latency.json > $OUT/tune.log 2>&1
     fi
     echo "tune rc=$?"; tail -n 4 $OUT/tune.log ;;
+  tune_only)  # args: TILES TOP [streams]; tries only the given tile codes (e.g. "46,47") against the entries the table holds,
+              # on the TOP most expensive shapes; the candidate table lands in $OUT (latency.json | lanes_full.json + lanes_new.json)
+    TL=${1:-46,47}; TOP=${2:-150}; STREAMS=${3:-1}
+    if [ "$STREAMS" -gt 1 ]; then
+      python - <<PY
+import json
+a = json.load(open("llm-groundeddiffusion_amd/tuning_gfx950.json")); a.update(json.load(open("llm-groundeddiffusion_amd/tuning_gfx950_lanes.json")))
+json.dump(a, open("gpurun_out/tune_only/lanes_full.json", "w"), indent=0, sort_keys=True)
+PY
+      LGD_TUNE_ONLY_TILES=$TL LGD_TUNE_STREAMS=$STREAMS LGD_TUNE_TOP=$TOP timeout ${TUNE_TIMEOUT:-700} python tools/tune_gemm.py sd14_gligen $OUT/lanes_full.json > $OUT/tune.log 2>&1
+      echo "tune rc=$?"; tail -n 3 $OUT/tune.log
+      python - <<PY
+import json
+lat = json.load(open("llm-groundeddiffusion_amd/tuning_gfx950.json"))
+full = json.load(open("gpurun_out/tune_only/lanes_full.json"))
+new = {k: v for k, v in full.items() if k not in lat or (lat[k]["tile"], lat[k]["splits"]) != (v["tile"], v["splits"])}
+json.dump(new, open("gpurun_out/tune_only/lanes_new.json", "w"), indent=0, sort_keys=True)
+print("lanes table:", len(new), "entries")
+PY
+    else
+      cp llm-groundeddiffusion_amd/tuning_gfx950.json $OUT/latency.json
+      LGD_TUNE_ONLY_TILES=$TL LGD_TUNE_TOP=$TOP timeout ${TUNE_TIMEOUT:-700} python tools/tune_gemm.py sd14_gligen $OUT/latency.json > $OUT/tune.log 2>&1
+      echo "tune rc=$?"; tail -n 3 $OUT/tune.log
+    fi
+    grep -c "tile 4[67]" $OUT/tune.log ;;
   tune_big)   # round 5: the GEMM shapes of the 16- / 32-image main plans and 8- / 16-image guidance plans (bigger UNet
               # calls, bench.py --group / --max-batch) added to the shared-GPU table; args: [streams]
     STREAMS=${1:-2}

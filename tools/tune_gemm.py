@@ -62,9 +62,12 @@ TILE_DIMS = {17: (128, 128), 18: (128, 64), 19: (64, 128), 20: (64, 64), 21: (32
              # round 4: the deeper-ringed small 8-wave tiles (5-6 LDS stages) were in the library but never candidates
              39: (128, 64), 40: (64, 160), 41: (64, 128), 42: (64, 64),
              # round 4: two-stage rings (plain single-source contractions only): 256x256, and 128x128 at two workgroups per CU
-             44: (256, 256), 45: (128, 128)}
+             44: (256, 256), 45: (128, 128),
+             # round 6: phase-split 256-row tiles (plain single-source contractions and 3x3 stride-1 same-size convolutions)
+             46: (256, 256), 47: (256, 320)}
 PLAIN_ONLY = {44, 45}
-NO_GEGLU = {22, 23, 33, 37, 40}                  # odd fragment counts cannot pair value | gate column blocks
+PHASE = {46, 47}
+NO_GEGLU = {22, 23, 33, 37, 40, 47}              # odd fragment counts cannot pair value | gate column blocks
 VERIFY_TOL = 2e-3                                # fp16 outputs, different summation orders
 rejected = []
 
@@ -177,6 +180,8 @@ for key, sh in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"
         if tile > 32 and (not pipe_ok or M < bm):
             continue
         if tile in PLAIN_ONLY and (sh["taps"] != 1 or sh["c1"] > 0):
+            continue
+        if tile in PHASE and (sh["c1"] > 0 or (sh["taps"] == 9 and (sh["stride"] != 1 or sh["ups"] != 0 or sh["hin"] != sh["hout"]))):
             continue
         wgs = -(-M // bm) * -(-N // bn)
         for sp in (1, 2, 3, 4, 6, 8, 12, 16):
