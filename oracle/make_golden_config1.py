@@ -86,6 +86,11 @@ def main():
                 rec["frozen"] = dict(frozen_steps=a[5], frozen_mask=a[2].detach().clone(), latents_all=a[1].detach().clone())
             else:
                 rec.setdefault("so_kwargs", []).append(dict(k["semantic_guidance_kwargs"]))
+                # round 6: the maps the per-box stage SAVES (pipelines.py:129-247, return_saved_cross_attn), before lmd.run
+                # shifts them onto the overall boxes: per step a dict key -> [1, heads, HW, 1] (condition half, word token)
+                sk = [tuple(kk_) for kk_ in k["saved_cross_attn_keys"]]
+                rec.setdefault("so_saved", []).append(dict(keys=sk, maps={kk_: torch.stack([st[kk_][0, :, :, 0] for st in out[2]]).clone()
+                                                                          for kk_ in dict.fromkeys(sk)}))
             rec["gens"].append(dict(kind=kind, seconds=time.time() - t0, starts=torch.stack(cur["starts"]), iters=list(cur["iters"]),
                                     losses=list(cur["losses"]), final=out[0].detach().clone(),
                                     latents_in=(a[1][0] if kind == "overall" else a[1]).detach().clone(),
@@ -141,6 +146,21 @@ def main():
     js = lambda d: json.dumps({kk: (vv if not torch.is_tensor(vv) else vv.tolist()) for kk, vv in d.items()}, default=lambda o_: list(o_))
     outs["ov_guidance_kwargs"] = np.array(js(rec["sg_kwargs"]))
     outs["so_guidance_kwargs"] = np.array(json.dumps([json.loads(js(d)) for d in rec["so_kwargs"]]))
+    maps = {}
+    for i, sv in enumerate(rec.get("so_saved", [])):
+        maps[f"so{i}_saved_keys"] = np.array(json.dumps([list(kk_) for kk_ in sv["keys"]]))
+        for ki, kk_ in enumerate(dict.fromkeys(sv["keys"])):
+            maps[f"so{i}_saved_k{ki}"] = sv["maps"][kk_].numpy().astype(np.float16)      # [T, heads, HW]; fp16 halves the file
+    if os.environ.get("LGD_CONFIG1_MAPS_ONLY"):
+        # keep the committed golden (its gates were measured against it): this run must reproduce it bit for bit, then
+        # only the per-box maps are written, beside it
+        old = np.load(os.path.join(ROOT, "tests", "golden", "run_lmd_sd15_config1.npz"))
+        same = all(np.array_equal(old[k_], outs[k_]) for k_ in ("g0_starts", "g1_starts", "g2_starts", "composed", "g2_final", "fg_idx"))
+        print("re-run reproduces the committed golden bit for bit:", same)
+        if same:
+            np.savez_compressed(os.path.join(ROOT, "tests", "golden", "run_lmd_sd15_config1_maps.npz"), **maps)
+            return
+    outs.update(maps)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "run_lmd_sd15_config1.npz"), **outs)
     summary = dict(what="BASELINE config[0]: the reference's own generation/lmd.run, SD1.5 architecture (seeded synthetic weights), "
                         "fp32, CPU, 1 cached layout (2 boxes), 10 DDIM steps, default arguments, SAM = box masks, VAE = stub",
