@@ -240,11 +240,12 @@ extern "C" int lgd_boxdiff_energy_f32(const float* const* maps, float* const* gm
   if (side < 2 || side > BD_MAXSIDE || side * side > BD_MAXHW || T < 3 || T > 128) return LGD_ERR_UNSUPPORTED;
   const size_t bytes = (size_t)(7 + 2 * (size_t)max_items) * side * side * sizeof(float);
   if (bytes > 150 * 1024) return LGD_ERR_UNSUPPORTED;     // item images live in LDS: HW = 256 allows 70 items per image
-  static const int attr = [] {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(boxdiff_energy_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-  }();
-  if (attr != (int)hipSuccess) return LGD_ERR_LAUNCH;
+  // the attribute is per DEVICE and a failure must not stick: set it whenever the launch needs more than the default
+  // 64 KB (a host call per launch of an eager-only kernel that runs once per denoising step)
+  if (bytes > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(boxdiff_energy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          150 * 1024) != hipSuccess)
+    return LGD_ERR_LAUNCH;
   BoxDiffArgs a{maps, gmaps, items, masks, smooth, groups, loss, n_maps, side, H, T, max_items, loss_scale, grad_scale};
   hipLaunchKernelGGL(boxdiff_energy_kernel, dim3(n_samples), dim3(256), bytes, reinterpret_cast<hipStream_t>(stream), a);
   return lgd_check_launch();

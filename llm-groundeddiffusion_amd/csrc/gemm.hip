@@ -434,6 +434,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& ga, f32x4 (&ac
   // LEAN (the 256 x 256 tile: 128 accumulators): column sums are fetched per column block inside the round loop and the
   // residual's column select is recomputed — hoisted they spill
   constexpr bool LEAN = MI * NI >= 32;
+  // LEAN2 (the phase-split tiles: 128 / 160 accumulators): biases too are fetched per column block inside the round loop,
+  // row statistics per round, the copy-out loop stays rolled — hoisted / unrolled they spilled up to 99 registers
+  constexpr bool LEAN2 = MI * NI >= 32 && WN == 4;       // the phase-split tiles (2 x 4 waves)
   float4 bv[NI_OUT], bg[NI_OUT], cv[NI_OUT], cg[NI_OUT];
   int ncol[NI_OUT];                                     // clamped output column of the residual fetch
 #pragma unroll
@@ -449,7 +452,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& ga, f32x4 (&ac
 #ifdef LGD_GEMM_ABLATION                 // tools: epi bit 18 = no parameter loads in the epilogue
     if (d.epi & (1 << 18)) continue;
 #endif
-    if (ok) {
+    if (ok && !LEAN2) {
       bv[no] = ld_bias_sum4(d, n_in);
       if (GEGLU && d.bias) bg[no] = ld_bias4(d.bias, n_in + 16);
       if constexpr (RN && !LEAN) {
@@ -466,7 +469,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& ga, f32x4 (&ac
     if (m >= d.M) m = d.M - 1;
     mrow[mi] = m;
     st[mi] = make_float2(0.f, 1.f);
-    if constexpr (RN) st[mi] = *reinterpret_cast<const float2*>(d.rowstat + (long)m * 2);
+    if constexpr (RN && !LEAN2) st[mi] = *reinterpret_cast<const float2*>(d.rowstat + (long)m * 2);
   }
   // rstd (v - mean colsum) + bias on the two halves of a piece
   auto normed = [&](const f32x4& v, const float2 s2, const float4 c, const float4 b, f32x2_t& lo, f32x2_t& hi) {
@@ -483,6 +486,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& ga, f32x4 (&ac
   unsigned char* lw = lds + (wm * WROWS + m_l) * CROW + (wn * 16 * NI_OUT + n_l) * 2;   // this lane's staging origin
 #pragma unroll
   for (int r = 0; r < R; ++r) {
+    if constexpr (RN && LEAN2) {
+#pragma unroll
+      for (int mj = 0; mj < MI_R; ++mj)
+        st[r * MI_R + mj] = *reinterpret_cast<const float2*>(d.rowstat + (long)mrow[r * MI_R + mj] * 2);
+    }
     // residual fetches of the round first (one memory round trip for MI_R x NI_OUT pieces)
     half4_t rpre[NI_OUT][MI_R];
     if constexpr (RES16) {
@@ -503,12 +511,18 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& ga, f32x4 (&ac
     }
 #pragma unroll
     for (int no = 0; no < NI_OUT; ++no) {
-      if constexpr (RN && LEAN) {
+      if constexpr ((RN && LEAN) || LEAN2) {
         const int n_out = n0_out + wn * 16 * NI_OUT + no * 16 + n_l;
         const int n_in = GEGLU ? n0 + wn * 16 * NI + no * 32 + n_l : n_out;
         if (n_out < n_total_out) {
-          cv[no] = *reinterpret_cast<const float4*>(d.colsum + n_in);
-          if (GEGLU) cg[no] = *reinterpret_cast<const float4*>(d.colsum + n_in + 16);
+          if constexpr (RN) {
+            cv[no] = *reinterpret_cast<const float4*>(d.colsum + n_in);
+            if (GEGLU) cg[no] = *reinterpret_cast<const float4*>(d.colsum + n_in + 16);
+          }
+          if constexpr (LEAN2) {
+            bv[no] = ld_bias_sum4(d, n_in);
+            if (GEGLU && d.bias) bg[no] = ld_bias4(d.bias, n_in + 16);
+          }
         }
       }
 #pragma unroll
@@ -539,8 +553,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& ga, f32x4 (&ac
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // whole rows, 16 bytes per lane
-#pragma unroll
+    // whole rows, 16 bytes per lane (LEAN2: a rolled loop — unrolled, the five chunks' 64-bit addresses were all computed
+    // ahead of the barrier above and spilled)
+#pragma unroll LEAN2 ? 1 : (RROWS * CPR + NT - 1) / NT
     for (int i = 0; i < (RROWS * CPR + NT - 1) / NT; ++i) {
       const int idx = tid + i * NT;
       const int row = idx / CPR, ch = idx - row * CPR;
@@ -1663,10 +1678,6 @@ __global__ __launch_bounds__(512, 1) void gemm_phase_kernel(const GemmArgs ga) {
   using seqB1 = std::make_integer_sequence<int, NI1>;
 
   f32x4 acc[NI][MI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
   half8_t af[2][MH], bf0[2][NI0], bf1[2][NI1];
   if constexpr (ABL & 2) {
 #pragma unroll
@@ -1714,6 +1725,12 @@ __global__ __launch_bounds__(512, 1) void gemm_phase_kernel(const GemmArgs ga) {
       dma_b(0, STAGE_B, nk > 1, sw, false);
       dma_a(0, STAGE_B, nk > 1, sa, tap, false);
     }
+    // accumulators are born here, behind the set-up and the prologue's issue (160 registers that were live across both
+    // made the 256 x 320 kernel spill its set-up values)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T_DMA) : "memory");   // B_q0, A_q0 of tile 0 landed (own share)
     LGD_PH_BAR();
     if (grp == 1 && !(ABL & 64)) LGD_PH_BAR();                     // the late group starts one interval behind
@@ -1765,6 +1782,12 @@ __global__ __launch_bounds__(512, 1) void gemm_phase_kernel(const GemmArgs ga) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     LGD_PH_BAR();
   }
+  else {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 #undef LGD_PH_MMA
 #undef LGD_PH_BAR
 
@@ -1795,7 +1818,7 @@ __global__ __launch_bounds__(512, 1) void gemm_phase_kernel(const GemmArgs ga) {
   }
   // one split: fp16 rows through LDS (the launcher admits nothing else); both stages are free
 #define LGD_EPI_LDS(G, RS, RNORM) \
-  gemm_epilogue_lds<MI, NI, WM, WN, 2 * STAGE_B, G, true, RS, RNORM>(ga, acc, m0, n0, grp, wn, lane, tid, c_off, r_off, lds)
+  gemm_epilogue_lds<MI, NI, WM, WN, (MI * NI > 32 ? STAGE_B : 2 * STAGE_B), G, true, RS, RNORM>(ga, acc, m0, n0, grp, wn, lane, tid, c_off, r_off, lds)
   const bool rn_ = d.epi & LGD_EPI_ROWNORM;
   if (d.epi & LGD_EPI_GEGLU) {
     if constexpr (NI % 2 == 0) {

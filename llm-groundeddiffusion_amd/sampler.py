@@ -180,16 +180,28 @@ class LMDSampler:
                     return a.heads
         raise KeyError(key)
 
-    def make_guidance(self, L, bboxes, object_positions, *, loss_scale=30, loss_threshold=0.2, max_iter=5,
-                      max_index_step=10, guidance_attn_keys=None, ref_maps=None, **kw) -> Optional[GuidanceState]:
+    def make_guidance(self, lat_size, bboxes, object_positions, *, loss_scale=30, loss_threshold=0.2, max_iter=5,
+                      max_index_step=None, guidance_attn_keys=None, ref_maps=None, **kw) -> Optional[GuidanceState]:
         """kwargs as latent_backward_guidance / compute_ca_lossv3 receive them (pipelines.py:16,
         guidance.py:244) — including the reference's default `use_ratio_based_loss=True` (guidance.py:91) when the
-        caller does not switch it off.  ref_maps: fp32 [T][n_boxes_flat][n_keys][heads][max_hw] or None."""
+        caller does not switch it off.  ref_maps: fp32 [T][n_boxes_flat][n_keys][heads][max_hw] or None.
+        lat_size: side of the latent map (NOT called `L`: BoxDiff's corner-margin hyperparameter has that name in the
+        reference, utils/boxdiff.py:28,169, and arrives through **kw).  max_index_step None = the callee's own default:
+        10 for latent_backward_guidance (pipelines.py:16), 25 for latent_backward_guidance_boxdiff (utils/boxdiff.py:190)."""
+        if kw.get("use_boxdiff"):
+            # dispatched BEFORE this function's defaults apply; reference arguments the port cannot honour are errors, not ignored
+            if not bboxes or (max_index_step is not None and max_index_step <= 0):
+                return None
+            bkw = {k: v for k, v in kw.items() if k not in ("use_boxdiff", "verbose")}
+            if bkw.pop("normalize_eot", False):
+                raise NotImplementedError("normalize_eot=True: the reference asserts against it as well (utils/boxdiff.py)")
+            if max_index_step is not None:
+                bkw["max_index_step"] = max_index_step
+            return self.make_boxdiff_guidance(lat_size, bboxes, object_positions, guidance_attn_keys=guidance_attn_keys, **bkw)
+        L = lat_size
+        max_index_step = 10 if max_index_step is None else max_index_step
         if not bboxes or max_index_step <= 0:
             return None
-        if kw.get("use_boxdiff"):
-            return self.make_boxdiff_guidance(L, bboxes, object_positions, max_index_step=max_index_step,
-                                              guidance_attn_keys=guidance_attn_keys, **kw)
         keys = [tuple(k) for k in (guidance_attn_keys or DEFAULT_GUIDANCE_ATTN_KEYS)]
         heads = self.heads_of(keys[0])
         assert all(self.heads_of(k) == heads for k in keys), "guidance keys with different head counts"
@@ -203,7 +215,7 @@ class LMDSampler:
             en.set_refs(ref_maps.reshape(T, -1, heads, en.max_hw))
         return GuidanceState(en, loss_scale, loss_threshold, max_iter, max_index_step)
 
-    def make_boxdiff_guidance(self, L, bboxes, object_positions, *, max_index_step=25, guidance_attn_keys=None,
+    def make_boxdiff_guidance(self, lat_size, bboxes, object_positions, *, max_index_step=25, guidance_attn_keys=None,
                               amp_loss_scale=10, latent_scale=20, scale_range=(1., 0.5), **kw) -> GuidanceState:
         """latent_backward_guidance_boxdiff's arguments (utils/boxdiff.py:199): one gradient step per denoising step while
         index < max_index_step — no loss threshold, no inner loop — of size latent_scale * sqrt(ramp(index)), the loss
@@ -211,14 +223,20 @@ class LMDSampler:
         keys = [tuple(k) for k in (guidance_attn_keys or BOXDIFF_GUIDANCE_ATTN_KEYS)]
         heads = self.heads_of(keys[0])
         assert all(self.heads_of(k) == heads for k in keys), "guidance keys with different head counts"
-        ekw = {k: kw[k] for k in ("P", "L", "smooth_attentions", "sigma", "kernel_size") if k in kw}
-        en = BoxDiffTables(self.dev, bboxes, object_positions, keys, self.map_hw(L), heads, self.eng.text_len,
+        known = ("P", "L", "smooth_attentions", "sigma", "kernel_size")
+        unknown = sorted(k for k in kw if k not in known and k not in ("loss_scale", "loss_threshold", "max_iter", "ref_maps"))
+        if unknown:
+            raise TypeError(f"make_boxdiff_guidance: unsupported arguments {unknown}")
+        ekw = {k: kw[k] for k in known if k in kw}
+        en = BoxDiffTables(self.dev, bboxes, object_positions, keys, self.map_hw(lat_size), heads, self.eng.text_len,
                            loss_scale=amp_loss_scale, **ekw)
         lo, hi = float(scale_range[0]), float(scale_range[1])
 
         def step_scale(index, n_timesteps):
             return latent_scale * (lo + (hi - lo) * index / max(n_timesteps - 1, 1)) ** 0.5 / amp_loss_scale
-        return GuidanceState(en, amp_loss_scale, float("-inf"), 1, max_index_step, kind="boxdiff", step_scale=step_scale)
+        gs = GuidanceState(en, amp_loss_scale, float("-inf"), 1, max_index_step, kind="boxdiff", step_scale=step_scale)
+        gs.step_params = (float(amp_loss_scale), float(latent_scale), lo, hi)      # jobs batched together must agree on these
+        return gs
 
     # ------------------------------------------------------------------------------------------
     MAX_STATES = 12
@@ -479,6 +497,8 @@ class LMDSampler:
             tables = BoxDiffTables if kinds == {"boxdiff"} else EnergyTables
             if kinds == {"boxdiff"}:             # utils/boxdiff.py:236-238: the update's own step table (all jobs alike)
                 gs0 = next(gs for gs in gstates if gs is not None)
+                if any(gs is not None and getattr(gs, "step_params", None) != getattr(gs0, "step_params", None) for gs in gstates):
+                    raise RuntimeError("BoxDiff jobs guided in one batch must share amp_loss_scale / latent_scale / scale_range")
                 st.gtab[:Tr, 0].copy_(torch.tensor([gs0.step_scale(i, Tr) for i in range(Tr)], dtype=F32))
             energy = gstates[[gs is not None for gs in gstates].index(True)].energy if nb == 1 else \
                 tables.merged([gs.energy if gs is not None else None for gs in gstates])

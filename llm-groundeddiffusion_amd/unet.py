@@ -498,7 +498,12 @@ class Plan:
                     x = self._resnet(r, x, None, H)
                     if b.attns:
                         x = self._transformer(b.attns[j], x, H)
+                        if x is None:            # the last saved / guidance key is a down-level one: the plan ends here
+                            done = True
+                            break
                     skips.append((x, H))
+                if done:
+                    break
                 if b.sampler:
                     x = self.conv(x, b.sampler, H, stride=2)
                     H = (H - 1) // 2 + 1

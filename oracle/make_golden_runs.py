@@ -236,6 +236,40 @@ def run_backward_guidance():
     print("wrote run_backward_guidance_tiny.npz", {k: getattr(v, "shape", None) for k, v in outs.items()})
 
 
+def run_gligen():
+    """The reference's own, unmodified `generation/gligen.run` (gligen.py:42-99): ONE generate_gligen call on the overall
+    prompt with the per-box prompts as grounding phrases.  Recorded: the initial latents, the final latents."""
+    cfg, md = build("tiny_gligen")
+    import models
+    models.sd_key = models.models.sd_key = "tiny_gligen"          # generation/gligen.py:16 asserts "gligen" in models.sd_key
+    import generation.gligen as g
+    g.height = g.width = 256
+    g.H = g.W = 32
+    g.num_inference_steps = 8
+    rec = []
+    o_gl = g.pipelines.generate_gligen
+
+    def gl(*a, **k):
+        out = o_gl(*a, **k)
+        rec.append(dict(latents_in=a[1].detach().clone(), phrases=list(a[5]), bboxes=[list(b) for b in a[4]], out=out[0].detach().clone(),
+                        beta=k.get("gligen_scheduled_sampling_beta"), guidance_scale=k.get("guidance_scale")))
+        return out
+    g.pipelines.generate_gligen = gl
+    outs = {}
+    for tag, spec, kw in (("a", SPEC, dict(bg_seed=3)), ("b", dict(SPEC3, gen_boxes=SPEC3["gen_boxes"][1:]), dict(bg_seed=11, gligen_scheduled_sampling_beta=0.25))):
+        rec.clear()
+        r = g.run(spec, **kw)
+        assert len(rec) == 1
+        outs[f"{tag}_latents_in"] = rec[0]["latents_in"].numpy()
+        outs[f"{tag}_final_latents"] = rec[0]["out"].numpy()
+        outs[f"{tag}_call"] = np.array(json.dumps(dict(phrases=rec[0]["phrases"], bboxes=rec[0]["bboxes"], beta=rec[0]["beta"],
+                                                       guidance_scale=rec[0]["guidance_scale"])))
+        outs[f"{tag}_image_shape"] = np.array(r.image.shape)
+    g.pipelines.generate_gligen = o_gl
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "run_gligen_tiny.npz"), **outs)
+    print("wrote run_gligen_tiny.npz", {k: getattr(v, "shape", None) for k, v in outs.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -245,3 +279,5 @@ if __name__ == "__main__":
         run_lmd()
     if which in ("all", "backward_guidance"):
         run_backward_guidance()
+    if which in ("all", "gligen"):
+        run_gligen()

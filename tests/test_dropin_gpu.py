@@ -324,6 +324,42 @@ def test_lmd_plus_run_vs_reference_run_golden(dropin, dev):
         sys.modules.pop("inflect", None)
 
 
+def test_gligen_plugin_vs_reference_run_golden(dropin, dev):
+    """The `gligen` plugin (generation/gligen.py:42-99) against the reference's OWN, unmodified run() on the tiny
+    GLIGEN network (CPU fp32; oracle/make_golden_runs.py gligen): what it hands to pipelines.generate_gligen (per-box PROMPTS as
+    grounding phrases, boxes in convert_spec's order, beta, guidance scale), the seeded initial noise bit for bit, the final
+    latents of the eight plain GLIGEN steps, and the run() contract (`version`, `.image`)."""
+    import json
+    import generation.gligen as g
+    from models import pipelines
+    assert g.version == "gligen"
+    gold = np.load(os.path.join(GOLD, "run_gligen_tiny.npz"))
+    g.height = g.width = 256
+    g.num_inference_steps = 8
+    rec = []
+    o_gl = pipelines.generate_gligen
+
+    def gl(md, lat, emb, T, bboxes, phrases, **k):
+        out = o_gl(md, lat, emb, T, bboxes, phrases, **k)
+        rec.append(dict(lat=lat.detach().float().cpu().clone(), out=out[0].detach().float().cpu().clone(), phrases=list(phrases),
+                        bboxes=[list(b) for b in bboxes], beta=k.get("gligen_scheduled_sampling_beta"), gs=k.get("guidance_scale")))
+        return out
+    g.pipelines.generate_gligen = gl
+    try:
+        for tag, spec, kw in (("a", SPEC, dict(bg_seed=3)),
+                              ("b", dict(SPEC3, gen_boxes=SPEC3["gen_boxes"][1:]), dict(bg_seed=11, gligen_scheduled_sampling_beta=0.25))):
+            rec.clear()
+            r = g.run(spec, **kw)
+            want = json.loads(str(gold[f"{tag}_call"]))
+            assert len(rec) == 1 and rec[0]["phrases"] == want["phrases"] and rec[0]["beta"] == want["beta"] and rec[0]["gs"] == want["guidance_scale"]
+            assert np.allclose(np.array(rec[0]["bboxes"]), np.array(want["bboxes"]), atol=0, rtol=0)
+            assert torch.equal(rec[0]["lat"], torch.from_numpy(gold[f"{tag}_latents_in"]))          # seeded CPU noise, bit for bit
+            gate(f"[run gligen {tag}] final latents (8 plain GLIGEN steps, free-running)", relerr(rec[0]["out"], gold[f"{tag}_final_latents"]), 1.5e-2)
+            assert r.image.dtype == np.uint8 and tuple(r.image.shape) == tuple(gold[f"{tag}_image_shape"])
+    finally:
+        g.pipelines.generate_gligen = o_gl
+
+
 def test_lmd_plus_overall_stage_teacher_forced(dropin, dev):
     """Every step of the reference run()'s OVERALL generation (generation/lmd_plus.py:418-470 -> pipelines.generate_gligen
     with semantic guidance, reference-attention transfer and the frozen-mask blend), one step at a time from the

@@ -71,9 +71,17 @@ def _check_steps(sm, tag, starts, final, iters, losses, loss_scale, ehs, lim_gui
     for s in range(T):
         tr = []
         out = sm.denoise(torch.from_numpy(starts[s]) if "hist" not in kw else kw["hist"](s), ehs, T, first_step=s, n_steps=1,
-                         trace=tr, **{k: v for k, v in kw.items() if k != "hist"})
+                         trace=tr, **{k: v for k, v in kw.items() if k not in ("hist", "saved_ref", "saved_keys", "map_err")})
         want = starts[s + 1] if s < T - 1 else final
         assert out["guidance_iters"] == int(iters[s]), (tag, s, out["guidance_iters"], int(iters[s]))
+        if kw.get("saved_ref") is not None:
+            # the maps this step SAVED (pipelines.py:129-247 return_saved_cross_attn: condition half, word token) against the
+            # reference's own, before lmd.run aligns them: {key: [T_run = 1, Bp = 1, heads, HW, 1]} vs [T, heads, HW]
+            for ki, k_ in enumerate(kw["saved_keys"]):
+                got_m = out["saved"][k_][0, 0, :, :, 0].float().cpu()
+                ref_m = torch.from_numpy(kw["saved_ref"][ki][s].astype(np.float32))
+                worst_map = max(kw["map_err"].get(k_, 0.0), float((got_m - ref_m).abs().max() / ref_m.abs().max().clamp_min(1e-12)))
+                kw["map_err"][k_] = worst_map
         if iters[s]:
             got = np.array([x["loss"] for x in tr]) / loss_scale
             ref = losses[n0:n0 + int(iters[s])]
@@ -93,14 +101,25 @@ def test_config1_per_box_generations_teacher_forced_vs_the_reference_run(dev):
     s = setup(dev)
     g = s["g"]
     sm = LMDSampler(s["eng"], DDIMScheduler())
+    mpath = os.path.join(ROOT, "tests", "golden", "run_lmd_sd15_config1_maps.npz")
+    gm = np.load(mpath) if os.path.exists(mpath) else None
     for i in (0, 1):
         gd = _so_guidance(g, i)
         ehs = torch.from_numpy(g[f"g{i}_text_embeddings"])
         assert relerr(g[f"g{i}_starts"][0], g[f"g{i}_latents_in"]) == 0.0
+        keys = [OBJ_KEY, *gd["guidance_attn_keys"]]
+        if gm is not None:
+            assert [tuple(k) for k in json.loads(str(gm[f"so{i}_saved_keys"]))] == keys
+        errs = {}
         _check_steps(sm, f"per-box generation {i}", g[f"g{i}_starts"], g[f"g{i}_final"], g[f"g{i}_iters"], g[f"g{i}_losses"],
                      gd["loss_scale"], ehs, 2e-2, 7e-3, guidance=gd,       # measured: step 0 6.7e-3 / 6.3e-3; later <= 2.4e-3
-                     saved_cross_attn_keys=[OBJ_KEY, *gd["guidance_attn_keys"]],
-                     return_cond_ca_only=True, return_token_ca_only=gd["object_positions"][0][-1])
+                     saved_cross_attn_keys=keys,
+                     return_cond_ca_only=True, return_token_ca_only=gd["object_positions"][0][-1],
+                     saved_ref=[gm[f"so{i}_saved_k{ki}"] for ki in range(len(keys))] if gm is not None else None,
+                     saved_keys=keys, map_err=errs)
+        for k_, e in errs.items():
+            # the reference's maps were stored as fp16 (2^-11 relative); the engine's fp16 softmax on top
+            gate(f"[config 1, per-box generation {i}] saved word-token maps at {k_} vs the reference's (all 10 steps, max-norm)", e, 3e-2)
 
 
 def test_config1_overall_generation_teacher_forced_vs_the_reference_run(dev):

@@ -9,8 +9,10 @@ from lgd_amd import ops
 
 TABLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llm-groundeddiffusion_amd",
                      "tuning_gfx950.json")
-PIPE = {33: 160, 34: 128, 35: 64, 37: 160, 38: 128, 39: 64, 40: 160, 41: 128, 42: 64, 44: 256, 45: 128}      # code -> tile width
+PIPE = {33: 160, 34: 128, 35: 64, 37: 160, 38: 128, 39: 64, 40: 160, 41: 128, 42: 64, 44: 256, 45: 128,      # code -> tile width
+        46: 256, 47: 320}
 TWO_STAGE = {44, 45}                                  # plain single-source contractions only; 44 (256 x 256): one split
+PHASE = {46, 47}                                      # round 6: single source; plain or 3x3 stride-1 same-size convolution
 LEGAL = (set(range(1, 11)) | {16 + t for t in range(1, 11)} | set(PIPE)) - {8, 24}
 TILE_BN = {1: 128, 2: 64, 3: 128, 4: 64, 5: 128, 6: 160, 7: 160, 9: 320, 10: 128}
 
@@ -29,9 +31,12 @@ def test_table_entries_are_legal():
         assert K == taps * (c0 + c1)
         assert 1 <= e["splits"] <= 16 and (e["splits"] == 1 or K // 64 >= e["splits"])
         if geglu:                                                          # 160/320-wide tiles cannot pair value|gate rows
-            assert PIPE.get(e["tile"], 0) != 160 and (e["tile"] in PIPE or (e["tile"] & 15) not in (6, 7, 9)), (key, e)
+            assert PIPE.get(e["tile"], 0) not in (160, 320) and (e["tile"] in PIPE or (e["tile"] & 15) not in (6, 7, 9)), (key, e)
         if e["tile"] in PIPE:
             assert K % 64 == 0 and (c0 + c1) % 64 == 0 and c0 % 64 == 0, (key, e)
+        if e["tile"] in PHASE:
+            hin, hout, stride, ups = int(m.group(7)), int(m.group(8)), int(m.group(9)), int(m.group(10))
+            assert c1 == 0 and int(m.group(12)) == 1 and (taps == 1 or (stride == 1 and ups == 0 and hin == hout)), (key, e)
         if e["tile"] in TWO_STAGE:
             assert taps == 1 and c1 == 0 and (e["tile"] != 44 or (e["splits"] == 1 and N % 8 == 0)), (key, e)
         assert e["us"] > 0 and e["tflops"] > 0
