@@ -438,11 +438,14 @@ def main():
     ap.add_argument("--sam", action="store_true",
                     help="refine every per-box mask with SAM (sam-vit-base architecture, seeded random weights, "
                          "device-side processor) as real runs do; the default uses box masks (SURVEY.md 8d)")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the rank(s) under torch.distributed.run and initialise RCCL even for --gpus 1: the rendezvous, "
+                         "rank pinning, weight broadcast, barrier and gather code path of an N-GPU run, rehearsed on one GPU")
     ap.add_argument("--cpu-dryrun", action="store_true",
                     help="rendezvous / weight broadcast / partition / timing collectives on CPU (gloo), no GPU work")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.spawn) and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn(args.gpus))
     if args.config is None:
         args.config = {"backward_guidance": "sd21", "sdxl_refiner": "sdxl_refiner", "lmd": "sd15"}.get(args.workload, "sd14_gligen")
@@ -539,13 +542,13 @@ def main():
     from lgd_amd.vae import make_hip_vae
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.spawn:
         ldist.init(backend="nccl")
     # rank 0 materialises the weights; everyone else receives the two arenas over RCCL/xGMI
     mb = max(1, args.max_batch)
     mbg = max(1, min(args.max_batch_guided, mb))
     eng = UNetEngine(cfg, dev, weights.synth_state_dict(cfg, 0) if rank == 0 else None, max_text_batch=max(32, 2 * mb))
-    bcast_s = ldist.broadcast_weights(eng.w, src=0) if world > 1 else 0.0
+    bcast_s = ldist.broadcast_weights(eng.w, src=0, force=args.spawn) if (world > 1 or args.spawn) else 0.0
     from lgd_amd.lanes import LanePool, make_lanes
     side = 8 * cfg.sample_size
     if args.sam and (args.no_decode or args.workload == "backward_guidance"):

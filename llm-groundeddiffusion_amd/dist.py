@@ -112,19 +112,24 @@ def gather_floats(x: float):
     return [float(o.item()) for o in out]
 
 
-def broadcast_weights(store, src=0, chunk_bytes=256 << 20) -> float:
-    """Replicates a WeightStore: two flat arenas, broadcast in large chunks (fewer, larger
-    collectives suit the point-to-point xGMI links).  Returns seconds."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def broadcast_weights(store, src=0, chunk_bytes=256 << 20, force=False) -> float:
+    """Replicates a WeightStore: two flat arenas, broadcast in large chunks (fewer, larger collectives suit the
+    point-to-point xGMI links), ALL chunks issued as non-blocking collectives and waited for once (round 6: they used to
+    be blocking calls one after another on the default stream).  force: issue the collectives with one rank as well (the
+    1-GPU rehearsal of the N-GPU path, bench.py --spawn).  Returns seconds."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return 0.0
     if store.arena16.is_cuda:
         torch.cuda.synchronize()
     t0 = time.perf_counter()
+    works = []
     for arena in (store.arena16, store.arena32):
         n = arena.numel()
         step = max(1, chunk_bytes // arena.element_size())
         for off in range(0, n, step):
-            dist.broadcast(arena[off:off + step], src=src)
+            works.append(dist.broadcast(arena[off:off + step], src=src, async_op=True))
+    for w in works:
+        w.wait()
     if store.arena16.is_cuda:
         torch.cuda.synchronize()
     store.refresh_scalars()

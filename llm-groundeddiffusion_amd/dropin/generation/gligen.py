@@ -31,7 +31,9 @@ def run(spec, gligen_scheduled_sampling_beta=0.4, bg_seed=1):
     input_embeddings = models.encode_prompts(prompts=[prompt], tokenizer=md.tokenizer, text_encoder=md.text_encoder,
                                              negative_prompt=negative_prompt)
     generator = torch.manual_seed(bg_seed)
-    lat = latents_utils.get_unscaled_latents(batch_size, md.unet.config.in_channels, height, width, generator, md.dtype)
+    # the reference's model_dict.dtype is torch.float unless load_sd(use_fp16=True) (models/models.py:34-38; fp16 arithmetic comes
+    # from autocast): the noise is drawn in fp32 — an fp16 draw consumes the generator differently — and stays fp32 (the sampler keeps fp32 latents)
+    lat = latents_utils.get_unscaled_latents(batch_size, md.unet.config.in_channels, height, width, generator, torch.float32)
     lat = lat * md.scheduler.init_noise_sigma
     lat, images = pipelines.generate_gligen(md, lat, input_embeddings, num_inference_steps, bboxes, phrases,
                                             guidance_scale=guidance_scale,

@@ -1,8 +1,8 @@
 """ORACLE TEST INFRASTRUCTURE (build container only) — BoxDiff goldens, from the reference's OWN code.
 
   1. tests/golden/boxdiff_energy.npz — utils/boxdiff.py:121-196 `compute_ca_loss_boxdiff` (unmodified, through
-     oracle/ref_harness.py) on seeded probability maps of the five BoxDiff keys: loss value and d loss / d map for every
-     key; cases: 16x16 maps with two single-box phrases (the SD1.5 geometry), 8x8 maps (the tiny test network), a phrase
+     oracle/ref_harness.py) on seeded probability maps of the five BoxDiff keys (tests/boxdiff_maps.py regenerates them):
+     loss value and d loss / d map (one tensor: the same for every key and head); cases: 16x16 maps with two single-box phrases (the SD1.5 geometry), 8x8 maps (the tiny test network), a phrase
      with two boxes, a box covering most of the map, and a box so small that its inner-box top-k has k = 0.
   2. tests/golden/run_boxdiff_tiny.npz — the reference's own `generation/boxdiff.run` (generation/boxdiff.py:46-131) on
      the tiny network with the fake tokenizer / text encoder of tests/fake_text.py: the latents entering every
@@ -25,37 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ref_harness as H  # noqa: E402
 from make_golden_runs import SPEC, SPEC3, build, record_phrase_calls  # noqa: E402
 
-KEYS = [("down", 2, 0, 0), ("down", 2, 1, 0), ("up", 1, 0, 0), ("up", 1, 1, 0), ("up", 1, 2, 0)]    # generation/boxdiff.py:33-39
-
-
-def energy_cases():
-    return dict(
-        hw256=dict(side=16, heads=8, bboxes=[[0.15, 0.35, 0.5, 0.8], [0.6, 0.38, 0.98, 0.8]], pos=[[1, 2, 3], [5, 6, 7]], seed=0),
-        hw64=dict(side=8, heads=4, bboxes=[[0.1, 0.3, 0.45, 0.85], [0.55, 0.3, 0.95, 0.8]], pos=[[1, 2, 3], [5, 6, 7]], seed=1),
-        two_boxes=dict(side=16, heads=8, bboxes=[[[0.05, 0.5, 0.3, 0.9], [0.4, 0.45, 0.7, 0.85]], [[0.72, 0.1, 0.97, 0.4]]],
-                       pos=[[2, 3], [9]], seed=2),
-        edge=dict(side=16, heads=8, bboxes=[[0.0, 0.0, 1.0, 0.6], [0.3, 0.7, 0.62, 0.97]], pos=[[4], [6, 7]], seed=3),
-        # a 2 x 2-pixel box: (mask.sum() * P).long() = 0 -> top-k of ZERO elements, mean = NaN, and Python's
-        # max(0, 1 - nan) = 0 drops the inner-box term (utils/boxdiff.py:81-83,107)
-        tiny_box=dict(side=16, heads=8, bboxes=[[0.5, 0.5, 0.62, 0.62], [0.1, 0.2, 0.4, 0.9]], pos=[[2, 3], [8]], seed=4),
-    )
-
-
-def make_maps(side, heads, seed):
-    """Five maps [1, heads, HW, 77] of probabilities over the 77 text tokens with a spatial structure (so that the
-    token soft-max at x100 is not one-hot everywhere and the top-k selections are not degenerate)."""
-    g = torch.Generator().manual_seed(seed)
-    hw = side * side
-    out = {}
-    yy, xx = torch.meshgrid(torch.linspace(0, 1, side), torch.linspace(0, 1, side), indexing="ij")
-    for k in KEYS:
-        logits = torch.randn((1, heads, hw, 77), generator=g) * 0.3
-        for tok in range(1, 12):                                        # smooth bumps per token, different per head
-            cx, cy = torch.rand(heads, generator=g), torch.rand(heads, generator=g)
-            bump = torch.exp(-(((xx[None] - cx[:, None, None]) ** 2 + (yy[None] - cy[:, None, None]) ** 2) / 0.05))
-            logits[0, :, :, tok] += 2.0 * bump.reshape(heads, hw)
-        out[k] = logits.softmax(dim=-1)
-    return out
+from boxdiff_maps import KEYS, energy_cases, make_maps  # noqa: E402  (tests/boxdiff_maps.py: shared with the tests)
 
 
 def golden_energy():
@@ -71,10 +41,14 @@ def golden_energy():
                                                    guidance_attn_keys=KEYS, ref_ca_saved_attns=None, index=0, verbose=False)
         grads = torch.autograd.grad(loss, [leaves[k] for k in KEYS])
         outs[f"{name}_loss"] = np.array(float(loss))
-        outs[f"{name}_spec"] = np.array(json.dumps(dict(side=c["side"], heads=c["heads"], bboxes=c["bboxes"], pos=c["pos"])))
-        for i, k in enumerate(KEYS):
-            outs[f"{name}_map{i}"] = maps[k].numpy()
-            outs[f"{name}_grad{i}"] = grads[i].numpy()
+        outs[f"{name}_spec"] = np.array(json.dumps(dict(side=c["side"], heads=c["heads"], bboxes=c["bboxes"], pos=c["pos"], seed=c["seed"])))
+        # the energy sees the MEAN over keys and heads (utils/boxdiff.py:152): d loss / d map is one tensor, repeated for every
+        # key and head — stored once (the maps themselves are regenerated from the seed: tests/boxdiff_maps.py)
+        for i in range(1, len(KEYS)):
+            assert torch.equal(grads[i], grads[0])
+        assert all(torch.equal(grads[0][:, h], grads[0][:, 0]) for h in range(c["heads"]))
+        outs[f"{name}_grad"] = grads[0][0, 0].numpy()                                  # [HW, 77]
+        outs[f"{name}_map0_checksum"] = np.array(float(maps[KEYS[0]].double().sum()))
         print(name, "loss", float(loss), "grad norms", [round(float(gm.norm()), 5) for gm in grads])
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "boxdiff_energy.npz"), **outs)
     print("wrote boxdiff_energy.npz")

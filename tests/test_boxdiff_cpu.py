@@ -15,6 +15,7 @@ import lgd_amd  # noqa: E402,F401
 from lgd_amd import weights  # noqa: E402
 import restate as R  # noqa: E402
 import restate_boxdiff as B  # noqa: E402
+from boxdiff_maps import make_maps  # noqa: E402
 
 KEYS = B.BOXDIFF_GUIDANCE_ATTN_KEYS
 CASES = ("hw256", "hw64", "two_boxes", "edge", "tiny_box")
@@ -26,13 +27,15 @@ def test_oracle_boxdiff_energy_matches_the_reference_function():
     g = np.load(os.path.join(GOLD, "boxdiff_energy.npz"))
     for name in CASES:
         spec = json.loads(str(g[f"{name}_spec"]))
-        leaves = {k: torch.from_numpy(g[f"{name}_map{i}"]).clone().requires_grad_(True) for i, k in enumerate(KEYS)}
+        maps = make_maps(spec["side"], spec["heads"], spec["seed"])             # the golden's inputs, regenerated from the seed
+        assert float(maps[tuple(KEYS[0])].double().sum()) == float(g[f"{name}_map0_checksum"]), name
+        leaves = {tuple(k): maps[tuple(k)].clone().requires_grad_(True) for k in KEYS}
         loss = B.compute_ca_loss_boxdiff(leaves, spec["bboxes"], spec["pos"], KEYS)
-        grads = torch.autograd.grad(loss, [leaves[k] for k in KEYS])
+        grads = torch.autograd.grad(loss, [leaves[tuple(k)] for k in KEYS])
         assert abs(float(loss.detach()) - float(g[f"{name}_loss"])) <= 1e-6 * abs(float(g[f"{name}_loss"])), name
+        ref = torch.from_numpy(g[f"{name}_grad"])                                # [HW, 77]: the same for every key and head
         for i, gr in enumerate(grads):
-            ref = torch.from_numpy(g[f"{name}_grad{i}"])
-            assert float((gr - ref).abs().max()) <= 1e-6 * float(ref.abs().max()), (name, i)
+            assert float((gr - ref[None, None]).abs().max()) <= 1e-6 * float(ref.abs().max()), (name, i)
 
 
 def test_gaussian_kernel_is_the_reference_smoothing_kernel():

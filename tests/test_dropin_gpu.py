@@ -23,6 +23,7 @@ def relerr(a, b):
 
 
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))           # restate_vae (the torch VAE restatement: test infrastructure)
 from conftest import gate  # noqa: E402
 from fake_text import FakeTextEncoder, FakeTokenizer  # noqa: E402
 
@@ -34,7 +35,8 @@ def dropin(dev):
     from lgd_amd import weights
     import models
     cfg = weights.CONFIGS["tiny_gligen"]
-    from lgd_amd.vae import HipVAEDecoder, VAEDecoder
+    from lgd_amd.vae import HipVAEDecoder
+    from restate_vae import VAEDecoder        # oracle/restate_vae.py (test infrastructure)
     torch.manual_seed(5)
     vae = HipVAEDecoder(VAEDecoder(ch=(128, 64, 64, 64), layers=1).float().eval(), dev)
     models.model_dict = models.build_model_dict(cfg, weights.synth_state_dict(cfg, 0), vae=vae,
@@ -443,7 +445,8 @@ def test_backward_guidance_run_vs_reference_run_golden(dev):
     keep = models.model_dict
     try:
         cfg = weights.CONFIGS["tiny"]
-        from lgd_amd.vae import HipVAEDecoder, VAEDecoder
+        from lgd_amd.vae import HipVAEDecoder
+        from restate_vae import VAEDecoder        # oracle/restate_vae.py (test infrastructure)
         torch.manual_seed(5)
         vae = HipVAEDecoder(VAEDecoder(ch=(128, 64, 64, 64), layers=1).float().eval(), dev)
         models.model_dict = models.build_model_dict(cfg, weights.synth_state_dict(cfg, 0), vae=vae, tokenizer=FakeTokenizer(),

@@ -335,7 +335,8 @@ def test_teacher_forced_guided_steps_vs_reference_golden(dev, which):
 
 def test_hip_vae_decoder_vs_torch(dev):
     """[ext] VAE decoder on the engine's kernels vs the plain-PyTorch module (fp32, CPU)."""
-    from lgd_amd.vae import HipVAEDecoder, VAEDecoder
+    from lgd_amd.vae import HipVAEDecoder
+    from restate_vae import VAEDecoder        # oracle/restate_vae.py (test infrastructure)
     torch.manual_seed(7)
     vae = VAEDecoder(ch=(128, 128, 64, 64), layers=1).float().eval()
     hip = HipVAEDecoder(vae, dev)
@@ -353,7 +354,8 @@ def test_hip_vae_decoder_full_size_from_autoencoderkl_state_dict(dev):
     512x512 image) loaded through AutoencoderKL's state-dict key names (both attention namings a checkpoint may
     carry) and run on the HIP kernels, vs the fp32 torch module on the host; B = 1 and a batch of 8 (the sampler's
     decode chunk: batched mid-block attention, per-image results independent of the batch)."""
-    from lgd_amd.vae import HipVAEDecoder, VAEDecoder
+    from lgd_amd.vae import HipVAEDecoder
+    from restate_vae import VAEDecoder        # oracle/restate_vae.py (test infrastructure)
     torch.manual_seed(11)
     vae = VAEDecoder().float().eval()
     torch.set_num_threads(min(os.cpu_count() or 1, 32))

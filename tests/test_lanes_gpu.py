@@ -79,3 +79,26 @@ def test_job_error_reaches_the_caller_and_the_pool_survives(dev):
             pool.map(bad, [0, 1, 0])
         out = pool.map(bad, [0, 0])
         assert torch.equal(out[0][0]["latents"], out[1][0]["latents"])
+
+
+def test_bench_self_spawn_path_with_rccl_on_one_gpu():
+    """the first real N-GPU run must not also be the first run of bench.py's self-spawn path.  `--gpus 1
+    --spawn` goes through `respawn` (python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1,
+    a free port), rank pinning, RCCL init with one rank, the non-blocking chunked arena broadcast, the barriers and the
+    gather of per-rank times, on the full-width network — everything an 8-GPU run does except crossing xGMI."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--steps", "1", "--warmup", "0",
+           "--num-inference-steps", "2", "--layouts", "1", "--lanes", "1", "--no-cpu-baseline", "--no-roofline", "--no-decode"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1 and line["value"] > 0
+    assert line["config"]["weight_broadcast_s"] > 0.0                    # the collectives were really issued
+    assert len(line["config"]["per_rank_busy_s"]) == 1
