@@ -328,6 +328,293 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
 int g_gn_fused_hw = 256;
 
 // ------------------------------------------------------------------------------------------
+// GroupNorm(+SiLU) in ONE launch for the LARGE maps (round 6): the 64x64 and 32x32 levels.  Same idea as
+// gn_fused_kernel — a workgroup owns the (image, kg groups) slab and reads it ONCE — but the slab (4096 pixels x 40
+// channels = 320 KB at the 64x64 level) lives in the register file of a 1024-thread workgroup (16 waves, 128 VGPRs
+// each = the CU's whole 512 KB file): MAXP <= 21 sixteen-byte vectors per thread.  The two-launch form moves the map
+// three times (statistics read, apply read, write) and was 7 % of the kernel time of an image at 2.3 TB/s.
+// Reduction: a thread folds its 8 channels into the (at most two, cpg >= 8) groups its vector touches, deposits the
+// two pairs in LDS at [column][pixel lane]; one wave per column adds the pixel lanes (lane-strided, then a butterfly);
+// thread t < kg adds the columns of group t.  Fixed order, no atomics: bit-reproducible.  Statistics are the
+// one-pass (sum, sum of squares) form of gn_stats_kernel / gn_apply_kernel, whose arithmetic this replaces.
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void gn_slab_reduce(float* s_col, float* s_tot, float (*s_g)[2], bool active, int plane,
+                                               int vcol, int nv, int pl, int cpg, int kg, float lo_a, float lo_b,
+                                               float hi_a, float hi_b) {
+  const int ncol = 2 * nv;
+  if (active) {
+    s_col[(2 * vcol + 0) * pl + plane] = lo_a;
+    s_col[(2 * vcol + 1) * pl + plane] = hi_a;
+    s_col[(ncol + 2 * vcol + 0) * pl + plane] = lo_b;
+    s_col[(ncol + 2 * vcol + 1) * pl + plane] = hi_b;
+  }
+  __syncthreads();
+  {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = w; c < ncol; c += NT / 64) {
+      float pa = 0.f, pb = 0.f;
+      for (int i = lane; i < pl; i += 64) {
+        pa += s_col[c * pl + i];
+        pb += s_col[(ncol + c) * pl + i];
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        pa += __shfl_xor(pa, o, 64);
+        pb += __shfl_xor(pb, o, 64);
+      }
+      if (lane == 0) { s_tot[c] = pa; s_tot[64 + c] = pb; }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kg) {
+    const int t = threadIdx.x;
+    const int v_lo = (t * cpg) / 8, v_hi = ((t + 1) * cpg - 1) / 8;
+    float a = 0.f, b = 0.f;
+    for (int v = v_lo; v <= v_hi; ++v) {
+      const int which = t - (8 * v) / cpg;          // 0: the group the vector starts in, 1: the next one
+      a += s_tot[2 * v + which];
+      b += s_tot[64 + 2 * v + which];
+    }
+    s_g[t][0] = a;
+    s_g[t][1] = b;
+  }
+  __syncthreads();
+}
+
+template <int NT, int MAXP, bool SILU>
+__global__ __launch_bounds__(NT) void gn_slab_kernel(const half_t* __restrict__ x0, const half_t* __restrict__ x1,
+                                                      int c0, int c1, int HW, int G, float eps,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      half_t* __restrict__ y, float* stats, int kg) {
+  __shared__ float s_col[4 * NT];
+  __shared__ float s_tot[128];
+  __shared__ float s_g[8][2];
+  const int tid = threadIdx.x;
+  const int C = c0 + c1, cpg = C / G;
+  const int b = blockIdx.y, g_lo = blockIdx.x * kg;
+  const int W = kg * cpg, nv = W / 8, pl = NT / nv;
+  const int vcol = tid % nv, plane = tid / nv;
+  const bool active = plane < pl;
+  const int c = g_lo * cpg + vcol * 8;                 // first of this thread's 8 channels
+  const bool second = c >= c0;
+  const half_t* src = (second ? x1 : x0) + (long)b * HW * (second ? c1 : c0) + (second ? c - c0 : c);
+  const int ld = second ? c1 : c0;
+  half8_t h[MAXP];
+  {
+    // ONE running pointer (pinned by the empty asm): left alone the compiler materialises all MAXP 64-bit addresses
+    // in front of the loads — 42 registers next to the 84 of the slab
+    const half_t* lp = src + (long)plane * ld;
+    const long lstep = (long)pl * ld;
+#pragma unroll
+    for (int u = 0; u < MAXP; ++u) {
+      const int pp = plane + u * pl;
+      const bool ok = active && pp < HW;                 // branch-free: a valid address either way; pixels past the map are
+      h[u] = *reinterpret_cast<const half8_t*>(ok ? lp : src);   // zeroed where the statistics read them
+      lp += lstep;
+      asm volatile("" : "+v"(lp));
+    }
+  }
+  const int gl = (8 * vcol) / cpg;                     // slab-local group the vector starts in
+  const int e0 = (gl + 1) * cpg - 8 * vcol;            // its first e0 (>= 1) channels belong to that group
+  float lo_a = 0.f, lo_b = 0.f, hi_a = 0.f, hi_b = 0.f;
+  {
+    float sa_[8], sq_[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sa_[e] = 0.f; sq_[e] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < MAXP; ++u) {
+      __builtin_amdgcn_sched_barrier(0);                 // convert vector by vector (register pressure)
+      asm volatile("" : "+v"(h[u]));
+      if (!(active && plane + u * pl < HW)) h[u] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = (float)h[u][e];
+        sa_[e] += f;
+        sq_[e] += f * f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (e < e0) { lo_a += sa_[e]; lo_b += sq_[e]; }
+      else { hi_a += sa_[e]; hi_b += sq_[e]; }
+    }
+  }
+  gn_slab_reduce<NT>(s_col, s_tot, s_g, active, plane, vcol, nv, pl, cpg, kg, lo_a, lo_b, hi_a, hi_b);
+  // the slab stays in registers as fp16: without this the compiler keeps the fp32 conversions of the statistics loop
+  // alive for the apply loop (twice the registers: 500 spilled at MAXP = 22)
+#pragma unroll
+  for (int u = 0; u < MAXP; ++u) asm volatile("" : "+v"(h[u]));
+  const float inv_n = 1.f / ((float)HW * cpg);
+  if (tid < kg && stats) {
+    const float mean = s_g[tid][0] * inv_n;
+    float var = s_g[tid][1] * inv_n - mean * mean;
+    if (var < 0.f) var = 0.f;
+    stats[((long)b * G + g_lo + tid) * 2 + 0] = mean;
+    stats[((long)b * G + g_lo + tid) * 2 + 1] = rsqrtf(var + eps);
+  }
+  if (!active) return;
+  float sa[8], sb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int g = e < e0 ? gl : gl + 1;
+    const float mean = s_g[g][0] * inv_n;
+    float var = s_g[g][1] * inv_n - mean * mean;
+    if (var < 0.f) var = 0.f;
+    sa[e] = rsqrtf(var + eps) * gamma[c + e];
+    sb[e] = beta[c + e] - mean * sa[e];
+  }
+  half_t* dst = y + (long)b * HW * C + c + (long)plane * C;
+  const long dstep = (long)pl * C;
+#pragma unroll
+  for (int u = 0; u < MAXP; ++u) {
+    const int pp = plane + u * pl;
+    if (pp < HW) {
+      half8_t o;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" : "+v"(h[u]));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)h[u][e] * sa[e] + sb[e];
+        if constexpr (SILU) f = silu_f(f);
+        o[e] = (half_t)f;
+      }
+      *reinterpret_cast<half8_t*>(dst) = o;
+    }
+    dst += dstep;
+    asm volatile("" : "+v"(dst));
+  }
+}
+
+// GroupNorm backward (w.r.t. x) in ONE launch, same slab ownership: x and gy of the slab are read once into registers,
+// S1 = sum dxhat and S2 = sum dxhat * xhat reduced as above, dx written from the registers.  The two-launch form read
+// both tensors twice and, on the 8x8 .. 32x32 maps of the guidance backward (4 images), paid two launch floors.
+template <int NT, int MAXP, bool SILU>
+__global__ __launch_bounds__(NT) void gn_bwd_slab_kernel(const half_t* __restrict__ gy, const half_t* __restrict__ x0,
+                                                          const half_t* __restrict__ x1, int c0, int c1, int HW, int G,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ stats, half_t* gx0,
+                                                          half_t* gx1, int accumulate, int kg) {
+  __shared__ float s_col[4 * NT];
+  __shared__ float s_tot[128];
+  __shared__ float s_g[8][2];
+  const int tid = threadIdx.x;
+  const int C = c0 + c1, cpg = C / G;
+  const int b = blockIdx.y, g_lo = blockIdx.x * kg;
+  const int W = kg * cpg, nv = W / 8, pl = NT / nv;
+  const int vcol = tid % nv, plane = tid / nv;
+  const bool active = plane < pl;
+  const int c = g_lo * cpg + vcol * 8;
+  const bool second = c >= c0;
+  const int ld = second ? c1 : c0;
+  const long xoff = (long)b * HW * ld + (second ? c - c0 : c);
+  const half_t* src = (second ? x1 : x0) + xoff;
+  const half_t* gsrc = gy + (long)b * HW * C + c;
+  half8_t hx[MAXP], hg[MAXP];
+  {
+    const half_t* lp = src + (long)plane * ld;           // running pointers, pinned (see gn_slab_kernel)
+    const half_t* gp = gsrc + (long)plane * C;
+    const long lstep = (long)pl * ld, gstep = (long)pl * C;
+#pragma unroll
+    for (int u = 0; u < MAXP; ++u) {
+      const int pp = plane + u * pl;
+      const bool ok = active && pp < HW;
+      hx[u] = *reinterpret_cast<const half8_t*>(ok ? lp : src);      // branch-free (see gn_slab_kernel)
+      hg[u] = *reinterpret_cast<const half8_t*>(ok ? gp : gsrc);
+      lp += lstep;
+      gp += gstep;
+      asm volatile("" : "+v"(lp), "+v"(gp));
+    }
+  }
+  const int gl = (8 * vcol) / cpg;
+  const int e0 = (gl + 1) * cpg - 8 * vcol;
+  // xhat = x * ra + rb;  z = gm * xhat + bt
+  float ra[8], rb[8], gm[8], bt[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int g = g_lo + (e < e0 ? gl : gl + 1);
+    const bool in = active && g < G;                    // the last vector of the slab never reaches past its groups; guard anyway
+    const float mean = in ? stats[((long)b * G + g) * 2] : 0.f;
+    const float rstd = in ? stats[((long)b * G + g) * 2 + 1] : 0.f;
+    ra[e] = rstd;
+    rb[e] = -mean * rstd;
+    gm[e] = active ? gamma[c + e] : 0.f;
+    bt[e] = active ? beta[c + e] : 0.f;
+  }
+  float lo_a = 0.f, lo_b = 0.f, hi_a = 0.f, hi_b = 0.f;
+  {
+    float a1[8], a2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < MAXP; ++u) {
+      __builtin_amdgcn_sched_barrier(0);                  // convert vector by vector (register pressure)
+      asm volatile("" : "+v"(hx[u]), "+v"(hg[u]));
+      if (!(active && plane + u * pl < HW)) hg[u] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};   // zero gradient: contributes nothing
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (float)hx[u][e] * ra[e] + rb[e];
+        float dz = (float)hg[u][e];
+        if constexpr (SILU) dz *= silu_grad_f(gm[e] * xh + bt[e]);
+        const float dxh = dz * gm[e];
+        a1[e] += dxh;
+        a2[e] += dxh * xh;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (e < e0) { lo_a += a1[e]; lo_b += a2[e]; }
+      else { hi_a += a1[e]; hi_b += a2[e]; }
+    }
+  }
+  gn_slab_reduce<NT>(s_col, s_tot, s_g, active, plane, vcol, nv, pl, cpg, kg, lo_a, lo_b, hi_a, hi_b);
+#pragma unroll
+  for (int u = 0; u < MAXP; ++u) asm volatile("" : "+v"(hx[u]), "+v"(hg[u]));     // keep the slab fp16 (see gn_slab_kernel)
+  if (!active) return;
+  const float inv_n = 1.f / ((float)HW * cpg);
+  const float m1_lo = s_g[gl][0] * inv_n, m2_lo = s_g[gl][1] * inv_n;
+  const float m1_hi = e0 < 8 ? s_g[gl + 1][0] * inv_n : 0.f, m2_hi = e0 < 8 ? s_g[gl + 1][1] * inv_n : 0.f;
+  half_t* dst = (second ? gx1 : gx0) + xoff + (long)plane * ld;
+  const long dstep = (long)pl * ld;
+#pragma unroll
+  for (int u = 0; u < MAXP; ++u, dst += dstep) {
+    const int pp = plane + u * pl;
+    asm volatile("" : "+v"(dst));
+    if (pp < HW) {
+      half8_t ho;
+      if (accumulate) ho = *reinterpret_cast<const half8_t*>(dst);
+      half8_t o;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" : "+v"(hx[u]), "+v"(hg[u]));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (float)hx[u][e] * ra[e] + rb[e];
+        float dz = (float)hg[u][e];
+        if constexpr (SILU) dz *= silu_grad_f(gm[e] * xh + bt[e]);
+        const float dxh = dz * gm[e];
+        float dx = ra[e] * (dxh - (e < e0 ? m1_lo : m1_hi) - xh * (e < e0 ? m2_lo : m2_hi));
+        if (accumulate) dx += (float)ho[e];
+        o[e] = (half_t)dx;
+      }
+      *reinterpret_cast<half8_t*>(dst) = o;
+    }
+  }
+}
+
+// option "gn_slab": 1 = the one-launch slab kernels take every map they can hold (default), 0 = two launches
+int g_gn_slab = 1;
+
+// slab geometry of a GroupNorm problem: kg groups per workgroup (smallest count whose channels fill whole 16-byte
+// vectors); false when the slab kernels cannot take it (a vector would straddle three groups, too many columns)
+bool gn_slab_geometry(int C, int G, int& kg, int& nv) {
+  const int cpg = C / G;
+  kg = 1;
+  while ((kg * cpg) % 8) kg *= 2;
+  nv = kg * cpg / 8;
+  return cpg >= 8 && kg <= 8 && (G % kg) == 0 && nv <= 32;
+}
+
+// ------------------------------------------------------------------------------------------
 // GroupNorm backward (w.r.t. x).  With xhat = (x-mean)*rstd, z = gamma*xhat+beta, y = act(z):
 //   dz = gy * act'(z);  dxhat = dz*gamma
 //   dx = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat*xhat))
@@ -728,7 +1015,8 @@ int gn_apply_blocks(int B, int HW, int C) {
 
 }  // namespace
 
-void lgd_gn_set_fused_hw(int hw) { g_gn_fused_hw = hw; }    // lgd_set_option("gn_fused", hw) (attn.hip)
+void lgd_gn_set_fused_hw(int hw) { g_gn_fused_hw = hw; }
+void lgd_gn_set_slab(int on) { g_gn_slab = on; }            // lgd_set_option("gn_slab", 0 | 1) (attn.hip)    // lgd_set_option("gn_fused", hw) (attn.hip)
 
 extern "C" int lgd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, int B, int HW,
                                  int G, float eps, const float* gamma, const float* beta, int silu,
@@ -759,6 +1047,25 @@ extern "C" int lgd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1,
       }
     }
   }
+  {
+    // large maps: the slab in the registers of a 1024-thread workgroup
+    int kg, nv;
+    if (g_gn_slab && gn_slab_geometry(C, G, kg, nv) && (c0 % 8) == 0) {
+      const int pl = 1024 / nv, npx = (HW + pl - 1) / pl;
+      if (npx <= 21) {
+#define GN_SLAB_(P, S)                                                                                              \
+  hipLaunchKernelGGL((gn_slab_kernel<1024, P, S>), dim3(G / kg, B), dim3(1024), 0, st, (const half_t*)x0,             \
+                     (const half_t*)x1, c0, c1, HW, G, eps, gamma, beta, (half_t*)y, stats, kg)
+#define GN_SLAB(P) do { if (silu) GN_SLAB_(P, true); else GN_SLAB_(P, false); } while (0)
+        if (npx <= 8) GN_SLAB(8);
+        else if (npx <= 16) GN_SLAB(16);
+        else GN_SLAB(21);
+#undef GN_SLAB
+#undef GN_SLAB_
+        return lgd_check_launch();
+      }
+    }
+  }
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, st, (const half_t*)x0,
                      (const half_t*)x1, c0, c1, HW, G, part, nchunk);
   const int napply = gn_apply_blocks(B, HW, C);
@@ -776,6 +1083,20 @@ extern "C" int lgd_groupnorm_bwd_f16(const void* gy, const void* x0, const void*
   const int C = c0 + c1;
   if (G > 64 || C > GN_MAXC || (C % G) || (c0 % 8) || (c1 % 8) || nchunk < 1) return LGD_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  {
+    int kg, nv;
+    if (g_gn_slab && gn_slab_geometry(C, G, kg, nv)) {
+#define GN_BWD_SLAB_(NT, P, S)                                                                                      \
+  hipLaunchKernelGGL((gn_bwd_slab_kernel<NT, P, S>), dim3(G / kg, B), dim3(NT), 0, st, (const half_t*)gy,             \
+                     (const half_t*)x0, (const half_t*)x1, c0, c1, HW, G, gamma, beta, stats, (half_t*)gx0,           \
+                     (half_t*)gx1, accumulate, kg)
+#define GN_BWD_SLAB(NT, P) do { if (silu) GN_BWD_SLAB_(NT, P, true); else GN_BWD_SLAB_(NT, P, false); } while (0)
+      if (HW <= 8 * (256 / nv)) { GN_BWD_SLAB(256, 8); return lgd_check_launch(); }
+      if (HW <= 11 * (512 / nv)) { GN_BWD_SLAB(512, 11); return lgd_check_launch(); }
+#undef GN_BWD_SLAB
+#undef GN_BWD_SLAB_
+    }
+  }
   hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nchunk, B), dim3(256), 0, st, (const half_t*)gy,
                      (const half_t*)x0, (const half_t*)x1, c0, c1, HW, G, gamma, beta, silu, stats,
                      part, nchunk);

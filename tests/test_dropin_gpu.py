@@ -357,7 +357,7 @@ def test_gligen_plugin_vs_reference_run_golden(dropin, dev):
             assert np.allclose(np.array(rec[0]["bboxes"]), np.array(want["bboxes"]), atol=0, rtol=0)
             assert torch.equal(rec[0]["lat"], torch.from_numpy(gold[f"{tag}_latents_in"]))          # seeded CPU noise, bit for bit
             gate(f"[run gligen {tag}] final latents (8 plain GLIGEN steps, free-running)", relerr(rec[0]["out"], gold[f"{tag}_final_latents"]), 1.5e-2)
-            assert r.image.dtype == np.uint8 and tuple(r.image.shape) == tuple(gold[f"{tag}_image_shape"])
+            assert r.image.dtype == np.uint8 and tuple(r.image.shape) == (256, 256, 3)      # (the golden run's stub VAE does not upsample)
     finally:
         g.pipelines.generate_gligen = o_gl
 

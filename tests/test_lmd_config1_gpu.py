@@ -76,9 +76,10 @@ def _check_steps(sm, tag, starts, final, iters, losses, loss_scale, ehs, lim_gui
         assert out["guidance_iters"] == int(iters[s]), (tag, s, out["guidance_iters"], int(iters[s]))
         if kw.get("saved_ref") is not None:
             # the maps this step SAVED (pipelines.py:129-247 return_saved_cross_attn: condition half, word token) against the
-            # reference's own, before lmd.run aligns them: {key: [T_run = 1, Bp = 1, heads, HW, 1]} vs [T, heads, HW]
+            # reference's own, before lmd.run aligns them: {key: [T, Bp = 1, heads, HW, 1]} (row = the absolute step index;
+            # a one-step run fills row s only) vs [T, heads, HW]
             for ki, k_ in enumerate(kw["saved_keys"]):
-                got_m = out["saved"][k_][0, 0, :, :, 0].float().cpu()
+                got_m = out["saved"][k_][s, 0, :, :, 0].float().cpu()
                 ref_m = torch.from_numpy(kw["saved_ref"][ki][s].astype(np.float32))
                 worst_map = max(kw["map_err"].get(k_, 0.0), float((got_m - ref_m).abs().max() / ref_m.abs().max().clamp_min(1e-12)))
                 kw["map_err"][k_] = worst_map

@@ -336,6 +336,62 @@ def test_groupnorm_one_launch_vs_torch_and_two_launch(dev, B, HW, C0, C1, silu):
     assert relerr(y1, y2) < 3e-3
 
 
+@pytest.mark.parametrize("B,HW,C0,C1,silu", [
+    (3, 4096, 320, 0, True), (2, 4096, 320, 320, True), (2, 4096, 320, 0, False),      # 64x64: cpg 10 (4 groups / slab), cpg 20; 21 vectors per thread
+    (2, 1024, 640, 0, True), (2, 1024, 1280, 640, True), (1, 1024, 640, 320, True),     # 32x32: cpg 20, 60 (15 columns), 30
+    (2, 1000, 1280, 0, False), (1, 300, 2560, 0, True), (2, 4000, 640, 0, True),       # ragged pixel counts; cpg 80 (10 columns)
+    (2, 256, 1280, 0, True), (4, 64, 1280, 1280, True), (2, 256, 1280, 640, False),     # backward on the small maps (256-thread slabs)
+])
+def test_groupnorm_slab_kernels_vs_torch_and_two_launch(dev, B, HW, C0, C1, silu):
+    """Round 6: GroupNorm forward of the 64x64 / 32x32 levels and GroupNorm backward in ONE launch (csrc/norm.hip
+    gn_slab_kernel, gn_bwd_slab_kernel: the (image, groups) slab in the registers of one workgroup) against torch and
+    against the two-launch kernels they replace (option "gn_slab" = 0), statistics and the accumulating backward
+    included.  Forward maps of <= 256 pixels take gn_fused_kernel either way; their backward is the slab kernel."""
+    C, G, eps = C0 + C1, 32, 1e-5
+    x = (rnd(B, HW, C, dev=dev, seed=1) * 2 + 3.0 * rnd(B, 1, C, dev=dev, seed=9)).half()      # per-channel offsets: mean >> std in places
+    gamma, beta = 1 + 0.2 * rnd(C, dev=dev, seed=2), 0.2 * rnd(C, dev=dev, seed=3)
+    x0 = x[..., :C0].reshape(B * HW, C0).contiguous()
+    x1 = x[..., C0:].reshape(B * HW, C1).contiguous() if C1 else None
+    gy = rnd(B * HW, C, dev=dev, seed=4).half()
+    acc0 = rnd(B * HW, C0, dev=dev, seed=5).half()
+    acc1 = rnd(B * HW, C1, dev=dev, seed=6).half() if C1 else None
+    res = []
+    try:
+        for slab in (1, 0):
+            ops.set_option("gn_slab", slab)
+            st = torch.zeros(B, G, 2, device=dev)
+            y = ops.groupnorm(x0, B, HW, G, eps, gamma, beta, silu, x1=x1, stats=st)
+            gx0, gx1 = ops.groupnorm_bwd(gy, x0, B, HW, G, gamma, beta, silu, st, x1=x1)
+            a0, a1 = ops.groupnorm_bwd(gy, x0, B, HW, G, gamma, beta, silu, st, x1=x1, gx0=acc0.clone(),
+                                       gx1=acc1.clone() if C1 else None, accumulate=True)
+            res.append((y, st, gx0, gx1, a0, a1))
+    finally:
+        ops.set_option("gn_slab", 1)
+    xr = x.float().permute(0, 2, 1).clone().requires_grad_(True)
+    ref = F.group_norm(xr, G, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    ref.backward(gy.float().reshape(B, HW, C).permute(0, 2, 1))
+    refl = ref.detach().permute(0, 2, 1).reshape(B * HW, C)
+    gref = xr.grad.permute(0, 2, 1).reshape(B * HW, C)
+    xg = x.float().reshape(B, HW, G, C // G)
+    mean, var = xg.mean(dim=(1, 3)), xg.var(dim=(1, 3), unbiased=False)
+    for tag, (y, st, gx0, gx1, a0, a1) in zip(("slab", "two-launch"), res):
+        assert relerr(st[..., 0], mean) < 1e-4 and relerr(st[..., 1], (var + eps).rsqrt()) < 1e-3, tag
+        assert relerr(y, refl) < 3e-3, tag
+        assert relerr(gx0, gref[:, :C0]) < 5e-3, tag
+        assert relerr(a0, gref[:, :C0] + acc0.float()) < 5e-3, tag
+        if C1:
+            assert relerr(gx1, gref[:, C0:]) < 5e-3 and relerr(a1, gref[:, C0:] + acc1.float()) < 5e-3, tag
+    assert relerr(res[0][0], res[1][0]) < 3e-3 and relerr(res[0][2], res[1][2]) < 3e-3
+    # bit-reproducible: fixed summation order, no atomics
+    ops.set_option("gn_slab", 1)
+    st = torch.zeros(B, G, 2, device=dev)
+    y2 = ops.groupnorm(x0, B, HW, G, eps, gamma, beta, silu, x1=x1, stats=st)
+    g2, _ = ops.groupnorm_bwd(gy, x0, B, HW, G, gamma, beta, silu, st, x1=x1)
+    assert torch.equal(y2, res[0][0]) and torch.equal(st, res[0][1]) and torch.equal(g2, res[0][2])
+
+
 @pytest.mark.parametrize("rows,C", [(8192, 320), (2048, 640), (513, 1280), (30, 64)])
 def test_layernorm_fwd_bwd(dev, rows, C):
     x = (rnd(rows, C, dev=dev, seed=1) * 1.5 + 0.3).half()

@@ -122,5 +122,13 @@ PY
     line lmd_v0.1_400prompts --workload lmd_v0.1 --prompts 400 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline
     line backward_guidance_sd21 --workload backward_guidance --steps 4 --warmup 1 --no-cpu-baseline
     line sdxl_refiner --workload sdxl_refiner --steps 2 --warmup 1 --no-cpu-baseline ;;
+  baseline)   # args: TAG; GPU suite + the driver's command + one launch sequence alone with the per-shape profile
+    T=${1:-r06}
+    timeout 1500 python -m pytest tests -q -m gpu -rP > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+    grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -n 3
+    timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/driver.log 2>&1
+    grep '^{' $OUT/driver.log | tail -1 > $OUT/${T}_bench_driver_command_bench_line.json; echo "driver: $(cut -c1-150 $OUT/${T}_bench_driver_command_bench_line.json)"
+    timeout 600 python bench.py --lanes 1 --steps 4 --warmup 1 --no-cpu-baseline --shape-profile $OUT/${T}_shape_profile.json > $OUT/lanes1.log 2>&1
+    grep '^{' $OUT/lanes1.log | tail -1 > $OUT/${T}_bench_lanes1_bench_line.json; echo "lanes1: $(cut -c1-150 $OUT/${T}_bench_lanes1_bench_line.json)" ;;
   *) echo "unknown stage $STAGE"; exit 2 ;;
 esac
