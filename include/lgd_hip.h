@@ -35,9 +35,9 @@ int lgd_abi_version(void);
  * 256 queries and >= 256 keys, 2 = for every problem size; "attn_w4_pipe": 1 = (default) one wave per SIMD with the
  * in-wave software pipeline, 0 = two waves per SIMD.  "gn_fused": the largest map (pixels per image) lgd_groupnorm_f16
  * normalises in ONE launch (a workgroup holds its image x groups slab in registers); default 256 (16x16), 0 = always
- * the two-launch form.  "gn_slab": 1 = (default) larger maps whose (image, groups) slab fits the register file of a
- * 1024-thread workgroup (the 64x64 and 32x32 levels) are normalised in one launch as well, forward and backward, 0 = two
- * launches.  Returns 0, or LGD_ERR_ARG for an unknown name. */
+ * the two-launch form.  "gn_slab": 1 = (default) lgd_groupnorm_bwd_f16 runs in one launch where a workgroup can hold its
+ * (image, groups) slab of x and gy in registers (<= 96 KB: the 8x8 and 16x16 maps), 0 = two launches.  Returns 0, or
+ * LGD_ERR_ARG for an unknown name. */
 int lgd_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------------------------------------

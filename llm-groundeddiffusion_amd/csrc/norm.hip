@@ -328,15 +328,14 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const half_t* __restrict_
 int g_gn_fused_hw = 256;
 
 // ------------------------------------------------------------------------------------------
-// GroupNorm(+SiLU) in ONE launch for the LARGE maps (round 6): the 64x64 and 32x32 levels.  Same idea as
-// gn_fused_kernel — a workgroup owns the (image, kg groups) slab and reads it ONCE — but the slab (4096 pixels x 40
-// channels = 320 KB at the 64x64 level) lives in the register file of a 1024-thread workgroup (16 waves, 128 VGPRs
-// each = the CU's whole 512 KB file): MAXP <= 21 sixteen-byte vectors per thread.  The two-launch form moves the map
-// three times (statistics read, apply read, write) and was 7 % of the kernel time of an image at 2.3 TB/s.
-// Reduction: a thread folds its 8 channels into the (at most two, cpg >= 8) groups its vector touches, deposits the
-// two pairs in LDS at [column][pixel lane]; one wave per column adds the pixel lanes (lane-strided, then a butterfly);
-// thread t < kg adds the columns of group t.  Fixed order, no atomics: bit-reproducible.  Statistics are the
-// one-pass (sum, sum of squares) form of gn_stats_kernel / gn_apply_kernel, whose arithmetic this replaces.
+// Slab reduction shared by the one-launch GroupNorm BACKWARD below (round 6): a workgroup owns the (image, kg groups)
+// slab; a thread folds its 8 channels into the (at most two, cpg >= 8) groups its vector touches and deposits the two
+// pairs in LDS at [column][pixel lane]; one wave per column adds the pixel lanes (lane-strided, then a butterfly);
+// thread t < kg adds the columns of group t.  Fixed order, no atomics: bit-reproducible.
+// (A FORWARD slab kernel for the 64x64 / 32x32 maps — 320 KB slabs in the registers of 1024-thread workgroups — was
+// built and measured in the same round: correct, but 0.4-0.7x of the two-launch form at 64x64 and +-5 % at 32x32: a
+// workgroup streams its slab at ~19 GB/s whatever the batch, i.e. the per-CU limit on outstanding misses, and
+// G / kg x B = 32 .. 128 workgroups cannot replace the ~1000 of the two-launch kernels.  Removed; profiles/HISTORY.md.)
 // ------------------------------------------------------------------------------------------
 template <int NT>
 __device__ __forceinline__ void gn_slab_reduce(float* s_col, float* s_tot, float (*s_g)[2], bool active, int plane,
@@ -382,113 +381,13 @@ __device__ __forceinline__ void gn_slab_reduce(float* s_col, float* s_tot, float
   __syncthreads();
 }
 
-template <int NT, int MAXP, bool SILU>
-__global__ __launch_bounds__(NT) void gn_slab_kernel(const half_t* __restrict__ x0, const half_t* __restrict__ x1,
-                                                      int c0, int c1, int HW, int G, float eps,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      half_t* __restrict__ y, float* stats, int kg) {
-  __shared__ float s_col[4 * NT];
-  __shared__ float s_tot[128];
-  __shared__ float s_g[8][2];
-  const int tid = threadIdx.x;
-  const int C = c0 + c1, cpg = C / G;
-  const int b = blockIdx.y, g_lo = blockIdx.x * kg;
-  const int W = kg * cpg, nv = W / 8, pl = NT / nv;
-  const int vcol = tid % nv, plane = tid / nv;
-  const bool active = plane < pl;
-  const int c = g_lo * cpg + vcol * 8;                 // first of this thread's 8 channels
-  const bool second = c >= c0;
-  const half_t* src = (second ? x1 : x0) + (long)b * HW * (second ? c1 : c0) + (second ? c - c0 : c);
-  const int ld = second ? c1 : c0;
-  half8_t h[MAXP];
-  {
-    // ONE running pointer (pinned by the empty asm): left alone the compiler materialises all MAXP 64-bit addresses
-    // in front of the loads — 42 registers next to the 84 of the slab
-    const half_t* lp = src + (long)plane * ld;
-    const long lstep = (long)pl * ld;
-#pragma unroll
-    for (int u = 0; u < MAXP; ++u) {
-      const int pp = plane + u * pl;
-      const bool ok = active && pp < HW;                 // branch-free: a valid address either way; pixels past the map are
-      h[u] = *reinterpret_cast<const half8_t*>(ok ? lp : src);   // zeroed where the statistics read them
-      lp += lstep;
-      asm volatile("" : "+v"(lp));
-    }
-  }
-  const int gl = (8 * vcol) / cpg;                     // slab-local group the vector starts in
-  const int e0 = (gl + 1) * cpg - 8 * vcol;            // its first e0 (>= 1) channels belong to that group
-  float lo_a = 0.f, lo_b = 0.f, hi_a = 0.f, hi_b = 0.f;
-  {
-    float sa_[8], sq_[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { sa_[e] = 0.f; sq_[e] = 0.f; }
-#pragma unroll
-    for (int u = 0; u < MAXP; ++u) {
-      __builtin_amdgcn_sched_barrier(0);                 // convert vector by vector (register pressure)
-      asm volatile("" : "+v"(h[u]));
-      if (!(active && plane + u * pl < HW)) h[u] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float f = (float)h[u][e];
-        sa_[e] += f;
-        sq_[e] += f * f;
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if (e < e0) { lo_a += sa_[e]; lo_b += sq_[e]; }
-      else { hi_a += sa_[e]; hi_b += sq_[e]; }
-    }
-  }
-  gn_slab_reduce<NT>(s_col, s_tot, s_g, active, plane, vcol, nv, pl, cpg, kg, lo_a, lo_b, hi_a, hi_b);
-  // the slab stays in registers as fp16: without this the compiler keeps the fp32 conversions of the statistics loop
-  // alive for the apply loop (twice the registers: 500 spilled at MAXP = 22)
-#pragma unroll
-  for (int u = 0; u < MAXP; ++u) asm volatile("" : "+v"(h[u]));
-  const float inv_n = 1.f / ((float)HW * cpg);
-  if (tid < kg && stats) {
-    const float mean = s_g[tid][0] * inv_n;
-    float var = s_g[tid][1] * inv_n - mean * mean;
-    if (var < 0.f) var = 0.f;
-    stats[((long)b * G + g_lo + tid) * 2 + 0] = mean;
-    stats[((long)b * G + g_lo + tid) * 2 + 1] = rsqrtf(var + eps);
-  }
-  if (!active) return;
-  float sa[8], sb[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int g = e < e0 ? gl : gl + 1;
-    const float mean = s_g[g][0] * inv_n;
-    float var = s_g[g][1] * inv_n - mean * mean;
-    if (var < 0.f) var = 0.f;
-    sa[e] = rsqrtf(var + eps) * gamma[c + e];
-    sb[e] = beta[c + e] - mean * sa[e];
-  }
-  half_t* dst = y + (long)b * HW * C + c + (long)plane * C;
-  const long dstep = (long)pl * C;
-#pragma unroll
-  for (int u = 0; u < MAXP; ++u) {
-    const int pp = plane + u * pl;
-    if (pp < HW) {
-      half8_t o;
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("" : "+v"(h[u]));
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float f = (float)h[u][e] * sa[e] + sb[e];
-        if constexpr (SILU) f = silu_f(f);
-        o[e] = (half_t)f;
-      }
-      *reinterpret_cast<half8_t*>(dst) = o;
-    }
-    dst += dstep;
-    asm volatile("" : "+v"(dst));
-  }
-}
-
-// GroupNorm backward (w.r.t. x) in ONE launch, same slab ownership: x and gy of the slab are read once into registers,
-// S1 = sum dxhat and S2 = sum dxhat * xhat reduced as above, dx written from the registers.  The two-launch form read
-// both tensors twice and, on the 8x8 .. 32x32 maps of the guidance backward (4 images), paid two launch floors.
+// GroupNorm backward (w.r.t. x) in ONE launch: x and gy of the slab are read once into registers (running pointers and
+// per-vector conversion pinned by empty asm statements: left alone hipcc materialises every address and every fp32
+// conversion up front and spills), S1 = sum dxhat and S2 = sum dxhat * xhat reduced as above, dx written from the
+// registers.  The two-launch form read both tensors twice and, on the 8x8 / 16x16 maps of the guidance backward (4
+// images), paid two launch floors: measured 13.6 -> 9.5 us (8x8, C = 1280), 14.8 -> 11.7 (16x16, C = 1280), 23.4 -> 11.1
+// (8x8, C = 2560), 26.1 -> 21.0 (16x16, C = 2560).  Slabs of more than 96 KB (x + gy) stay on the two-launch kernels:
+// there a workgroup is bound by its CU's outstanding misses (32x32, C = 640: 18.1 -> 25.5 us).
 template <int NT, int MAXP, bool SILU>
 __global__ __launch_bounds__(NT) void gn_bwd_slab_kernel(const half_t* __restrict__ gy, const half_t* __restrict__ x0,
                                                           const half_t* __restrict__ x1, int c0, int c1, int HW, int G,
@@ -512,14 +411,14 @@ __global__ __launch_bounds__(NT) void gn_bwd_slab_kernel(const half_t* __restric
   const half_t* gsrc = gy + (long)b * HW * C + c;
   half8_t hx[MAXP], hg[MAXP];
   {
-    const half_t* lp = src + (long)plane * ld;           // running pointers, pinned (see gn_slab_kernel)
+    const half_t* lp = src + (long)plane * ld;           // ONE running pointer per tensor, pinned by the empty asm below
     const half_t* gp = gsrc + (long)plane * C;
     const long lstep = (long)pl * ld, gstep = (long)pl * C;
 #pragma unroll
     for (int u = 0; u < MAXP; ++u) {
       const int pp = plane + u * pl;
       const bool ok = active && pp < HW;
-      hx[u] = *reinterpret_cast<const half8_t*>(ok ? lp : src);      // branch-free (see gn_slab_kernel)
+      hx[u] = *reinterpret_cast<const half8_t*>(ok ? lp : src);      // branch-free: a valid address either way (masked where used)
       hg[u] = *reinterpret_cast<const half8_t*>(ok ? gp : gsrc);
       lp += lstep;
       gp += gstep;
@@ -569,7 +468,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_slab_kernel(const half_t* __restric
   }
   gn_slab_reduce<NT>(s_col, s_tot, s_g, active, plane, vcol, nv, pl, cpg, kg, lo_a, lo_b, hi_a, hi_b);
 #pragma unroll
-  for (int u = 0; u < MAXP; ++u) asm volatile("" : "+v"(hx[u]), "+v"(hg[u]));     // keep the slab fp16 (see gn_slab_kernel)
+  for (int u = 0; u < MAXP; ++u) asm volatile("" : "+v"(hx[u]), "+v"(hg[u]));     // keep the slab fp16 across the reduction
   if (!active) return;
   const float inv_n = 1.f / ((float)HW * cpg);
   const float m1_lo = s_g[gl][0] * inv_n, m2_lo = s_g[gl][1] * inv_n;
@@ -601,7 +500,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_slab_kernel(const half_t* __restric
   }
 }
 
-// option "gn_slab": 1 = the one-launch slab kernels take every map they can hold (default), 0 = two launches
+// option "gn_slab": 1 = the one-launch backward takes every slab of <= 96 KB it can hold (default), 0 = two launches
 int g_gn_slab = 1;
 
 // slab geometry of a GroupNorm problem: kg groups per workgroup (smallest count whose channels fill whole 16-byte
@@ -1047,25 +946,6 @@ extern "C" int lgd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1,
       }
     }
   }
-  {
-    // large maps: the slab in the registers of a 1024-thread workgroup
-    int kg, nv;
-    if (g_gn_slab && gn_slab_geometry(C, G, kg, nv) && (c0 % 8) == 0) {
-      const int pl = 1024 / nv, npx = (HW + pl - 1) / pl;
-      if (npx <= 21) {
-#define GN_SLAB_(P, S)                                                                                              \
-  hipLaunchKernelGGL((gn_slab_kernel<1024, P, S>), dim3(G / kg, B), dim3(1024), 0, st, (const half_t*)x0,             \
-                     (const half_t*)x1, c0, c1, HW, G, eps, gamma, beta, (half_t*)y, stats, kg)
-#define GN_SLAB(P) do { if (silu) GN_SLAB_(P, true); else GN_SLAB_(P, false); } while (0)
-        if (npx <= 8) GN_SLAB(8);
-        else if (npx <= 16) GN_SLAB(16);
-        else GN_SLAB(21);
-#undef GN_SLAB
-#undef GN_SLAB_
-        return lgd_check_launch();
-      }
-    }
-  }
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, st, (const half_t*)x0,
                      (const half_t*)x1, c0, c1, HW, G, part, nchunk);
   const int napply = gn_apply_blocks(B, HW, C);
@@ -1091,8 +971,11 @@ extern "C" int lgd_groupnorm_bwd_f16(const void* gy, const void* x0, const void*
                      (const half_t*)x0, (const half_t*)x1, c0, c1, HW, G, gamma, beta, stats, (half_t*)gx0,           \
                      (half_t*)gx1, accumulate, kg)
 #define GN_BWD_SLAB(NT, P) do { if (silu) GN_BWD_SLAB_(NT, P, true); else GN_BWD_SLAB_(NT, P, false); } while (0)
-      if (HW <= 8 * (256 / nv)) { GN_BWD_SLAB(256, 8); return lgd_check_launch(); }
-      if (HW <= 11 * (512 / nv)) { GN_BWD_SLAB(512, 11); return lgd_check_launch(); }
+      const long slab_bytes = 2L * HW * (8 * nv) * 2;             // x and gy of one workgroup
+      if (slab_bytes <= 96 * 1024) {
+        if (HW <= 8 * (256 / nv)) { GN_BWD_SLAB(256, 8); return lgd_check_launch(); }
+        if (HW <= 11 * (512 / nv)) { GN_BWD_SLAB(512, 11); return lgd_check_launch(); }
+      }
 #undef GN_BWD_SLAB
 #undef GN_BWD_SLAB_
     }

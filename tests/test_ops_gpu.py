@@ -337,16 +337,15 @@ def test_groupnorm_one_launch_vs_torch_and_two_launch(dev, B, HW, C0, C1, silu):
 
 
 @pytest.mark.parametrize("B,HW,C0,C1,silu", [
-    (3, 4096, 320, 0, True), (2, 4096, 320, 320, True), (2, 4096, 320, 0, False),      # 64x64: cpg 10 (4 groups / slab), cpg 20; 21 vectors per thread
-    (2, 1024, 640, 0, True), (2, 1024, 1280, 640, True), (1, 1024, 640, 320, True),     # 32x32: cpg 20, 60 (15 columns), 30
-    (2, 1000, 1280, 0, False), (1, 300, 2560, 0, True), (2, 4000, 640, 0, True),       # ragged pixel counts; cpg 80 (10 columns)
-    (2, 256, 1280, 0, True), (4, 64, 1280, 1280, True), (2, 256, 1280, 640, False),     # backward on the small maps (256-thread slabs)
+    (2, 256, 1280, 0, True), (4, 64, 1280, 1280, True), (2, 256, 1280, 1280, False),    # cpg 40, 80: 256- and 512-thread slabs
+    (3, 64, 1280, 0, False), (2, 256, 640, 0, True), (2, 64, 1280, 640, True),          # cpg 20 (two groups per slab), 60
+    (2, 100, 960, 0, True), (1, 256, 320, 0, True), (2, 256, 1280, 640, True),          # ragged map; cpg 10; a slab over 96 KB (two launches)
+    (2, 4096, 320, 0, True), (2, 1024, 640, 320, True),                                  # large maps stay on the two-launch kernels
 ])
-def test_groupnorm_slab_kernels_vs_torch_and_two_launch(dev, B, HW, C0, C1, silu):
-    """Round 6: GroupNorm forward of the 64x64 / 32x32 levels and GroupNorm backward in ONE launch (csrc/norm.hip
-    gn_slab_kernel, gn_bwd_slab_kernel: the (image, groups) slab in the registers of one workgroup) against torch and
-    against the two-launch kernels they replace (option "gn_slab" = 0), statistics and the accumulating backward
-    included.  Forward maps of <= 256 pixels take gn_fused_kernel either way; their backward is the slab kernel."""
+def test_groupnorm_bwd_slab_kernel_vs_torch_and_two_launch(dev, B, HW, C0, C1, silu):
+    """Round 6: GroupNorm backward in ONE launch (csrc/norm.hip gn_bwd_slab_kernel: x and gy of the (image, groups) slab
+    in the registers of one workgroup, taken for slabs of <= 96 KB) against torch and against the two-launch kernels it
+    replaces (option "gn_slab" = 0), the accumulating form included; bit-reproducible."""
     C, G, eps = C0 + C1, 32, 1e-5
     x = (rnd(B, HW, C, dev=dev, seed=1) * 2 + 3.0 * rnd(B, 1, C, dev=dev, seed=9)).half()      # per-channel offsets: mean >> std in places
     gamma, beta = 1 + 0.2 * rnd(C, dev=dev, seed=2), 0.2 * rnd(C, dev=dev, seed=3)

@@ -130,5 +130,15 @@ PY
     grep '^{' $OUT/driver.log | tail -1 > $OUT/${T}_bench_driver_command_bench_line.json; echo "driver: $(cut -c1-150 $OUT/${T}_bench_driver_command_bench_line.json)"
     timeout 600 python bench.py --lanes 1 --steps 4 --warmup 1 --no-cpu-baseline --shape-profile $OUT/${T}_shape_profile.json > $OUT/lanes1.log 2>&1
     grep '^{' $OUT/lanes1.log | tail -1 > $OUT/${T}_bench_lanes1_bench_line.json; echo "lanes1: $(cut -c1-150 $OUT/${T}_bench_lanes1_bench_line.json)" ;;
+  phase_abl)  # ablation of the phase-split GEMM tiles (46, 47) on big shapes: builds the -DLGD_GEMM_ABLATION library on the box
+    python llm-groundeddiffusion_amd/build.py --force > $OUT/build.log 2>&1
+    bash tools/build_abl.sh >> $OUT/build.log 2>&1; tail -n 1 $OUT/build.log
+    for A in ${ABLS:-0 1 2 3 4 16 32 64}; do
+      echo "== ABL $A" >> $OUT/abl.log
+      LGD_GEMM_ABL=$A TILES=${TILES:-46} SHAPES=sq,geglu ROUNDS=3 timeout 200 python tools/gemm_ab.py 2>&1 | grep "^M" | cut -c1-90 >> $OUT/abl.log
+      LGD_GEMM_ABL=$A TILES=${TILES2:-47:2} SHAPES=conv FIRST=2 ROUNDS=3 timeout 200 python tools/gemm_ab.py 2>&1 | grep "^M" | cut -c1-90 >> $OUT/abl.log
+    done
+    cat $OUT/abl.log
+    python llm-groundeddiffusion_amd/build.py --force > /dev/null 2>&1 ;;
   *) echo "unknown stage $STAGE"; exit 2 ;;
 esac
