@@ -500,6 +500,9 @@ __global__ __launch_bounds__(NT) void gn_bwd_slab_kernel(const half_t* __restric
   }
 }
 
+// option "ln_stream": 1 = (default) statistics-only LayerNorm runs ln_stats_kernel, 0 = the row kernels
+int g_ln_stream = 1;
+
 // option "gn_slab": 1 = the one-launch backward takes every slab of <= 96 KB it can hold (default), 0 = two launches
 int g_gn_slab = 1;
 
@@ -848,6 +851,92 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// LayerNorm STATISTICS ONLY (round 6; the other half of those LayerNorms rides in the consuming GEMM's epilogue,
+// LGD_EPI_ROWNORM), as a stream: L = 8 / 16 / 32 / 64 lanes share a row (C = 320 / 640 / 1280 / 2560: five 16-byte
+// vectors per lane, lane i of the group reads vectors i, i + L, ...: L x 16 contiguous bytes per instruction and
+// group), so a wave-instruction covers 64 / L rows and every lane does useful work (layernorm_rows_kernel: one wave per
+// row = 40 of 64 lanes at C = 320, and two 64-lane butterflies per 640-byte row).  R row sets per wave are loaded
+// before the first reduction; the in-group sums are DPP steps inside a 16-lane row (quad permutes, half-mirror,
+// mirror) plus at most two cross-row shuffles.  Same two-pass arithmetic (mean, then centred squares) as the row kernels.
+// ------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+  return v + __builtin_bit_cast(float, t);
+}
+template <int L>
+__device__ __forceinline__ float lane_group_sum(float v) {
+  v = dpp_add<0xB1>(v);                                  // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);                                  // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);                                 // row_half_mirror: lane i <-> 7 - i of its 8
+  if constexpr (L >= 16) v = dpp_add<0x140>(v);          // row_mirror: lane i <-> 15 - i of its 16
+  if constexpr (L >= 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (L >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+template <int L, int R>
+__global__ __launch_bounds__(256) void ln_stats_kernel(const half_t* __restrict__ x, long ldx, int rows, int C, float eps,
+                                                        float* __restrict__ stats, int rpb, long x_bs) {
+  constexpr int V = 5;                                   // vectors per lane: C <= 8 * 5 * L
+  constexpr int RPW = 64 / L;                            // rows per wave-instruction
+  const int lane = threadIdx.x & 63, li = lane % L, lr = lane / L;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (RPW * R) + lr;
+  const int nvec = C / 8;
+  half8_t h[R][V];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = row0 + r * RPW;
+    const int rc = row < rows ? row : rows - 1;          // a valid address either way; rows past the end are not stored
+    const int bb = rc / rpb, rr = rc - bb * rpb;
+    const half_t* xr = x + bb * x_bs + (long)rr * ldx;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int v = li + j * L;
+      h[r][j] = v < nvec ? *reinterpret_cast<const half8_t*>(xr + v * 8) : (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  const float inv_c = 1.f / C;
+  float mean[R], var[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)h[r][j][e];              // lanes past nvec hold zeros
+    mean[r] = s;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) mean[r] = lane_group_sum<L>(mean[r]) * inv_c;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int j = 0; j < V; ++j) asm volatile("" : "+v"(h[r][j]));      // keep the rows fp16 between the passes (registers)
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+      if (li + j * L < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dlt = (float)h[r][j][e] - mean[r];
+          q += dlt * dlt;
+        }
+      }
+    var[r] = q;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) var[r] = lane_group_sum<L>(var[r]) * inv_c;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = row0 + r * RPW;
+    if (li == 0 && row < rows) *reinterpret_cast<float2*>(stats + (long)row * 2) = make_float2(mean[r], rsqrtf(var[r] + eps));
+  }
+}
+
 // dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat))
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const half_t* __restrict__ gy, long ldgy, const half_t* __restrict__ x, long ldx, half_t* gx,
@@ -915,6 +1004,7 @@ int gn_apply_blocks(int B, int HW, int C) {
 }  // namespace
 
 void lgd_gn_set_fused_hw(int hw) { g_gn_fused_hw = hw; }
+void lgd_ln_set_stream(int on) { g_ln_stream = on; }        // lgd_set_option("ln_stream", 0 | 1) (attn.hip)
 void lgd_gn_set_slab(int on) { g_gn_slab = on; }            // lgd_set_option("gn_slab", 0 | 1) (attn.hip)    // lgd_set_option("gn_fused", hw) (attn.hip)
 
 extern "C" int lgd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, int B, int HW,
@@ -995,12 +1085,25 @@ extern "C" int lgd_layernorm_f16(const void* x, int64_t ldx, void* y, int64_t ld
                                  int rows_per_batch, int64_t x_bs, int64_t y_bs, void* stream) {
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if ((C % 8) || C > 64 * 8 * LN_MAXV || rows < 1) return LGD_ERR_ARG;
-  if (!y && (!stats || C > 192 * 8)) return LGD_ERR_ARG;      // statistics-only form: the row kernels, stats required
+  if (!y && (!stats || C > 192 * 8)) return LGD_ERR_ARG;      // statistics-only form: stats required
   if (rows_per_batch < 1) rows_per_batch = rows;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const half_t* xp = (const half_t*)x;
   half_t* yp = (half_t*)y;
   const int nvec = C / 8;
+  if (!y && g_ln_stream) {
+    // statistics only: the streaming kernel (lane groups per row)
+#define LGD_LN_STATS(L, R)                                                                                         \
+  hipLaunchKernelGGL((ln_stats_kernel<L, R>), dim3((rows + 4 * (64 / L) * R - 1) / (4 * (64 / L) * R)), dim3(256), 0, st, xp, \
+                     (long)ldx, rows, C, eps, stats, rows_per_batch, (long)x_bs)
+    const bool big = (long)rows * C >= (4L << 20);          // enough rows: four row sets per wave in flight
+    if (nvec <= 40) { if (big) LGD_LN_STATS(8, 4); else LGD_LN_STATS(8, 2); }
+    else if (nvec <= 80) { if (big) LGD_LN_STATS(16, 4); else LGD_LN_STATS(16, 2); }
+    else if (nvec <= 160) { if (big) LGD_LN_STATS(32, 4); else LGD_LN_STATS(32, 2); }
+    else { LGD_LN_STATS(64, 2); }
+#undef LGD_LN_STATS
+    return lgd_check_launch();
+  }
 #define LGD_LN_LAUNCH(MAXV, ROWS)                                                                   \
   hipLaunchKernelGGL((layernorm_rows_kernel<MAXV, ROWS>), dim3((rows + 4 * ROWS - 1) / (4 * ROWS)), \
                      dim3(256), 0, st, xp, (long)ldx, yp, (long)ldy, rows, C, eps, gamma, beta,      \

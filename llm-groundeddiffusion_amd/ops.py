@@ -501,7 +501,7 @@ def layernorm_stats(x, C_, eps=1e-5, *, stats=None, rows=None, ldx=None):
         rows = x.numel() // C_
     if stats is None:
         stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
-    _prof("layernorm_rows_kernel (statistics only)", 2.0 * rows * C_,
+    _prof("ln_stats_kernel (LayerNorm statistics only)", 2.0 * rows * C_,
           lambda: _call("lgd_layernorm_f16", _p(x), ldx or C_, _p(None), C_, rows, C_, float(eps), _p(None), _p(None),
                         _p(stats), 0, 0, 0, _stream()), shape=f"R{rows}_C{C_}")
     return stats

@@ -391,6 +391,34 @@ def test_groupnorm_bwd_slab_kernel_vs_torch_and_two_launch(dev, B, HW, C0, C1, s
     assert torch.equal(y2, res[0][0]) and torch.equal(st, res[0][1]) and torch.equal(g2, res[0][2])
 
 
+@pytest.mark.parametrize("rows,C,ldx", [
+    (65536, 320, 320), (16384, 640, 640), (4096, 1280, 1280), (4100, 320, 320), (515, 640, 640), (1027, 1280, 1280),   # 8 / 16 / 32 lanes per row, ragged
+    (3, 320, 320), (1000, 320, 960), (300, 1536, 1536), (77, 64, 64), (130, 2560, 2560),                                # row stride; 64 lanes per row; tiny
+])
+def test_layernorm_statistics_streaming_kernel(dev, rows, C, ldx):
+    """Round 6: the statistics-only LayerNorm as a stream (csrc/norm.hip ln_stats_kernel: 8 .. 64 lanes share a row, DPP
+    sums) against fp32 torch and against the one-wave-per-row kernels it replaces (option "ln_stream" = 0); rows past
+    the end are not written."""
+    x = (rnd(rows, ldx, dev=dev, seed=1) * 1.5 + rnd(rows, 1, dev=dev, seed=7) * 2.0).half()
+    xv = x[:, :C]
+    mu, var = xv.float().mean(1), xv.float().var(1, unbiased=False)
+    got = []
+    try:
+        for stream in (1, 0):
+            if not stream and C > 192 * 8:
+                continue
+            ops.set_option("ln_stream", stream)
+            st = torch.full((rows + 8, 2), -7.0, device=dev)
+            ops.layernorm_stats(x, C, stats=st, rows=rows, ldx=ldx)
+            assert relerr(st[:rows, 0], mu) < 1e-5 and relerr(st[:rows, 1], (var + 1e-5).rsqrt()) < 1e-5, stream
+            assert bool((st[rows:] == -7.0).all())
+            got.append(st[:rows].clone())
+    finally:
+        ops.set_option("ln_stream", 1)
+    if len(got) == 2:
+        assert relerr(got[0], got[1]) < 2e-6
+
+
 @pytest.mark.parametrize("rows,C", [(8192, 320), (2048, 640), (513, 1280), (30, 64)])
 def test_layernorm_fwd_bwd(dev, rows, C):
     x = (rnd(rows, C, dev=dev, seed=1) * 1.5 + 0.3).half()

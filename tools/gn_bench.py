@@ -1,5 +1,5 @@
-"""A/B timing of GroupNorm forward / backward: the one-launch slab kernels (option gn_slab = 1) against the two-launch
-kernels (gn_slab = 0) on the benchmark's shapes.  python tools/gn_bench.py"""
+"""A/B timing of GroupNorm forward / backward (one-launch slab kernels, option gn_slab = 1, against the two-launch kernels)
+and of the statistics-only LayerNorm (streaming kernel, option ln_stream = 1, against the row kernels) on the benchmark's shapes.  python tools/gn_bench.py"""
 import os
 import sys
 
@@ -57,3 +57,12 @@ def run(kind, shapes):
 
 run("fwd", FWD)
 run("bwd", BWD)
+for rows, C in [(65536, 320), (32768, 320), (16384, 640), (8192, 640), (4096, 1280), (2048, 1280), (1024, 1280), (16384, 320)]:
+    x = torch.randn(rows, C, device=dev).half()
+    st = torch.empty(rows, 2, device=dev)
+    res = {}
+    for stream in (0, 1):
+        ops.set_option("ln_stream", stream)
+        res[stream] = timeit(lambda: ops.layernorm_stats(x, C, stats=st))
+    ops.set_option("ln_stream", 1)
+    print(f"ln stats R{rows:6d} C{C:5d}: rows kernel {res[0]:6.1f} us  stream {res[1]:6.1f} us  x{res[0] / res[1]:.2f}  {2.0 * rows * C / res[1] * 1e-6:.2f} TB/s")
