@@ -37,8 +37,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ROCPROF_SUMMARY = ("profiles/r05_bench_lanes1_kernel_stats.csv (one launch sequence alone: its per-launch averages are the "
-                   "ones comparable with avg_launch_us); profiles/r05_bench_driver_kernel_stats.csv (the default command: "
+ROCPROF_SUMMARY = ("profiles/r06_bench_lanes1_kernel_stats.csv (one launch sequence alone: its per-launch averages are the "
+                   "ones comparable with avg_launch_us); profiles/r06_bench_driver_kernel_stats.csv (the default command: "
                    "durations of kernels of different lanes overlap each other)")
 MFMA_PEAK_F16 = 2.5e15       # dense fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
@@ -692,7 +692,7 @@ def main():
             ops.PROFILER = None
             w = n_runs / reps / my_images                                 # per image of this rank
             for dst, summ in ((agg, prof.summary()), (tag_agg, prof.summary(by_tag=True)),
-                              (shape_agg, prof.summary(by_shape=True) if args.shape_profile else {})):
+                              (shape_agg, prof.summary(by_shape=True))):
                 for k, v in summ.items():
                     a = dst.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, n=0.0, raw_ms=0.0, raw_n=0))
                     a["ms"] += v["ms"] * w
@@ -716,8 +716,8 @@ def main():
             # HBM bytes per launch come from a committed PMC summary of THIS command's short form (PMC passes serialise
             # every dispatch: they cannot run inside the timed region) — the source file is named in the record
             traffic, traffic_note, traffic_source = None, "no PMC summary for this kernel under profiles/", None
-            for fname in ("r05_bench_traffic_pmc.json", "r04_bench_traffic_pmc.json", "r03_bench_traffic_pmc.json",
-                          "r02_bench_traffic_pmc.json"):
+            for fname in ("r06_bench_traffic_pmc.json", "r05_bench_traffic_pmc.json", "r04_bench_traffic_pmc.json",
+                          "r03_bench_traffic_pmc.json", "r02_bench_traffic_pmc.json"):
                 tpath = os.path.join(ROOT, "profiles", fname)
                 if not os.path.exists(tpath):
                     continue
@@ -726,6 +726,26 @@ def main():
                 if ent:
                     traffic, traffic_note, traffic_source = ent["hbm_bytes_per_launch"], tj.get("method", ""), f"profiles/{fname}"
                     break
+            # the dominant kernel's heaviest SHAPE, with the HBM bytes one launch of exactly that shape moved (PMC passes on
+            # that shape alone: tools/gpu_session.sh evidence -> profiles/r06_gemm_pmc_summary.json) against its algorithmic
+            # bytes — the family average above mixes shapes and cannot be set against anything
+            dominant_shape = None
+            cand = [(k, v) for k, v in shape_agg.items() if k.split(" | ")[0] == name and " | " in k]
+            if cand:
+                import re
+                sk, sv = max(cand, key=lambda kv: kv[1]["ms"])
+                dominant_shape = dict(shape=sk.split(" | ")[1], ms_per_image=round(sv["ms"], 2), launches_per_image=round(sv["n"], 1),
+                                      avg_launch_us=round(sv["raw_ms"] * 1e3 / max(sv["raw_n"], 1), 1),
+                                      tflops=round(sv["flops"] / max(sv["ms"] * 1e-3, 1e-12) / 1e12, 1))
+                m = re.match(r"M(\d+)_N(\d+)_K(\d+)_t(\d+)_.*_e(\d+)_", dominant_shape["shape"])
+                ppath = os.path.join(ROOT, "profiles", "r06_gemm_pmc_summary.json")
+                if m and os.path.exists(ppath):
+                    key = "M%s_N%s_K%s_t%s" % m.groups()[:4] + ("_geglu" if int(m.group(5)) & 1 else "")
+                    ent = json.load(open(ppath)).get("shapes", {}).get(key)
+                    if ent and "traffic" in ent:
+                        dominant_shape.update(traffic=ent["traffic"], algorithmic_bytes=ent["algorithmic_bytes"],
+                                              traffic_ratio=ent["traffic_ratio"], mfma_busy_share=ent.get("mfma_busy_share"),
+                                              traffic_source="profiles/r06_gemm_pmc_summary.json")
             gem = [v for k, v in agg.items() if k.startswith("gemm")]
             gemm_tf = sum(v["flops"] for v in gem) / max(sum(v["ms"] for v in gem) * 1e-3, 1e-12) / 1e12 if gem else None
             ap_ = tag_agg.get("attn_path")
@@ -735,7 +755,7 @@ def main():
                             # avg_launch_us x launches_per_image = est_ms_per_image
                             avg_launch_us=round(a["ms"] * 1e3 / a["n"], 2),
                             launches_per_image=round(a["n"], 1), est_ms_per_image=round(a["ms"], 1),
-                            traffic_note=traffic_note, traffic_source=traffic_source,
+                            traffic_note=traffic_note, traffic_source=traffic_source, dominant_shape=dominant_shape,
                             rocprof_summary=ROCPROF_SUMMARY,
                             method="HIP events around each launch, eager replay of the benchmark's plans right after "
                                    "the timed region, ONE launch sequence alone on the GPU (the timed region itself "

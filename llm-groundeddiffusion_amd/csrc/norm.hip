@@ -1085,22 +1085,23 @@ extern "C" int lgd_layernorm_f16(const void* x, int64_t ldx, void* y, int64_t ld
                                  int rows_per_batch, int64_t x_bs, int64_t y_bs, void* stream) {
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
   if ((C % 8) || C > 64 * 8 * LN_MAXV || rows < 1) return LGD_ERR_ARG;
-  if (!y && (!stats || C > 192 * 8)) return LGD_ERR_ARG;      // statistics-only form: stats required
+  if (!y && (!stats || C > (g_ln_stream ? 64 * 5 * 8 : 192 * 8))) return LGD_ERR_ARG;      // statistics-only form: stats required
   if (rows_per_batch < 1) rows_per_batch = rows;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const half_t* xp = (const half_t*)x;
   half_t* yp = (half_t*)y;
   const int nvec = C / 8;
-  if (!y && g_ln_stream) {
-    // statistics only: the streaming kernel (lane groups per row)
+  // statistics only: the streaming kernel (lane groups per row) once the map is large enough to keep every CU streaming
+  // (measured, 40 launches in one graph: 65536 x 320 16.4 -> 10.0 us, 32768 x 320 8.7 -> 4.9, 16384 x 640 7.1 -> 5.0;
+  // below ~8 M elements the one-wave-per-row kernels with their 4x more workgroups win: 4096 x 1280 3.7 vs 4.8 us)
+  if (!y && g_ln_stream && ((long)rows * C >= (8L << 20) || nvec > 192)) {
 #define LGD_LN_STATS(L, R)                                                                                         \
   hipLaunchKernelGGL((ln_stats_kernel<L, R>), dim3((rows + 4 * (64 / L) * R - 1) / (4 * (64 / L) * R)), dim3(256), 0, st, xp, \
                      (long)ldx, rows, C, eps, stats, rows_per_batch, (long)x_bs)
-    const bool big = (long)rows * C >= (4L << 20);          // enough rows: four row sets per wave in flight
-    if (nvec <= 40) { if (big) LGD_LN_STATS(8, 4); else LGD_LN_STATS(8, 2); }
-    else if (nvec <= 80) { if (big) LGD_LN_STATS(16, 4); else LGD_LN_STATS(16, 2); }
-    else if (nvec <= 160) { if (big) LGD_LN_STATS(32, 4); else LGD_LN_STATS(32, 2); }
-    else { LGD_LN_STATS(64, 2); }
+    if (nvec <= 40) LGD_LN_STATS(8, 4);
+    else if (nvec <= 80) LGD_LN_STATS(16, 4);
+    else if (nvec <= 160) LGD_LN_STATS(32, 4);
+    else LGD_LN_STATS(64, 2);
 #undef LGD_LN_STATS
     return lgd_check_launch();
   }

@@ -392,8 +392,9 @@ def test_groupnorm_bwd_slab_kernel_vs_torch_and_two_launch(dev, B, HW, C0, C1, s
 
 
 @pytest.mark.parametrize("rows,C,ldx", [
-    (65536, 320, 320), (16384, 640, 640), (4096, 1280, 1280), (4100, 320, 320), (515, 640, 640), (1027, 1280, 1280),   # 8 / 16 / 32 lanes per row, ragged
-    (3, 320, 320), (1000, 320, 960), (300, 1536, 1536), (77, 64, 64), (130, 2560, 2560),                                # row stride; 64 lanes per row; tiny
+    (65536, 320, 320), (16384, 640, 640), (8200, 1280, 1280), (32771, 320, 320), (13001, 640, 640),    # 8 / 16 / 32 lanes per row, ragged
+    (30000, 320, 960), (130, 2560, 2560), (7, 2560, 2560),                                               # row stride; 64 lanes per row
+    (4096, 1280, 1280), (515, 640, 640), (300, 1536, 1536), (77, 64, 64),                                # small maps stay on the row kernels
 ])
 def test_layernorm_statistics_streaming_kernel(dev, rows, C, ldx):
     """Round 6: the statistics-only LayerNorm as a stream (csrc/norm.hip ln_stats_kernel: 8 .. 64 lanes share a row, DPP

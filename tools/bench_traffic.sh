@@ -20,6 +20,8 @@ def norm(k):
     k = k.replace(" ", "")
     m = re.match(r"(gemm_pipe_kernel)<(\d+),(\d+),(\d+),(\d+),(\d+),", k)
     if m: return "%s<%s,%s,%s,%s,%s>" % m.groups()
+    m = re.match(r"(gemm_phase_kernel)<(\d+),(\d+),", k)
+    if m: return "%s<%s,%s>" % m.groups()
     m = re.match(r"(gemm_dma_kernel)<(\d+),(\d+),(\d+)>", k)
     if m: return "%s<%s,%s,%s>" % m.groups()
     return k

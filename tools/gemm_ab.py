@@ -33,6 +33,8 @@ ALL = {  # (M, N, K, taps, cin, h, geglu)
 }
 which = os.environ.get("SHAPES", "conv")
 SHAPES = sum(ALL.values(), []) if which == "all" else sum((ALL[w] for w in which.split(",")), [])
+if os.environ.get("SHAPE"):          # one explicit shape: SHAPE=M,N,K,taps,cin,h,geglu
+    SHAPES = [tuple(int(x) for x in os.environ["SHAPE"].split(","))]
 # TILES: comma list of tile codes, each optionally "tile:splits" (tile 0 = the tuning table's choice)
 splits = int(os.environ.get("SPLITS", "1"))
 if os.environ.get("FIRST"):

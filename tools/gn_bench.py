@@ -16,17 +16,29 @@ BWD = [(4, 64, 1280, 0), (4, 256, 1280, 0), (4, 4096, 320, 0), (4, 1024, 640, 0)
        (4, 1024, 320, 0), (4, 256, 640, 0)]
 
 
-def timeit(fn, n=50):
-    for _ in range(5):
+def timeit(fn, n=40):
+    """Average device time of fn: n calls captured into ONE hipGraph and replayed (eager launches through ctypes are
+    host-bound below ~11 us per call and cannot resolve the small kernels)."""
+    fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
         fn()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(n):
+                fn()
+    for _ in range(3):
+        g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n):
-        fn()
+    for _ in range(5):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / n
+    return e0.elapsed_time(e1) * 1e3 / (5 * n)
 
 
 def run(kind, shapes):

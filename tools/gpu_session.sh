@@ -140,5 +140,33 @@ PY
     done
     cat $OUT/abl.log
     python llm-groundeddiffusion_amd/build.py --force > /dev/null 2>&1 ;;
+  evidence)   # args: TAG; rocprofv3 kernel-trace stats of the bench lines DESIGN.md quotes, the HBM-traffic PMC passes of the default
+              # command, and SQ / TCC / HBM counters of the phase-split GEMM tiles on the benchmark's heaviest shapes (one shape per pass)
+    T=${1:-r06}
+    cd /tmp && export TMPDIR=/tmp
+    prof() { tag=$1; shift
+      timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$tag -- python $R/bench.py "$@" > $OUT/$tag.log 2>&1
+      grep '^{' $OUT/$tag.log | tail -1 > $OUT/${tag}_bench_line.json
+      f=$(find $OUT/$tag -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/${tag}_kernel_stats.csv
+      rm -rf $OUT/$tag; cut -c1-160 $OUT/${tag}_bench_line.json; }
+    prof ${T}_bench_lanes1 --lanes 1 --steps 1 --warmup 1 --no-cpu-baseline
+    prof ${T}_bench_driver --steps 4 --warmup 1 --no-cpu-baseline --no-roofline
+    TAG=evidence/traffic bash $R/tools/bench_traffic.sh > $OUT/traffic.log 2>&1
+    cp $OUT/traffic/bench_traffic_pmc.json $OUT/${T}_bench_traffic_pmc.json 2>/dev/null
+    rm -rf $OUT/traffic/FETCH_SIZE $OUT/traffic/WRITE_SIZE
+    i=0; dirs=""
+    for spec in "47:65536,320,2880,9,320,64,0" "46:65536,2560,320,1,320,0,1" "46:16384,5120,640,1,640,0,1" "46:4096,10240,1280,1,1280,0,1" "47:65536,320,320,1,320,0,0" "46:8192,8192,4096,1,4096,0,0"; do
+      tile=${spec%%:*}; shp=${spec#*:}; d=$OUT/shape$i; mkdir -p $d; echo $shp > $d/shape.txt; echo $tile > $d/tile.txt
+      run() { n=$1; shift; SHAPE=$shp TILES=$tile ROUNDS=1 REPS=3 timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $d/$n -- python $R/tools/gemm_ab.py > $d/$n.log 2>&1; }
+      run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS
+      run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE
+      run tcc1 TCC_HIT_sum TCC_MISS_sum
+      run tcc2 FETCH_SIZE
+      run tcc3 WRITE_SIZE
+      dirs="$dirs $d"; i=$((i+1))
+    done
+    python $R/tools/pmc_shapes.py $OUT/${T}_gemm_pmc_summary.json $dirs
+    find $OUT -name '*.csv' -path '*shape*' -delete 2>/dev/null
+    ls $OUT ;;
   *) echo "unknown stage $STAGE"; exit 2 ;;
 esac
