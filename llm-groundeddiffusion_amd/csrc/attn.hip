@@ -1085,12 +1085,14 @@ bool bad_view(int64_t ld, int d) { return (ld % 8) != 0 || (d % 8) != 0; }
 void lgd_gn_set_fused_hw(int hw);                          // norm.hip
 void lgd_gn_set_slab(int on);                              // norm.hip
 void lgd_ln_set_stream(int on);                            // norm.hip
+void lgd_gn_set_apply_wgs(int n);                          // norm.hip
 
 extern "C" int lgd_set_option(const char* name, int value) {
   if (!name) return LGD_ERR_ARG;
   if (!strcmp(name, "gn_fused") && value >= 0 && value <= 4096) { lgd_gn_set_fused_hw(value); return LGD_OK; }
   if (!strcmp(name, "gn_slab") && (value == 0 || value == 1)) { lgd_gn_set_slab(value); return LGD_OK; }
   if (!strcmp(name, "ln_stream") && (value == 0 || value == 1)) { lgd_ln_set_stream(value); return LGD_OK; }
+  if (!strcmp(name, "gn_apply_wgs") && value >= 64 && value <= 8192) { lgd_gn_set_apply_wgs(value); return LGD_OK; }
   if (!strcmp(name, "attn32")) { g_attn32 = value; return LGD_OK; }
   if (!strcmp(name, "attn_w4") && value >= 0 && value <= 2) { g_attn_w4.store(value, std::memory_order_relaxed); return LGD_OK; }
   if (!strcmp(name, "attn_w4_pipe") && (value == 0 || value == 1)) { lgd_attn_w4_set_pipe(value); return LGD_OK; }

@@ -991,11 +991,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
 
 // Workgroups per image of the apply passes: about 1024 workgroups in total, at least one full
 // GN_UNROLL trip of pixels per thread.
+int g_gn_apply_wgs = 1024;        // option "gn_apply_wgs" (tools): workgroups per launch the apply passes aim at
 int gn_apply_blocks(int B, int HW, int C) {
   const int nvec = C / 8;
   const int pl = nvec < 256 ? 256 / nvec : 1;
   int px = GN_UNROLL * pl;
-  const int want = (int)(((long)HW * B + 1023) / 1024);
+  const int want = (int)(((long)HW * B + g_gn_apply_wgs - 1) / g_gn_apply_wgs);
   if (px < want) px = want;
   int n = (HW + px - 1) / px;
   return n < 1 ? 1 : n;
@@ -1005,7 +1006,8 @@ int gn_apply_blocks(int B, int HW, int C) {
 
 void lgd_gn_set_fused_hw(int hw) { g_gn_fused_hw = hw; }
 void lgd_ln_set_stream(int on) { g_ln_stream = on; }        // lgd_set_option("ln_stream", 0 | 1) (attn.hip)
-void lgd_gn_set_slab(int on) { g_gn_slab = on; }            // lgd_set_option("gn_slab", 0 | 1) (attn.hip)    // lgd_set_option("gn_fused", hw) (attn.hip)
+void lgd_gn_set_slab(int on) { g_gn_slab = on; }
+void lgd_gn_set_apply_wgs(int n) { g_gn_apply_wgs = n; }            // lgd_set_option("gn_slab", 0 | 1) (attn.hip)    // lgd_set_option("gn_fused", hw) (attn.hip)
 
 extern "C" int lgd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, int B, int HW,
                                  int G, float eps, const float* gamma, const float* beta, int silu,

@@ -441,10 +441,13 @@ def conv_out(x, w, bias, B, L, out=None, out_scale=1.0):
 # ---------------------------------------------------------------------------------------------
 # norms
 # ---------------------------------------------------------------------------------------------
+GN_STATS_WGS = int(_os.environ.get("LGD_GN_STATS_WGS", "1024"))      # workgroups per launch the statistics pass aims at
+
+
 def gn_chunks(B, HW):
     """Pixel chunks per image of the GroupNorm statistics pass (>= 8 pixels each, at most 64 so that the
     partial table [B, nchunk, G, 2] every apply workgroup re-reduces stays at 16 KB per image)."""
-    return max(1, min(HW // 8, 1024 // max(B, 1), 64))
+    return max(1, min(HW // 8, GN_STATS_WGS // max(B, 1), 64))
 
 
 def groupnorm(x, B, HW, G, eps, gamma, beta, silu, *, x1=None, out=None, part=None, stats=None):
