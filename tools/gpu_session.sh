@@ -168,5 +168,29 @@ PY
     python $R/tools/pmc_shapes.py $OUT/${T}_gemm_pmc_summary.json $dirs
     find $OUT -name '*.csv' -path '*shape*' -delete 2>/dev/null
     ls $OUT ;;
+  pmc_shapes) # args: OUT.json SPEC... (SPEC = tile:M,N,K,taps,cin,h,geglu): the per-shape PMC passes of the evidence stage on
+              # further shapes, merged into an existing summary (profiles/r06_gemm_pmc_summary.json)
+    J=$1; shift
+    cd /tmp && export TMPDIR=/tmp
+    i=0; dirs=""
+    for spec in "$@"; do
+      tile=${spec%%:*}; shp=${spec#*:}; d=$OUT/shape$i; mkdir -p $d; echo $shp > $d/shape.txt; echo $tile > $d/tile.txt
+      run() { n=$1; shift; SHAPE=$shp TILES=$tile ROUNDS=1 REPS=3 timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $d/$n -- python $R/tools/gemm_ab.py > $d/$n.log 2>&1; }
+      run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS
+      run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE
+      run tcc1 TCC_HIT_sum TCC_MISS_sum
+      run tcc2 FETCH_SIZE
+      run tcc3 WRITE_SIZE
+      dirs="$dirs $d"; i=$((i+1))
+    done
+    python $R/tools/pmc_shapes.py $OUT/new.json $dirs
+    python - <<PY
+import json
+old = json.load(open("$R/$J")); new = json.load(open("$OUT/new.json"))
+old["shapes"].update(new["shapes"])
+json.dump(old, open("$OUT/merged.json", "w"), indent=1)
+print("merged:", list(old["shapes"]))
+PY
+    find $OUT -name '*.csv' -delete 2>/dev/null ;;
   *) echo "unknown stage $STAGE"; exit 2 ;;
 esac
