@@ -38,7 +38,8 @@ int lgd_abi_version(void);
  * the two-launch form.  "gn_slab": 1 = (default) lgd_groupnorm_bwd_f16 runs in one launch where a workgroup can hold its
  * (image, groups) slab of x and gy in registers (<= 96 KB: the 8x8 and 16x16 maps), 0 = two launches.  "ln_stream": 1 =
  * (default) the statistics-only form of lgd_layernorm_f16 (y = NULL) runs the streaming kernel (lane groups share a row),
- * 0 = the one-wave-per-row kernels.  Returns 0, or LGD_ERR_ARG for an unknown name. */
+ * 0 = the one-wave-per-row kernels.  "gn_apply_wgs" (tools): the number of workgroups per launch the GroupNorm apply passes
+ * aim at, 64 .. 8192, default 1024.  Returns 0, or LGD_ERR_ARG for an unknown name. */
 int lgd_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------------------------------------
