@@ -1046,6 +1046,21 @@ void launch_attn_dp(const AttnArgs& a, hipStream_t st) {
         return;
       }
     }
+    if constexpr (DP == 160) {
+      // round 6: the 16x16 level (S = 256, d = 160): ONE workgroup per (image, head) — eight waves x two query tiles = all
+      // 256 queries share each staged K / V^T tile, which the 64-query workgroups stage four times over.  A workgroup of
+      // either form is a chain of four or five load -> stage -> barrier round trips of ~4.5 us (not MFMA work), so the wide
+      // form wins only where the narrow one needs two rounds of workgroups: measured (tools/attn160_ab.py, 40 launches in
+      // one graph) B = 16: 33.6 -> 23.8 us (160 -> 226 TF/s), with the fuser's 286 keys 38.0 -> 26.8; B = 8: 18.4 -> 21.8,
+      // B = 4: 14.5 -> 20.7 — hence the (image, head) count in the condition.  LGD_ATTN160=0: old form.  Same per-row
+      // arithmetic and key order: bit-identical outputs.
+      static const int wide = [] { const char* e = getenv("LGD_ATTN160"); return e ? atoi(e) : 1; }();
+      if (wide && a.d == DP && a.Sq >= 256 && (long)a.H * a.B * ((a.Sq + 63) / 64) > 256) {
+        dim3 g8((a.Sq + 255) / 256, a.H, a.B);
+        hipLaunchKernelGGL((attn_self_kernel<DP, false, 2, DP / 16, 8>), g8, dim3(512), 0, st, a);
+        return;
+      }
+    }
     if (DP == 64 && a.d < 48) hipLaunchKernelGGL((attn_self_kernel<DP, true, 1, DP == 64 ? 3 : DP / 16>), grid, dim3(256), 0, st, a);
     else if (a.d < DP) hipLaunchKernelGGL((attn_self_kernel<DP, true, 1>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_self_kernel<DP, false, 1>), grid, dim3(256), 0, st, a);

@@ -444,6 +444,7 @@ def _attn_ref(q, k, v, scale):
 @pytest.mark.parametrize("B,H,Sq,Sk,d", [
     (2, 8, 4096, 4096, 40), (2, 8, 1024, 1054, 80), (1, 8, 256, 286, 160), (2, 8, 64, 64, 160),
     (1, 5, 576, 576, 64), (2, 8, 100, 77, 8), (1, 8, 256, 256, 16), (1, 8, 64, 94, 32),
+    (9, 8, 256, 286, 160), (5, 8, 300, 256, 160),        # round 6: > 256 (image, head, 64-query) blocks -> one 256-query workgroup per (image, head)
 ])
 def test_attn_fwd_bwd(dev, B, H, Sq, Sk, d):
     C = H * d
