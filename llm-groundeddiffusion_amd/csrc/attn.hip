@@ -1002,13 +1002,17 @@ void launch_attn_dp(const AttnArgs& a, hipStream_t st) {
       // measured (tools/attn_quick.py, B = 16): d = 80 (DK = 96) 97 -> 80 us; d = 40 (DK = 48) 570 -> 630 us — at two
       // waves per SIMD (170 VGPRs) its stalls are not covered the way the 16x16x32 kernel's four waves cover theirs —
       // so by default only the DK = 96 heads take this kernel
-      if (a32 && a.d % 8 == 0 && (a32 == 2 || (dk == 96 && (long)((a.Sq + 255) / 256) * a.H * a.B >= 512))) {
+      // round 6: the threshold was 512 blocks of 256 queries ("fill the chip twice"); measured (tools/attn80_ab.py) the
+      // 8-image calls (256 blocks) run 70.3 -> 42.0 us on this kernel (305 -> 512 TF/s; with the fuser's 1054 keys 73.7 ->
+      // 45.9) and the 4-image calls (128 blocks) 34.7 -> 33.2 us with 128-query workgroups
+      const long blocks256 = (long)((a.Sq + 255) / 256) * a.H * a.B;
+      if (a32 && a.d % 8 == 0 && (a32 == 2 || (dk == 96 && blocks256 >= 128))) {
         const int var = attn32_var();
         auto go = [&](auto kern, int nw) {
           dim3 g32((a.Sq + 32 * nw - 1) / (32 * nw), a.H, a.B);
           hipLaunchKernelGGL(kern, g32, dim3(64 * nw), 0, st, a);
         };
-        if (attn32_nw() == 4) {
+        if (attn32_nw() == 4 || (a32 != 2 && blocks256 < 256)) {
           if (dk == 48) { go(&attn_self32_kernel<48, 2, 4>, 4); return; }
           if (dk == 96) { go(&attn_self32_kernel<96, 3, 4>, 4); return; }
         } else if (var == 1) {
