@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LGD_ABI_VERSION 9
+#define LGD_ABI_VERSION 10
 int lgd_abi_version(void);
 /* Kernel-variant switches of the library (A/B timing and tests; the defaults are what the benchmark runs).  No
  * counterpart in the reference.  "attn32": self-attention forward without map capture — 0 = the 16x16x32 kernel,
@@ -172,6 +172,18 @@ int lgd_attn_bwd_f16(const void* q, int64_t ldq, int64_t q_bs, const void* k, in
                      const float* lse, float* delta, void* gq, int64_t ldgq, int64_t gq_bs, void* gk,
                      int64_t ldgk, int64_t gk_bs, void* gv, int64_t ldgv, int64_t gv_bs, int B, int H,
                      int Sq, int Sk, int d, float scale, void* stream);
+/* The same with dK / dV computed for the first Sk_grad <= Sk keys only (ABI v10); dQ still sums over all Sk keys.
+ * GLIGEN's gated self-attention (attention.py:43-53) attends over [visual tokens ; 30 grounding tokens] and keeps the
+ * visual rows; the grounding rows of the concatenated input are constants of a run, so nothing reads the gradient of
+ * their keys / values, and the key block that holds them would cost the dK/dV pass a whole extra round of workgroups
+ * (4096 + 30 keys = 17 blocks of 256 per (image, head) on a grid that 16 fill exactly).  Rows >= Sk_grad of gk / gv are
+ * not written. */
+int lgd_attn_bwd_keys_f16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk,
+                          int64_t k_bs, const void* v, int64_t ldv, int64_t v_bs, const void* o,
+                          int64_t ldo, int64_t o_bs, const void* go, int64_t ldgo, int64_t go_bs,
+                          const float* lse, float* delta, void* gq, int64_t ldgq, int64_t gq_bs, void* gk,
+                          int64_t ldgk, int64_t gk_bs, void* gv, int64_t ldgv, int64_t gv_bs, int B, int H,
+                          int Sq, int Sk, int Sk_grad, int d, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Cross-attention over the 77 text tokens with probability-map capture — the hook of

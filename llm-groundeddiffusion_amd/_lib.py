@@ -14,7 +14,7 @@ import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgd_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -60,6 +60,8 @@ SIGNATURES = {
     "lgd_attn_fwd_f16": [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _I, _I, _F, _P],
     "lgd_attn_bwd_f16": [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _P,
                          _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _P],
+    "lgd_attn_bwd_keys_f16": [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _P,
+                              _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _F, _P],
     "lgd_cross_attn_fwd_f16": [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I,
                                _I, _I, _I, _I, _I, _F, _P],
     "lgd_cross_attn_bwd_f16": [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _P, _L, _L,

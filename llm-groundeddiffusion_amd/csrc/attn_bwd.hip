@@ -87,6 +87,7 @@ struct AttnBwdArgs {
   half_t* gk; long ldgk, gk_bs;
   half_t* gv; long ldgv, gv_bs;
   int B, H, Sq, Sk, d;
+  int sk_grad;          // dK / dV are wanted for the first sk_grad keys only (<= Sk; dQ always sums over all Sk keys)
   float scale, scale_log2;
 };
 
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const AttnBwdArgs
 #pragma unroll
   for (int k2 = 0; k2 < KT; ++k2) {
     const int krow = k0 + k2 * 16 + c16;
-    if (krow < a.Sk) {
+    if (krow < a.sk_grad) {
       half_t* outk = a.gk + (long)b * a.gk_bs + (long)krow * a.ldgk + (long)h * d;
       half_t* outv = a.gv + (long)b * a.gv_bs + (long)krow * a.ldgv + (long)h * d;
 #pragma unroll
@@ -743,7 +744,7 @@ int launch_bwd_nt(const AttnBwdArgs& a, hipStream_t st) {
   (void)attr_set;
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, NQ, NDT, NW, DB>), dim3((a.Sq + 16 * NW * NQ - 1) / (16 * NW * NQ), a.H, a.B),
                      dim3(64 * NW), smem_dq, st, a);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, NK, NDT, NW, DB>), dim3((a.Sk + 16 * NW * NK - 1) / (16 * NW * NK), a.H, a.B),
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, NK, NDT, NW, DB>), dim3((a.sk_grad + 16 * NW * NK - 1) / (16 * NW * NK), a.H, a.B),
                      dim3(64 * NW), smem_dkv, st, a);
   return lgd_check_launch();
 }
@@ -783,6 +784,14 @@ int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int lgd_attn_bwd_keys_f16(const void* q, int64_t ldq, int64_t q_bs, const void* k,
+                                     int64_t ldk, int64_t k_bs, const void* v, int64_t ldv, int64_t v_bs,
+                                     const void* o, int64_t ldo, int64_t o_bs, const void* go,
+                                     int64_t ldgo, int64_t go_bs, const float* lse, float* delta, void* gq,
+                                     int64_t ldgq, int64_t gq_bs, void* gk, int64_t ldgk, int64_t gk_bs,
+                                     void* gv, int64_t ldgv, int64_t gv_bs, int B, int H, int Sq, int Sk,
+                                     int Sk_grad, int d, float scale, void* stream);
+
 extern "C" int lgd_attn_bwd_f16(const void* q, int64_t ldq, int64_t q_bs, const void* k,
                                 int64_t ldk, int64_t k_bs, const void* v, int64_t ldv, int64_t v_bs,
                                 const void* o, int64_t ldo, int64_t o_bs, const void* go,
@@ -790,8 +799,19 @@ extern "C" int lgd_attn_bwd_f16(const void* q, int64_t ldq, int64_t q_bs, const 
                                 int64_t ldgq, int64_t gq_bs, void* gk, int64_t ldgk, int64_t gk_bs,
                                 void* gv, int64_t ldgv, int64_t gv_bs, int B, int H, int Sq, int Sk,
                                 int d, float scale, void* stream) {
+  return lgd_attn_bwd_keys_f16(q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, o, ldo, o_bs, go, ldgo, go_bs, lse, delta, gq, ldgq,
+                               gq_bs, gk, ldgk, gk_bs, gv, ldgv, gv_bs, B, H, Sq, Sk, Sk, d, scale, stream);
+}
+
+extern "C" int lgd_attn_bwd_keys_f16(const void* q, int64_t ldq, int64_t q_bs, const void* k,
+                                     int64_t ldk, int64_t k_bs, const void* v, int64_t ldv, int64_t v_bs,
+                                     const void* o, int64_t ldo, int64_t o_bs, const void* go,
+                                     int64_t ldgo, int64_t go_bs, const float* lse, float* delta, void* gq,
+                                     int64_t ldgq, int64_t gq_bs, void* gk, int64_t ldgk, int64_t gk_bs,
+                                     void* gv, int64_t ldgv, int64_t gv_bs, int B, int H, int Sq, int Sk,
+                                     int Sk_grad, int d, float scale, void* stream) {
   (void)hipGetLastError();  // drop stale errors of unrelated earlier runtime calls
-  if (B < 1 || H < 1 || Sq < 1 || Sk < 1 || d < 8 || (d % 8)) return LGD_ERR_ARG;
+  if (B < 1 || H < 1 || Sq < 1 || Sk < 1 || Sk_grad < 1 || Sk_grad > Sk || d < 8 || (d % 8)) return LGD_ERR_ARG;
   if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 8) || (ldgo % 8) || (ldgq % 4) || (ldgk % 4) ||
       (ldgv % 4) || !lse || !delta)
     return LGD_ERR_ARG;
@@ -806,6 +826,7 @@ extern "C" int lgd_attn_bwd_f16(const void* q, int64_t ldq, int64_t q_bs, const 
   a.gk = (half_t*)gk; a.ldgk = ldgk; a.gk_bs = gk_bs;
   a.gv = (half_t*)gv; a.ldgv = ldgv; a.gv_bs = gv_bs;
   a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.d = d;
+  a.sk_grad = Sk_grad;
   a.scale = scale;
   a.scale_log2 = scale * 1.4426950408889634f;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

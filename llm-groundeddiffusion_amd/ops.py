@@ -545,7 +545,9 @@ def attn_fwd(q, k, v, o, B, H, Sq, Sk, d, scale, *, lse=None, q_view=None, k_vie
 
 def attn_bwd(q, k, v, o, go, lse, delta, gq, gk, gv, B, H, Sq, Sk, d, scale, *, q_view=None,
              k_view=None, v_view=None, o_view=None, go_view=None, gq_view=None, gk_view=None,
-             gv_view=None):
+             gv_view=None, sk_grad=None):
+    """sk_grad: dK / dV are computed (and written) for the first sk_grad keys only (lgd_attn_bwd_keys_f16); default all."""
+    skg = Sk if sk_grad is None else int(sk_grad)
     dq_ = (H * d, Sq * H * d)
     dk_ = (H * d, Sk * H * d)
     qv, kv, vv = q_view or dq_, k_view or dk_, v_view or dk_
@@ -554,10 +556,11 @@ def attn_bwd(q, k, v, o, go, lse, delta, gq, gk, gv, B, H, Sq, Sk, d, scale, *, 
     # flash backward with recompute: QK^T twice (dQ and dK/dV passes), dP = dO V^T twice, dV, dK, dQ -> 14 B H Sq Sk d
     # executed; the ALGORITHMIC work of an attention backward is 5 contractions = 10 B H Sq Sk d (DESIGN.md kernel table)
     _prof(f"attn_bwd_dq + attn_bwd_dkv d={d}", 2.0 * B * H * d * (4 * Sq + 4 * Sk),
-          lambda: _call("lgd_attn_bwd_f16", _p(q), qv[0], qv[1], _p(k), kv[0], kv[1], _p(v), vv[0], vv[1], _p(o),
+          lambda: _call("lgd_attn_bwd_keys_f16", _p(q), qv[0], qv[1], _p(k), kv[0], kv[1], _p(v), vv[0], vv[1], _p(o),
                         ov[0], ov[1], _p(go), gov[0], gov[1], _p(lse), _p(delta), _p(gq), gqv[0], gqv[1], _p(gk),
-                        gkv[0], gkv[1], _p(gv), gvv[0], gvv[1], B, H, Sq, Sk, d, float(scale), _stream()),
-          flops=10.0 * B * H * Sq * Sk * d, tag="attn_path_bwd", shape=f"B{B}_H{H}_Sq{Sq}_Sk{Sk}")
+                        gkv[0], gkv[1], _p(gv), gvv[0], gvv[1], B, H, Sq, Sk, skg, d, float(scale), _stream()),
+          # algorithmic: dQ over all keys (S, dP, dQ) + dK / dV for the keys whose gradient is wanted (2 of the 5 contractions)
+          flops=6.0 * B * H * Sq * Sk * d + 4.0 * B * H * Sq * skg * d, tag="attn_path_bwd", shape=f"B{B}_H{H}_Sq{Sq}_Sk{Sk}")
 
 
 def cross_attn_fwd(q, k, v, o, B, H, Sq, Sk, d, scale, *, probs=None, tok=-1, cond_only=False,

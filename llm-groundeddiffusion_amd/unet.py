@@ -349,15 +349,18 @@ class Plan:
             gq, gk, gv = g, g[:, C:], g[:, 2 * C:]
             pad = Sk > S
 
-            # query-gradient rows of the 30 grounding tokens stay zero (they have no queries): only that slice is
-            # cleared — the backward kernels overwrite every other element of the fused [q | k | v] gradient
-            gq_tail = g.view(B, Sk, 3 * C)[:, S:, :C] if pad else None
+            # the gradient rows of the 30 grounding tokens are cleared whole (round 6): they have no queries, and their
+            # key / value gradients are not computed — those rows of the concatenated input are constants of a run
+            # (nothing reads the gradient behind them: the LayerNorm backward takes the visual rows only), and the key
+            # block holding them cost the dK/dV pass an extra round of workgroups (sk_grad = S: lgd_attn_bwd_keys_f16).
+            # The backward kernels overwrite every other element of the fused [q | k | v] gradient
+            g_tail = g.view(B, Sk, 3 * C)[:, S:, :] if pad else None
 
             def run():
                 if pad:
-                    ops.zero_(gq_tail)
+                    ops.zero_(g_tail)
                 ops.attn_bwd(qt, kt, vt, o.t, o.g, lse, delta, gq, gk, gv, B, heads, S, Sk, d, scale,
-                             q_view=view, k_view=view, v_view=view, gq_view=view, gk_view=view, gv_view=view)
+                             q_view=view, k_view=view, v_view=view, gq_view=view, gk_view=view, gv_view=view, sk_grad=S)
             return run
         self._add(fwd, make_bwd, [qkv])
         return o

@@ -472,6 +472,32 @@ def test_attn_fwd_bwd(dev, B, H, Sq, Sk, d):
     assert relerr(gv, un(vr.grad, Sk)) < 1e-2
 
 
+@pytest.mark.parametrize("B,H,S,d", [(2, 8, 4096, 40), (2, 8, 1024, 80), (4, 8, 256, 160), (1, 3, 200, 40)])
+def test_attn_bwd_key_gradients_for_the_visual_rows_only(dev, B, H, S, d):
+    """lgd_attn_bwd_keys_f16 (ABI v10): the GLIGEN fuser's attention over [S visual ; 30 grounding] keys with dK / dV wanted for
+    the S visual keys only (attention.py:43-53: the grounding rows are constants of a run) — dQ and the first S rows of dK / dV
+    bit-identical to the full backward, rows >= S untouched."""
+    Sk, C, scale = S + 30, H * d, d ** -0.5
+    q = rnd(B, S, C, dev=dev, seed=1).half()
+    k = rnd(B, Sk, C, dev=dev, seed=2).half()
+    v = rnd(B, Sk, C, dev=dev, seed=3).half()
+    go = rnd(B, S, C, dev=dev, seed=4).half()
+    o = torch.empty(B, S, C, device=dev, dtype=H16)
+    lse = torch.empty(B, H, S, device=dev)
+    ops.attn_fwd(q, k, v, o, B, H, S, Sk, d, scale, lse=lse)
+    outs = []
+    for skg in (None, S):
+        gq, gk, gv = torch.full_like(q, 7.0), torch.full_like(k, 7.0), torch.full_like(v, 7.0)
+        delta = torch.empty(B, H, S, device=dev)
+        ops.attn_bwd(q, k, v, o, go, lse, delta, gq, gk, gv, B, H, S, Sk, d, scale, sk_grad=skg)
+        outs.append((gq, gk, gv))
+    (gq0, gk0, gv0), (gq1, gk1, gv1) = outs
+    assert torch.equal(gq0, gq1)
+    assert torch.equal(gk0[:, :S], gk1[:, :S]) and torch.equal(gv0[:, :S], gv1[:, :S])
+    assert bool((gk1[:, S:] == 7.0).all()) and bool((gv1[:, S:] == 7.0).all())
+    assert not bool((gk0[:, S:] == 7.0).all())
+
+
 @pytest.mark.parametrize("B,H,Sq,Sk,d", [
     (2, 8, 4096, 4096, 40), (1, 8, 300, 333, 40), (2, 8, 1024, 1054, 80), (1, 3, 77, 64, 40), (1, 2, 256, 1, 80),
     (1, 8, 4096, 4126, 40), (1, 4, 129, 257, 24), (1, 2, 500, 190, 56), (1, 2, 64, 700, 88),
