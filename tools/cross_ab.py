@@ -1,5 +1,5 @@
-"""GPU-box tool: cross-attention forward WITHOUT map capture (77 text keys) — the exact two-pass kernel of
-lgd_cross_attn_fwd_f16 against the flash self-attention entry point on the same operands; graph-captured timing."""
+"""GPU-box tool: cross-attention forward WITHOUT map capture (77 text keys) — the flash kernels (option cross_resident = 0)
+against the resident-keys kernel of round 6 on the same operands; graph-captured timing (the option is read at launch, i.e. at capture)."""
 import os
 import sys
 
@@ -47,11 +47,18 @@ for (B, H, S, d) in [(16, 8, 4096, 40), (8, 8, 4096, 40), (4, 8, 4096, 40), (16,
     o1 = torch.zeros(B, S, C, device=dev, dtype=torch.float16)
     o2 = torch.zeros(B, S, C, device=dev, dtype=torch.float16)
     f1 = lambda: ops.cross_attn_fwd(q, k, v, o1, B, H, S, T, d, d ** -0.5, k_view=view, v_view=view)
-    f2 = lambda: ops.attn_fwd(q, k, v, o2, B, H, S, T, d, d ** -0.5, k_view=view, v_view=view)
-    f1(); f2(); torch.cuda.synchronize()
+    f2 = lambda: ops.cross_attn_fwd(q, k, v, o2, B, H, S, T, d, d ** -0.5, k_view=view, v_view=view)
+    ops.set_option("cross_resident", 0)
+    f1()
+    ops.set_option("cross_resident", 1)
+    f2(); torch.cuda.synchronize()
     sl = slice(0, d)
     p = (q[0, :, sl].float() @ kv[0, :, sl].float().t() * d ** -0.5).softmax(-1)
     ref = p @ kv[0, :, C:C + d].float()
     e1 = float((o1[0, :, sl].float() - ref).abs().max() / ref.abs().max())
     e2 = float((o2[0, :, sl].float() - ref).abs().max() / ref.abs().max())
-    print(f"B{B} S{S} d{d}: two-pass {timeit(f1):6.1f} us (err {e1:.1e})   flash {timeit(f2):6.1f} us (err {e2:.1e})", flush=True)
+    ops.set_option("cross_resident", 0)
+    t1 = timeit(f1)
+    ops.set_option("cross_resident", 1)
+    t2 = timeit(f2)
+    print(f"B{B} S{S} d{d}: flash kernels {t1:6.1f} us (err {e1:.1e})   resident keys {t2:6.1f} us (err {e2:.1e})  x{t1 / t2:.2f}  {4.0 * B * S * C / t2 * 1e-6:.2f} TB/s of Q + O", flush=True)

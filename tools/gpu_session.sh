@@ -192,5 +192,12 @@ json.dump(old, open("$OUT/merged.json", "w"), indent=1)
 print("merged:", list(old["shapes"]))
 PY
     find $OUT -name '*.csv' -delete 2>/dev/null ;;
+  tune_vae)   # the VAE decoder's GEMM shapes (decode batches 1, 2) added to the latency table; the untuned shapes only
+    cp llm-groundeddiffusion_amd/tuning_gfx950.json $OUT/latency.json
+    LGD_TUNE_VAE=${1:-1,2} timeout ${TUNE_TIMEOUT:-900} python tools/tune_gemm.py sd14_gligen $OUT/latency.json > $OUT/tune.log 2>&1
+    echo "tune rc=$?"; grep -c "TF/s" $OUT/tune.log; grep "VAE decode\|sum over\|REJECTED" $OUT/tune.log; tail -n 30 $OUT/tune.log | cut -c1-160
+    for f in "" "--no-decode"; do python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-roofline $f 2>&1 | grep "^{" | cut -c1-120; done
+    cp $OUT/latency.json llm-groundeddiffusion_amd/tuning_gfx950.json
+    python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-roofline 2>&1 | grep "^{" | cut -c1-120 ;;
   *) echo "unknown stage $STAGE"; exit 2 ;;
 esac

@@ -53,6 +53,15 @@ else:
     for kind, fz, nb, fn in sm.profile_passes(L, 50, cfg.use_gated_attention, main_batches=batches,
                                               guide_batches=gbatches):
         fn()
+if os.environ.get("LGD_TUNE_VAE") and not XL:
+    # round 6: the VAE decodes inside the timed region (2.6 % of the default line) ran on heuristic tiles: their GEMM /
+    # implicit-conv shapes for the decode batches the pipelines use (LGD_TUNE_VAE="1,2": one final image, two per-box images)
+    from lgd_amd.vae import make_hip_vae
+    hv = make_hip_vae(dev)
+    n_before = len(shapes)
+    for b_ in (int(x) for x in os.environ["LGD_TUNE_VAE"].split(",")):
+        hv.decode(torch.zeros(b_, 4, L, L, device=dev))
+    print(f"VAE decode: {len(shapes) - n_before} further shapes")
 torch.cuda.synchronize()
 ops.gemm_launch = orig
 print(f"{len(shapes)} distinct GEMM shapes")
@@ -181,6 +190,8 @@ for key, sh in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"
             continue
         if tile in PLAIN_ONLY and (sh["taps"] != 1 or sh["c1"] > 0):
             continue
+        if (tile in PLAIN_ONLY or tile in PHASE) and not key.endswith("_b1"):
+            continue   # one matrix per launch: batched problems (the VAE's mid-block attention GEMMs) keep the older tiles
         if tile in PHASE and (sh["c1"] > 0 or (sh["taps"] == 9 and (sh["stride"] != 1 or sh["ups"] != 0 or sh["hin"] != sh["hout"]))):
             continue
         wgs = -(-M // bm) * -(-N // bn)
