@@ -986,168 +986,6 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_self32_kernel(const AttnArg
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Cross-attention forward WITHOUT map capture over <= 96 keys (the 77 text tokens; round 6).  The flash kernels stage
-// K / V^T per 64 .. 256 queries, clear two LDS stages and run an online softmax over two key tiles of which the second
-// is 80 % padding: at the 64x64 level (B = 16: 524 288 queries x 77 keys, 84 MB of Q and O) that took 39 us = 2.1 TB/s.
-// Here the keys stay RESIDENT: a workgroup stages K (row-major) and V^T of its (image, head) once and streams a chunk of
-// queries — every wave walks 16-query tiles, the next tile's Q fragment in flight while the current one is multiplied;
-// all <= 96 keys of a query sit in registers (6 accumulator tiles: lane = query lane & 15, keys kt*16 + (lane>>4)*4 + r),
-// so the softmax is exact, not online.  S^T = K Q^T, P = softmax(scale S), O^T = V^T P^T (same operand layouts as
-// attn_fwd_kernel).  grid = (chunks, H, B).
-// ---------------------------------------------------------------------------------------------
-constexpr int XF_KEYS = 96;
-constexpr int XF_VLD = XF_KEYS + 8;           // halfs per V^T row
-
-template <int DP>
-__global__ __launch_bounds__(256) void cross_fwd_resident_kernel(const AttnArgs a, int chunk) {
-  constexpr int K_LD = DP + 16;
-  constexpr int NDC = DP / 32;
-  constexpr int NDT = DP / 16;
-  constexpr int KSEG = DP / 8;
-  __shared__ __attribute__((aligned(16))) half_t smem[XF_KEYS * K_LD + DP * XF_VLD];
-  half_t* Ks = smem;
-  half_t* Vt = smem + XF_KEYS * K_LD;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int g = lane >> 4, c16 = lane & 15;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int d = a.d;
-  const half_t* Qb = a.q + (long)b * a.q_bs + (long)h * d;
-  const half_t* Kb = a.k + (long)b * a.k_bs + (long)h * d;
-  const half_t* Vb = a.v + (long)b * a.v_bs + (long)h * d;
-  half_t* Ob = a.o + (long)b * a.o_bs + (long)h * d;
-
-  // ---- K row-major and V^T, zero-padded to 96 keys x DP
-  for (int idx = tid; idx < XF_KEYS * KSEG; idx += 256) {
-    const int row = idx / KSEG, seg = idx - row * KSEG;
-    const bool ok = row < a.Sk && seg * 8 < d;
-    const uint4 kv = ok ? *reinterpret_cast<const uint4*>(Kb + (long)row * a.ldk + seg * 8) : make_uint4(0, 0, 0, 0);
-    *reinterpret_cast<uint4*>(Ks + row * K_LD + seg * 8) = kv;
-  }
-  for (int idx = tid; idx < (XF_KEYS / 2) * KSEG; idx += 256) {
-    const int pair = idx % (XF_KEYS / 2), seg = idx / (XF_KEYS / 2);
-    uint4 v2[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int row = pair * 2 + r;
-      v2[r] = (row < a.Sk && seg * 8 < d) ? *reinterpret_cast<const uint4*>(Vb + (long)row * a.ldv + seg * 8) : make_uint4(0, 0, 0, 0);
-    }
-    const half_t* e0 = reinterpret_cast<const half_t*>(&v2[0]);
-    const half_t* e1 = reinterpret_cast<const half_t*>(&v2[1]);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      half2_t pr = {e0[e], e1[e]};
-      *reinterpret_cast<half2_t*>(Vt + (seg * 8 + e) * XF_VLD + pair * 2) = pr;
-    }
-  }
-  __syncthreads();
-
-  const int q_beg = blockIdx.x * chunk;
-  int q_end = q_beg + chunk;
-  if (q_end > a.Sq) q_end = a.Sq;
-  auto load_q = [&](int q0, half8_t (&qf)[NDC]) {
-    const int qrow = q0 + c16;
-#pragma unroll
-    for (int dc = 0; dc < NDC; ++dc) {
-      const int dd = dc * 32 + g * 8;
-      qf[dc] = (qrow < q_end && dd < d) ? *reinterpret_cast<const half8_t*>(Qb + (long)qrow * a.ldq + dd)
-                                        : (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
-    }
-  };
-  half8_t qn[NDC];
-  int q0 = q_beg + wid * 16;
-  if (q0 < q_end) load_q(q0, qn);
-  for (; q0 < q_end; q0 += 64) {
-    half8_t qf[NDC];
-#pragma unroll
-    for (int dc = 0; dc < NDC; ++dc) qf[dc] = qn[dc];
-    if (q0 + 64 < q_end) load_q(q0 + 64, qn);                 // next tile's fragment in flight
-    // ---- S^T (log2 domain), padded keys masked
-    f32x4 s[6];
-    float mx = NEG_BIG;
-#pragma unroll
-    for (int kt = 0; kt < 6; ++kt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int dc = 0; dc < NDC; ++dc) {
-        const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kt * 16 + c16) * K_LD + dc * 32 + g * 8);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[dc], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + g * 4 + r;
-        s[kt][r] = key < a.Sk ? acc[r] * a.scale_log2 : NEG_BIG;
-        mx = fmaxf(mx, s[kt][r]);
-      }
-    }
-    mx = quad_row_max(mx);
-    float l = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 6; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx);
-        l += s[kt][r];
-      }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv_l = 1.f / l;
-    // ---- O^T = V^T P^T over three 32-key chunks
-    f32x4 oacc[NDT];
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      half8_t pf;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pf[r] = (half_t)(s[2 * c][r] * inv_l);
-        pf[4 + r] = (half_t)(s[2 * c + 1][r] * inv_l);
-      }
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) {
-        const half_t* vrow = Vt + (dt * 16 + c16) * XF_VLD + c * 32 + g * 4;
-        const half4_t lo = *reinterpret_cast<const half4_t*>(vrow);
-        const half4_t hi = *reinterpret_cast<const half4_t*>(vrow + 16);
-        const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
-      }
-    }
-    const int qrow = q0 + c16;
-    if (qrow < q_end) {
-      half_t* out = Ob + (long)qrow * a.ldo;
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) {
-        const int dv = dt * 16 + g * 4;
-        if (dv < d) {
-          half4_t o4;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o4[r] = (half_t)oacc[dt][r];
-          *reinterpret_cast<half4_t*>(out + dv) = o4;
-        }
-      }
-    }
-  }
-}
-
-// option "cross_resident": 1 = (default) cross-attention forward without map capture over <= 96 keys runs the
-// resident-keys kernel, 0 = the flash kernels
-int g_cross_resident = 1;
-
-template <int DP>
-bool launch_cross_resident(const AttnArgs& a, hipStream_t st) {
-  if (!g_cross_resident || a.Sk > XF_KEYS || a.causal || a.lse || a.probs || (a.ldo % 4) || (a.d % 4)) return false;
-  // about two workgroups per CU, chunks of whole 64-query rounds, at least 256 queries per staging of K / V^T where there are
-  const long pairs = (long)a.B * a.H;
-  long per = ((long)a.Sq * pairs + 511) / 512;
-  per = (per + 63) / 64 * 64;
-  if (per < 256) per = 256;
-  if (per > a.Sq) per = (a.Sq + 63) / 64 * 64;
-  dim3 grid((unsigned)((a.Sq + per - 1) / per), a.H, a.B);
-  hipLaunchKernelGGL((cross_fwd_resident_kernel<DP>), grid, dim3(256), 0, st, a, (int)per);
-  return true;
-}
-
 template <int DP, bool SAVE_P>
 void launch_attn_dp(const AttnArgs& a, hipStream_t st) {
   if constexpr (SAVE_P) {
@@ -1237,15 +1075,6 @@ template <bool SAVE_P>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
   const int d = a.d;
   if constexpr (!SAVE_P) {
-    if (a.Sk <= XF_KEYS && !a.lse) {
-      bool done = false;
-      if (d <= 32) done = launch_cross_resident<32>(a, st);
-      else if (d <= 64) done = launch_cross_resident<64>(a, st);
-      else if (d <= 96) done = launch_cross_resident<96>(a, st);
-      else if (d <= 128) done = launch_cross_resident<128>(a, st);
-      else if (d <= 160) done = launch_cross_resident<160>(a, st);
-      if (done) return lgd_check_launch();
-    }
     // d = 40 (SD1.x 64x64 level): the one-wave-per-SIMD kernel of attn_w4.hip once a launch has enough 256-query
     // workgroups to occupy the chip (it holds ONE workgroup per CU); smaller problems keep the 4-waves-per-SIMD kernel
     const int w4 = attn_w4_mode();
@@ -1280,7 +1109,6 @@ void lgd_gn_set_apply_wgs(int n);                          // norm.hip
 extern "C" int lgd_set_option(const char* name, int value) {
   if (!name) return LGD_ERR_ARG;
   if (!strcmp(name, "gn_fused") && value >= 0 && value <= 4096) { lgd_gn_set_fused_hw(value); return LGD_OK; }
-  if (!strcmp(name, "cross_resident") && (value == 0 || value == 1)) { g_cross_resident = value; return LGD_OK; }
   if (!strcmp(name, "gn_slab") && (value == 0 || value == 1)) { lgd_gn_set_slab(value); return LGD_OK; }
   if (!strcmp(name, "ln_stream") && (value == 0 || value == 1)) { lgd_ln_set_stream(value); return LGD_OK; }
   if (!strcmp(name, "gn_apply_wgs") && value >= 64 && value <= 8192) { lgd_gn_set_apply_wgs(value); return LGD_OK; }
